@@ -1,0 +1,330 @@
+/* oracle/av1o_search.c -- phase 1: per-tile partition / mode / tx-type RDO with reconstruction.
+ * TEST INFRASTRUCTURE (see av1o.h).
+ * Structure follows rav1e (all absent from /root/reference):
+ *   encode_partition_topdown + rdo_partition_decision  -> rd_partition()
+ *   rdo_mode_decision / intra_frame_rdo_mode_decision  -> try_block(): SATD pre-filter, then full RD
+ *   rdo_tx_type_decision                               -> loop over the intra tx set per surviving mode
+ *   rdo_cfl_alpha                                      -> cfl_search()
+ * Deliberate simplifications (documented in DESIGN.md): rates come from the frame's initial CDFs (no
+ * in-tile adaptation during search), distortion is plain SSE, square partitions only, TX_MODE_LARGEST. */
+#include "av1o_int.h"
+#include "av1o_syms.h"
+
+static const uint8_t intra_mode_ctx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };
+
+typedef struct {
+  Av1oFrame *f; TileB t;
+  int64_t wq[3];           /* plane distortion weights, Q12 */
+} Search;
+
+typedef struct {            /* saved state of one block area (for NONE-vs-SPLIT comparison) */
+  int n;
+  uint16_t rec[3][64 * 64];
+  int32_t coef[3][64 * 64];
+  uint8_t maps[10][16 * 16];
+  uint8_t lvl[3][16 * 16], dc[3][16 * 16];
+  uint16_t eob[3][16 * 16];
+} AreaSnap;
+
+static uint8_t *map_ptr(Av1oFrame *f, int i) {
+  switch (i) {
+    case 0: return f->m_bsize; case 1: return f->m_skip; case 2: return f->m_ymode; case 3: return f->m_uvmode;
+    case 4: return f->m_txtype; case 5: return f->m_cfl_sign; case 6: return f->m_cfl_au; case 7: return f->m_cfl_av;
+    case 8: return (uint8_t *)f->m_angle_y; default: return (uint8_t *)f->m_angle_uv;
+  }
+}
+static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save) {
+  const int n = 4 << bs, n4 = 1 << bs;
+  s->n = n;
+  for (int p = 0; p < f->np; p++) {
+    for (int i = 0; i < n; i++) {
+      uint16_t *fr = f->rec[p] + (r * 4 + i) * f->stride + c * 4;
+      int32_t *fc = f->coef[p] + (r * 4 + i) * f->stride + c * 4;
+      if (save) { memcpy(s->rec[p] + i * n, fr, 2 * (size_t)n); memcpy(s->coef[p] + i * n, fc, 4 * (size_t)n); }
+      else { memcpy(fr, s->rec[p] + i * n, 2 * (size_t)n); memcpy(fc, s->coef[p] + i * n, 4 * (size_t)n); }
+    }
+    for (int i = 0; i < n4; i++) {
+      int o = (r + i) * f->mi_stride + c;
+      if (save) { memcpy(s->lvl[p] + i * n4, f->m_lvl[p] + o, (size_t)n4); memcpy(s->dc[p] + i * n4, f->m_dc[p] + o, (size_t)n4); memcpy(s->eob[p] + i * n4, f->m_eob[p] + o, 2 * (size_t)n4); }
+      else { memcpy(f->m_lvl[p] + o, s->lvl[p] + i * n4, (size_t)n4); memcpy(f->m_dc[p] + o, s->dc[p] + i * n4, (size_t)n4); memcpy(f->m_eob[p] + o, s->eob[p] + i * n4, 2 * (size_t)n4); }
+    }
+  }
+  for (int m = 0; m < 10; m++) {
+    uint8_t *mp = map_ptr(f, m);
+    for (int i = 0; i < n4; i++) {
+      if (save) memcpy(s->maps[m] + i * n4, mp + (r + i) * f->mi_stride + c, (size_t)n4);
+      else memcpy(mp + (r + i) * f->mi_stride + c, s->maps[m] + i * n4, (size_t)n4);
+    }
+  }
+}
+static void set_decoded(Av1oFrame *f, int r, int c, int bs, int v) {
+  const int n4 = 1 << bs;
+  for (int i = 0; i < n4; i++) memset(f->m_decoded + (r + i) * f->mi_stride + c, v, (size_t)n4);
+}
+static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) {
+  for (int i = 0; i < n4; i++) memset(m + (r + i) * ms + c, v, (size_t)n4);
+}
+
+/* 4x4 Hadamard SATD summed over the block (rav1e get_satd uses 8x8 for larger blocks) */
+static int64_t satd_block(const uint16_t *src, int ss, const uint16_t *pred, int ps, int n) {
+  int64_t total = 0;
+  for (int by = 0; by < n; by += 4) for (int bx = 0; bx < n; bx += 4) {
+    int d[16], t[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) d[i * 4 + j] = (int)src[(by + i) * ss + bx + j] - (int)pred[(by + i) * ps + bx + j];
+    for (int i = 0; i < 4; i++) {
+      int a = d[i * 4] + d[i * 4 + 1], b = d[i * 4] - d[i * 4 + 1], c2 = d[i * 4 + 2] + d[i * 4 + 3], e = d[i * 4 + 2] - d[i * 4 + 3];
+      t[i * 4] = a + c2; t[i * 4 + 1] = b + e; t[i * 4 + 2] = a - c2; t[i * 4 + 3] = b - e;
+    }
+    int s = 0;
+    for (int j = 0; j < 4; j++) {
+      int a = t[j] + t[4 + j], b = t[j] - t[4 + j], c2 = t[8 + j] + t[12 + j], e = t[8 + j] - t[12 + j];
+      s += iabs(a + c2) + iabs(b + e) + iabs(a - c2) + iabs(b - e);
+    }
+    total += s;
+  }
+  return total;
+}
+static int64_t sse_block(const uint16_t *a, int as, const uint16_t *b, int bs_, int n) {
+  int64_t s = 0;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { int d = (int)a[i * as + j] - (int)b[i * bs_ + j]; s += (int64_t)d * d; }
+  return s;
+}
+
+/* One transform block: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J. */
+typedef struct { int eob, cul, dcc; int64_t sse; uint32_t rate; } TxRes;
+static int64_t eval_tx(Search *s, int plane, int r, int c, int bs, const uint16_t *pred /* n x n, stride n */, int txtype,
+                       int tx_off, int tx_sym, int tx_ns, uint16_t *rec_out /* n x n */, int32_t *qc_out, TxRes *tr) {
+  Av1oFrame *f = s->f;
+  const int n = 4 << bs, cs = imin(n, 32), x = c * 4, y = r * 4, txs = bs;
+  static int16_t resid[64 * 64]; static int32_t coef[32 * 32], dq[32 * 32];
+  const uint16_t *src = f->src[plane] + y * f->stride + x;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
+  av1o_fwd_txfm2d(resid, n, coef, txs, txtype, f->bd);
+  int eob = av1o_quantize(coef, qc_out, txs, txtype, f->dc_q[plane], f->ac_q[plane]);
+  int sctx, dctx;
+  av1o_txb_ctx(f, &s->t, plane, r, c, txs, bs, &sctx, &dctx);
+  tr->rate = av1o_coef_rate_full(f, qc_out, eob, plane, txs, txtype, sctx, dctx, tx_off, tx_sym, tx_ns, &tr->cul, &tr->dcc);
+  memcpy(rec_out, pred, sizeof(uint16_t) * (size_t)(n * n));
+  if (eob > 0) {
+    av1o_dequantize(qc_out, dq, txs, f->dc_q[plane], f->ac_q[plane], f->bd, eob, txtype);
+    av1o_inv_txfm2d_add(dq, rec_out, n, txs, txtype, f->bd);
+  }
+  tr->eob = eob;
+  tr->sse = sse_block(src, f->stride, rec_out, n, n);
+  (void)cs;
+  return ((tr->sse * s->wq[plane]) >> 5) + (((int64_t)tr->rate * f->rdmult[0] + 256) >> 9);
+}
+
+static void commit_plane(Av1oFrame *f, int plane, int r, int c, int bs, const uint16_t *rec, const int32_t *qc, const TxRes *tr) {
+  const int n = 4 << bs, cs = imin(n, 32), n4 = 1 << bs;
+  for (int i = 0; i < n; i++) memcpy(f->rec[plane] + (r * 4 + i) * f->stride + c * 4, rec + i * n, 2 * (size_t)n);
+  for (int i = 0; i < cs; i++) memcpy(f->coef[plane] + (r * 4 + i) * f->stride + c * 4, qc + i * cs, 4 * (size_t)cs);
+  fill_map(f->m_lvl[plane], f->mi_stride, r, c, n4, tr->cul);
+  fill_map(f->m_dc[plane], f->mi_stride, r, c, n4, tr->dcc);
+  f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)tr->eob;
+}
+
+/* rdo_cfl_alpha: per plane, the alpha (|a| in 1..16, sign) minimising prediction SSE; 0 = CFL_SIGN_ZERO */
+static int cfl_best_alpha(Search *s, int plane, int r, int c, int bs, const uint16_t *dc_pred) {
+  Av1oFrame *f = s->f; const int n = 4 << bs;
+  static uint16_t tmp[64 * 64];
+  const uint16_t *src = f->src[plane] + r * 4 * f->stride + c * 4;
+  int best = 0; int64_t best_sse = sse_block(src, f->stride, dc_pred, n, n);
+  for (int mag = 1; mag <= 16; mag++) for (int sg = 0; sg < 2; sg++) {
+    int alpha = sg ? -mag : mag;
+    memcpy(tmp, dc_pred, 2 * (size_t)(n * n));
+    av1o_predict_cfl(f, plane, c * 4, r * 4, 2 + bs, alpha, tmp, n);
+    int64_t e = sse_block(src, f->stride, tmp, n, n);
+    if (e < best_sse) { best_sse = e; best = alpha; }
+  }
+  return best;
+}
+
+/* Full decision for one block; writes maps/recon/coefs for the area and returns its RD cost. */
+static int64_t try_block(Search *s, int r, int c, int bs) {
+  Av1oFrame *f = s->f; const TileB *t = &s->t;
+  const int n = 4 << bs, n4 = 1 << bs, ms = f->mi_stride, mi = r * ms + c, log2w = 2 + bs, txs = bs;
+  const int x = c * 4, y = r * 4;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int have_ar = availU && (c + n4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + n4];
+  const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
+  const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
+  const uint32_t *ycost = f->cost + CDF_KF_Y + (intra_mode_ctx[amode] * 5 + intra_mode_ctx[lmode]) * CDF_KF_Y_STRIDE;
+  #define IS_SMOOTH(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
+  const int ftype_y = (availU && IS_SMOOTH(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH(f->m_ymode[mi - 1]));
+  const int ftype_uv = (availU && IS_SMOOTH(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH(f->m_uvmode[mi - 1]));
+  static uint16_t pred[64 * 64], rec_best[3][64 * 64], rec_tmp[64 * 64];
+  static int32_t qc_best[3][32 * 32], qc_tmp[32 * 32];
+  const uint16_t *src = f->src[0] + y * f->stride + x;
+
+  /* ---- luma: SATD pre-filter over the 13 modes ---- */
+  int64_t satd[13]; int order[13];
+  for (int m = 0; m < 13; m++) {
+    av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, 0, ftype_y, pred, n);
+    satd[m] = satd_block(src, f->stride, pred, n, n);
+    order[m] = m;
+  }
+  for (int i = 1; i < 13; i++) { int v = order[i], j = i; while (j > 0 && satd[order[j - 1]] > satd[v]) { order[j] = order[j - 1]; j--; } order[j] = v; }
+  const int ncand = f->cfg.complex_modes ? 7 : 3;
+  /* ---- full RD over surviving (mode, angle delta) x tx type ---- */
+  int64_t best_j = INT64_MAX; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
+  int tx_ns, tx_set;
+  for (int ci = 0; ci < ncand; ci++) {
+    const int m = order[ci];
+    int delta = 0;
+    const int directional = m >= V_PRED && m <= D67_PRED;
+    if (directional && bs >= BS_8 && f->cfg.fine_directional) {
+      int64_t bsd = satd[m];
+      static const int dl[6] = { -1, 1, -2, 2, -3, 3 };
+      for (int k = 0; k < 6; k++) {
+        av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, dl[k], ftype_y, pred, n);
+        int64_t sd = satd_block(src, f->stride, pred, n, n);
+        if (sd < bsd) { bsd = sd; delta = dl[k]; }
+      }
+    }
+    av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, delta, ftype_y, pred, n);
+    uint32_t mode_rate = ycost[m];
+    if (directional && bs >= BS_8) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+    const int tx_off = av1o_intra_tx_cdf(f, txs, m, &tx_ns, &tx_set);
+    const int ntx = (f->cfg.rdo_tx && tx_off >= 0) ? tx_ns : 1;
+    for (int ti = 0; ti < ntx; ti++) {
+      int txtype;
+      if (ntx > 1) txtype = av1o_symbol_to_tx_type(tx_set, ti);
+      else { txtype = av1o_mode_to_txtype(m); if (tx_off < 0 || !av1o_tx_type_in_set(tx_set, txtype)) txtype = DCT_DCT; }
+      TxRes tr;
+      int64_t j = eval_tx(s, 0, r, c, bs, pred, txtype, tx_off, tx_off >= 0 ? av1o_tx_type_to_symbol(tx_set, txtype) : 0, tx_ns, rec_tmp, qc_tmp, &tr);
+      j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
+      if (j < best_j) {
+        best_j = j; best_mode = m; best_delta = delta; best_tx = txtype; best_tr = tr;
+        memcpy(rec_best[0], rec_tmp, 2 * (size_t)(n * n)); memcpy(qc_best[0], qc_tmp, 4 * (size_t)imin(n * n, 1024));
+      }
+    }
+  }
+  commit_plane(f, 0, r, c, bs, rec_best[0], qc_best[0], &best_tr);
+  fill_map(f->m_ymode, ms, r, c, n4, best_mode);
+  fill_map((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)best_delta);
+  fill_map(f->m_txtype, ms, r, c, n4, best_tr.eob ? best_tx : DCT_DCT);
+  fill_map(f->m_bsize, ms, r, c, n4, bs);
+  int64_t total_j = best_j; int any_coef = best_tr.eob > 0;
+
+  /* ---- chroma ---- */
+  if (f->np > 1) {
+    const int cfl_allowed = bs <= BS_32;
+    const uint32_t *uvcost = cfl_allowed ? f->cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : f->cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
+    int cands[16], nc = 0;
+    cands[nc++] = DC_PRED;
+    if (best_mode != DC_PRED) cands[nc++] = best_mode;
+    if (f->cfg.complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) cands[nc++] = m;
+    if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
+    int64_t best_uv = INT64_MAX; int buv = DC_PRED, bdelta = 0, bsign = 0, bau = 0, bav = 0; TxRes btr[3];
+    static uint16_t rec_c[3][64 * 64]; static int32_t qc_c[3][32 * 32];
+    for (int ci = 0; ci < nc; ci++) {
+      const int um = cands[ci];
+      int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && bs >= BS_8) ? best_delta : 0;
+      int alpha[3] = { 0, 0, 0 }, jsign = 0;
+      uint32_t mode_rate = uvcost[um];
+      if (um >= V_PRED && um <= D67_PRED && bs >= BS_8) mode_rate += f->cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+      int txtype = av1o_mode_to_txtype(um);
+      if (!av1o_tx_type_in_set(av1o_tx_set(txs, f->cfg.reduced_tx_set), txtype)) txtype = DCT_DCT;
+      int64_t j = 0; TxRes trs[3]; int ok = 1;
+      for (int p = 1; p < 3 && ok; p++) {
+        if (um == UV_CFL_PRED) {
+          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
+          alpha[p] = cfl_best_alpha(s, p, r, c, bs, pred);
+          if (p == 2) {
+            if (alpha[1] == 0 && alpha[2] == 0) { ok = 0; break; }
+            int su = alpha[1] == 0 ? 0 : (alpha[1] < 0 ? 1 : 2), sv = alpha[2] == 0 ? 0 : (alpha[2] < 0 ? 1 : 2);
+            jsign = su * 3 + sv - 1;
+            mode_rate += f->cost[CDF_CFL_SIGN + jsign];
+            if (su) mode_rate += f->cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs(alpha[1]) - 1];
+            if (sv) mode_rate += f->cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs(alpha[2]) - 1];
+          }
+        }
+      }
+      if (!ok) continue;
+      for (int p = 1; p < 3; p++) {
+        if (um == UV_CFL_PRED) {
+          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
+          if (alpha[p]) av1o_predict_cfl(f, p, x, y, log2w, alpha[p], pred, n);
+        } else {
+          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, um, delta, ftype_uv, pred, n);
+        }
+        j += eval_tx(s, p, r, c, bs, pred, txtype, -1, 0, 0, rec_best[p], qc_best[p], &trs[p]);
+      }
+      j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
+      if (j < best_uv) {
+        best_uv = j; buv = um; bdelta = delta; bsign = jsign; bau = alpha[1]; bav = alpha[2]; btr[1] = trs[1]; btr[2] = trs[2];
+        for (int p = 1; p < 3; p++) { memcpy(rec_c[p], rec_best[p], 2 * (size_t)(n * n)); memcpy(qc_c[p], qc_best[p], 4 * (size_t)imin(n * n, 1024)); }
+      }
+    }
+    for (int p = 1; p < 3; p++) { commit_plane(f, p, r, c, bs, rec_c[p], qc_c[p], &btr[p]); any_coef |= btr[p].eob > 0; }
+    fill_map(f->m_uvmode, ms, r, c, n4, buv);
+    fill_map((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)bdelta);
+    fill_map(f->m_cfl_sign, ms, r, c, n4, bsign);
+    fill_map(f->m_cfl_au, ms, r, c, n4, bau ? iabs(bau) - 1 : 0);
+    fill_map(f->m_cfl_av, ms, r, c, n4, bav ? iabs(bav) - 1 : 0);
+    total_j += best_uv;
+  }
+  /* ---- skip flag ---- */
+  const int skip = !any_coef;
+  fill_map(f->m_skip, ms, r, c, n4, skip);
+  if (skip) for (int p = 0; p < f->np; p++) { fill_map(f->m_lvl[p], ms, r, c, n4, 0); fill_map(f->m_dc[p], ms, r, c, n4, 0); }
+  const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
+  total_j += ((int64_t)f->cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult[0] + 256) >> 9;
+  set_decoded(f, r, c, bs, 1);
+  return total_j;
+}
+
+static uint32_t partition_rate(Search *s, int r, int c, int bs, int part) {
+  Av1oFrame *f = s->f; const TileB *t = &s->t; const int ms = f->mi_stride;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+  return f->cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
+}
+
+/* encode_partition_topdown */
+static void rd_partition(Search *s, int r, int c, int bs) {
+  Av1oFrame *f = s->f;
+  if (r >= f->mi_rows || c >= f->mi_cols) return;
+  const int half = (1 << bs) >> 1, px = 4 << bs;
+  const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
+  const int must_split = bs > BS_4 && (px > f->cfg.part_max || !has_rows || !has_cols);
+  const int can_split = bs > BS_4 && (px > f->cfg.part_min || must_split);
+  set_decoded(f, r, c, bs, 0);
+  if (!can_split) { try_block(s, r, c, bs); return; }
+  int do_split = must_split;
+  if (!must_split) {
+    static AreaSnap snap[5];
+    int64_t j_none = try_block(s, r, c, bs) + (((int64_t)partition_rate(s, r, c, bs, PARTITION_NONE) * f->rdmult[0] + 256) >> 9);
+    area_copy(f, &snap[bs], r, c, bs, 1);
+    set_decoded(f, r, c, bs, 0);
+    int64_t j_split = ((int64_t)partition_rate(s, r, c, bs, PARTITION_SPLIT) * f->rdmult[0] + 256) >> 9;
+    for (int k = 0; k < 4 && j_split < j_none; k++) {
+      int rr = r + (k >> 1) * half, cc = c + (k & 1) * half;
+      if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
+      j_split += try_block(s, rr, cc, bs - 1);
+      if (bs - 1 >= BS_8) j_split += ((int64_t)partition_rate(s, rr, cc, bs - 1, PARTITION_NONE) * f->rdmult[0] + 256) >> 9;
+    }
+    if (j_split < j_none) do_split = 1;
+    else { area_copy(f, &snap[bs], r, c, bs, 0); set_decoded(f, r, c, bs, 1); }
+  }
+  if (do_split) {
+    set_decoded(f, r, c, bs, 0);
+    /* m_bsize of the area must not look like an undivided block to later context derivations */
+    rd_partition(s, r, c, bs - 1); rd_partition(s, r, c + half, bs - 1);
+    rd_partition(s, r + half, c, bs - 1); rd_partition(s, r + half, c + half, bs - 1);
+  }
+}
+
+void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
+  Search s; s.f = f;
+  s.t.mi_row_start = f->tile_row_start[tile_row] * SB_MI; s.t.mi_row_end = imin(f->tile_row_start[tile_row + 1] * SB_MI, f->mi_rows);
+  s.t.mi_col_start = f->tile_col_start[tile_col] * SB_MI; s.t.mi_col_end = imin(f->tile_col_start[tile_col + 1] * SB_MI, f->mi_cols);
+  for (int p = 0; p < f->np; p++) {
+    /* (q_y / q_p)^2 in Q12 == rav1e dist_scale */
+    s.wq[p] = (((int64_t)f->ac_q[0] * f->ac_q[0]) << 12) / ((int64_t)f->ac_q[p] * f->ac_q[p]);
+  }
+  for (int r = s.t.mi_row_start; r < s.t.mi_row_end; r += SB_MI)
+    for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI)
+      rd_partition(&s, r, c, BS_64);
+}
