@@ -1,0 +1,130 @@
+// dev_common.h -- device-side frame descriptor and wave helpers for the MI355X AV1 intra path.
+// One wavefront (64 lanes) owns one tile during the search and entropy-coding kernels; all
+// cross-lane traffic is wave shuffles or that wave's own LDS region.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "av1_tables.h"
+
+#define MI_MAX_TILE_COLS 64
+#define MI_MAX_TILE_ROWS 64
+
+enum { BS_4 = 0, BS_8 = 1, BS_16 = 2, BS_32 = 3, BS_64 = 4 };
+enum { DC_PRED = 0, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED,
+       SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED, PAETH_PRED, UV_CFL_PRED };
+enum { DCT_DCT = 0, ADST_DCT, DCT_ADST, ADST_ADST, FLIPADST_DCT, DCT_FLIPADST, FLIPADST_FLIPADST,
+       ADST_FLIPADST, FLIPADST_ADST, IDTX, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST };
+enum { TXC_2D = 0, TXC_HORIZ = 1, TXC_VERT = 2 };
+
+// Everything a kernel needs to know about one plane-set being encoded (one AV1 frame: the colour
+// image or the alpha plane of one input image).  Lives in device memory; pointers are device pointers.
+struct FrameDev {
+  int w, h, bd, np;
+  int mi_cols, mi_rows, sb_cols, sb_rows;
+  int pw, ph, stride, mi_stride, mi_h;
+  uint16_t *src[3], *rec[3], *fin[3];      // source, in-loop reconstruction, post-CDEF output
+  int32_t *coef[3];
+  uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av, *m_decoded;
+  int8_t *m_angle_y, *m_angle_uv;
+  uint8_t *m_lvl[3], *m_dc[3];
+  uint16_t *m_eob[3];
+  int8_t *cdef_idx;
+  // quantizer / lambda
+  int base_q_idx, qctx, dc_q[3], ac_q[3];
+  long long rdmult, wq[3];
+  // tools
+  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, enable_cdef;
+  // tiles (SB units)
+  int tile_cols, tile_rows, tile_cols_log2, tile_rows_log2;
+  int tile_col_start[MI_MAX_TILE_COLS + 1], tile_row_start[MI_MAX_TILE_ROWS + 1];
+  // static rate table (cost per symbol in 1/512 bit, same flat layout as the CDF context) + initial CDFs
+  const uint16_t *cost;      // [CDF_TOTAL]
+  const uint16_t *cdf0;      // [CDF_TOTAL]
+  // loop filter / cdef
+  int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
+  // per-tile scratch + outputs
+  uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
+  uint8_t *tile_out;         // per tile: tile_out_cap bytes
+  uint32_t *tile_len;        // per tile
+  uint32_t tile_out_cap;
+  int tile_base;             // index of this frame's first tile in the launch-wide tile list
+  int dbg;                   // debug bisect level (0 = off)
+};
+
+struct TileJob { int frame; int tile_row, tile_col; };
+
+#define LANE ((int)(threadIdx.x & 63))
+
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int iclamp_(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs_(int a) { return a < 0 ? -a : a; }
+__device__ __forceinline__ int round2_(int x, int n) { return n == 0 ? x : (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    int lo = __shfl_xor((int)(v & 0xffffffffLL), o, 64);
+    int hi = __shfl_xor((int)(v >> 32), o, 64);
+    v += ((long long)hi << 32) | (unsigned int)lo;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = imax_(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_or_i32(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+// single-wave workgroup: orders this wave's LDS/global traffic between phases
+#define WAVE_SYNC() __syncthreads()
+
+struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };
+
+__device__ __forceinline__ int tx_set_of(int txs, int reduced) { return txs >= 3 ? 0 : (reduced ? 2 : (txs == 2 ? 2 : 1)); }
+__device__ __forceinline__ int tx_set_count(int set) { return set == 0 ? 1 : (set == 1 ? 7 : 5); }
+__device__ __forceinline__ int sym_to_txtype(int set, int s) {
+  if (set == 0) return DCT_DCT;
+  if (set == 1) { const int t[7] = { IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST }; return t[s]; }
+  const int t2[5] = { IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST }; return t2[s];
+}
+__device__ __forceinline__ int txtype_to_sym(int set, int t) {
+  const int n = tx_set_count(set);
+  for (int i = 0; i < n; i++) if (sym_to_txtype(set, i) == t) return i;
+  return -1;
+}
+__device__ __forceinline__ int mode_to_txtype(int m) {
+  const int t[14] = { DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT, ADST_ADST, ADST_DCT, DCT_ADST, ADST_ADST, DCT_DCT };
+  return t[m];
+}
+__device__ __forceinline__ int tx_class_of(int t) {
+  if (t == V_DCT || t == V_ADST || t == V_FLIPADST) return TXC_VERT;
+  if (t == H_DCT || t == H_ADST || t == H_FLIPADST) return TXC_HORIZ;
+  return TXC_2D;
+}
+// scan position i -> raster position within the n x n coded area (n = min(32, tx size))
+__device__ __forceinline__ int scan_pos(int n, int cls, int i) {
+  if (cls == TXC_2D) {
+    switch (n) { case 4: return av1_default_scan_4x4[i]; case 8: return av1_default_scan_8x8[i];
+                 case 16: return av1_default_scan_16x16[i]; default: return av1_default_scan_32x32[i]; }
+  }
+  if (cls == TXC_VERT) return i;                       // mrow scan
+  const int c = i / n, r = i - c * n; return r * n + c; // mcol scan
+}
+// intra tx-type CDF row for luma; returns -1 when the type is not signalled
+__device__ __forceinline__ int intra_tx_cdf(const FrameDev *f, int txs, int ymode, int *nsyms, int *set_out) {
+  const int set = tx_set_of(txs, f->reduced_tx_set);
+  *set_out = set;
+  if (set == 0 || f->base_q_idx == 0) { *nsyms = 0; return -1; }
+  if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + (txs * 13 + ymode) * CDF_INTRA_TX1_STRIDE; }
+  *nsyms = 5; return CDF_INTRA_TX2 + (txs * 13 + ymode) * CDF_INTRA_TX2_STRIDE;
+}

@@ -1,0 +1,132 @@
+// dev_rate.h -- coefficient-coding contexts (spec 5.11.39 coeffs() + its CDF selection) evaluated in
+// parallel: every lane prices the symbols of its own scan positions against the frame's static rate
+// table and the wave sums the result.  rav1e prices candidates with a counting writer over adaptive CDFs
+// (src/context/*.rs, absent from /root/reference); see DESIGN.md for the static-table divergence.
+#pragma once
+#include "dev_common.h"
+
+// all_zero and dc_sign contexts from the level/dc maps left by the neighbours (inside the tile only)
+__device__ inline void txb_ctx_dev(const FrameDev *f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
+  const int w4 = 1 << txs, ms = f->mi_stride;
+  int top = 0, left = 0, dcs = 0, any_a = 0, any_l = 0;
+  const int k = LANE;
+  if (k < w4) {
+    if (r4 - 1 >= t->mi_row_start && c4 + k < f->mi_cols) {
+      const int l = f->m_lvl[plane][(r4 - 1) * ms + c4 + k], d = f->m_dc[plane][(r4 - 1) * ms + c4 + k];
+      top = l; any_a = l | d; dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+    }
+    if (c4 - 1 >= t->mi_col_start && r4 + k < f->mi_rows) {
+      const int l = f->m_lvl[plane][(r4 + k) * ms + c4 - 1], d = f->m_dc[plane][(r4 + k) * ms + c4 - 1];
+      left = l; any_l = l | d; dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+    }
+  }
+  top = wave_max_i32(top); left = wave_max_i32(left); dcs = wave_sum_i32(dcs);
+  any_a = wave_or_i32(any_a); any_l = wave_or_i32(any_l);
+  *dc_ctx = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+  if (plane == 0) {
+    int ctx;
+    if (bs == txs) ctx = 0;
+    else if (top == 0 && left == 0) ctx = 1;
+    else if (top == 0 || left == 0) ctx = 2 + (imax_(top, left) > 3);
+    else if (imax_(top, left) <= 3) ctx = 4;
+    else if (imin_(top, left) <= 3) ctx = 5;
+    else ctx = 6;
+    *skip_ctx = ctx;
+  } else {
+    *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (bs > txs ? 3 : 0);
+  }
+}
+
+__device__ __forceinline__ int eob_to_pt(int eob) { return eob < 3 ? eob : (32 - __clz(eob - 1) + 1); }
+__device__ __forceinline__ int eob_pt_cdf(int eob_multi, int pt, int cls) {
+  const int off[7] = { CDF_EOB_PT_16, CDF_EOB_PT_32, CDF_EOB_PT_64, CDF_EOB_PT_128, CDF_EOB_PT_256, CDF_EOB_PT_512, CDF_EOB_PT_1024 };
+  const int str[7] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_32_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_128_STRIDE,
+                       CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_512_STRIDE, CDF_EOB_PT_1024_STRIDE };
+  return off[eob_multi] + (pt * 2 + (cls == TXC_2D ? 0 : 1)) * str[eob_multi];
+}
+// context of coeff_base (not the eob position) from the padded level map; L points at this coefficient
+__device__ __forceinline__ int base_ctx(const uint8_t *L, int st, int cls, int row, int col) {
+  int mag = imin_(L[1], 3) + imin_(L[st], 3);
+  if (cls == TXC_2D) {
+    mag += imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3);
+    const int m = imin_((mag + 1) >> 1, 4);
+    if (row == 0 && col == 0) return 0;
+    if (row + col < 2) return m + 1;
+    if (row + col < 4) return m + 6;
+    return m + 21;
+  } else if (cls == TXC_VERT) {
+    mag += imin_(L[2 * st], 3) + imin_(L[3 * st], 3) + imin_(L[4 * st], 3);
+    const int m = imin_((mag + 1) >> 1, 4);
+    return m + (row == 0 ? 26 : (row == 1 ? 31 : 36));
+  }
+  mag += imin_(L[2], 3) + imin_(L[3], 3) + imin_(L[4], 3);
+  const int m = imin_((mag + 1) >> 1, 4);
+  return m + (col == 0 ? 26 : (col == 1 ? 31 : 36));
+}
+__device__ __forceinline__ int br_ctx(const uint8_t *L, int st, int cls, int row, int col, int c) {
+  int mag = imin_(L[1], 15) + imin_(L[st], 15);
+  if (cls == TXC_2D) { mag += imin_(L[st + 1], 15); mag = imin_((mag + 1) >> 1, 6); return c == 0 ? mag : ((row < 2 && col < 2) ? mag + 7 : mag + 14); }
+  if (cls == TXC_HORIZ) { mag += imin_(L[2], 15); mag = imin_((mag + 1) >> 1, 6); return c == 0 ? mag : (col == 0 ? mag + 7 : mag + 14); }
+  mag += imin_(L[2 * st], 15); mag = imin_((mag + 1) >> 1, 6); return c == 0 ? mag : (row == 0 ? mag + 7 : mag + 14);
+}
+
+// Fills the padded level map (LDS, (n+4)^2 bytes) from qc; all lanes.
+__device__ inline void build_level_map(const int32_t *qc, uint8_t *lev, int n) {
+  const int st = n + 4, tot = st * st;
+  for (int i = LANE; i < tot; i += 64) {
+    const int r = i / st, c = i - r * st;
+    lev[i] = (r < n && c < n) ? (uint8_t)imin_(iabs_(qc[r * n + c]), 127) : 0;
+  }
+  WAVE_SYNC();
+}
+
+// Rate (1/512 bit) of coeffs() for one transform block. tx_off >= 0: luma tx-type symbol is priced too.
+__device__ inline uint32_t coef_rate_dev(const FrameDev *f, const int32_t *qc, int eob, int plane, int txs, int txtype,
+                                         int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint8_t *lev, int *cul_out, int *dc_cat) {
+  const uint16_t *cost = f->cost;
+  const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
+  const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
+  *cul_out = 0; *dc_cat = 0;
+  uint32_t head = cost[CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  if (eob == 0) return head;
+  if (tx_off >= 0) head += cost[tx_off + tx_sym];
+  const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
+  head += cost[eob_pt_cdf(eob_multi, pt, cls) + eob_pt - 1];
+  if (eob_pt >= 3) {
+    const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+    head += cost[CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
+    head += 512u * (uint32_t)(nb - 1);
+  }
+  build_level_map(qc, lev, n);
+  const int st = n + 4, area = n * n;
+  long long bits = 0; int cul = 0, dcc = 0;
+  for (int c = LANE; c < eob; c += 64) {
+    const int p = scan_pos(n, cls, c), row = p >> bwl, col = p & (n - 1);
+    const int v = qc[p], level = iabs_(v);
+    const uint8_t *L = lev + row * st + col;
+    if (c == eob - 1) {
+      const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
+      bits += cost[CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+    } else {
+      const int ctx = base_ctx(L, st, cls, row, col);
+      bits += cost[CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+    }
+    if (level > 2) {
+      const int ctx = br_ctx(L, st, cls, row, col, c);
+      const int off = CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+      int rem = level - 3;
+      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); bits += cost[off + s]; rem -= s; if (s < 3) break; }
+    }
+    if (level) {
+      if (c == 0) { bits += cost[CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + (v < 0)]; dcc = v < 0 ? 1 : 2; }
+      else bits += 512;
+      if (level > 14) { const int len = 32 - __clz(level - 14); bits += 512 * (2 * len - 1); }
+    }
+    cul += level;
+  }
+  bits = wave_sum_i64(bits);
+  cul = wave_sum_i32(imin_(cul, 1 << 20));
+  dcc = wave_max_i32(dcc);
+  *cul_out = imin_(cul, 63); *dc_cat = dcc;
+  return head + (uint32_t)bits;
+}

@@ -1,0 +1,280 @@
+// loopfilter.h -- kernels K2 (deblocking, spec 7.14) and K3 (CDEF direction + strength search + filter,
+// spec 7.15).  Frame-level, fully data-parallel: K2 runs one thread per 4-sample edge line (all edges of a
+// pass are independent because a filter never reaches past half of the smaller adjoining transform);
+// K3 runs one workgroup per 64x64 filter block, one wavefront per 8x8 block (64 lanes = 64 pixels),
+// wave-reduced SSE per strength candidate, LDS reduction across the workgroup.
+// rav1e equivalents (absent): src/deblock.rs, src/cdef.rs, rdo.rs::rdo_loop_decision.
+#pragma once
+#include "dev_common.h"
+
+__device__ inline void filter_edge_sample_dev(uint16_t *px, int step, int filter_size, int plane, int lvl, int sharp, int bd) {
+  const int sh = sharp > 4 ? 2 : (sharp > 0 ? 1 : 0);
+  const int limit = sharp > 0 ? iclamp_(lvl >> sh, 1, 9 - sharp) : imax_(1, lvl >> sh);
+  const int blimit = 2 * (lvl + 2) + limit, thresh = lvl >> 4, s8 = bd - 8;
+  const int limit_bd = limit << s8, blimit_bd = blimit << s8, thresh_bd = thresh << s8, flat_bd = 1 << s8;
+#define PX_P(i) ((int)px[-((i) + 1) * step])
+#define PX_Q(i) ((int)px[(i) * step])
+  const int p0 = PX_P(0), p1 = PX_P(1), q0 = PX_Q(0), q1 = PX_Q(1);
+  const int hev = iabs_(p1 - p0) > thresh_bd || iabs_(q1 - q0) > thresh_bd;
+  const int flen = filter_size == 4 ? 4 : (plane != 0 ? 6 : (filter_size == 8 ? 8 : 16));
+  int mask = iabs_(p1 - p0) <= limit_bd && iabs_(q1 - q0) <= limit_bd && (iabs_(p0 - q0) * 2 + iabs_(p1 - q1) / 2) <= blimit_bd;
+  if (flen >= 6) mask = mask && iabs_(PX_P(2) - p1) <= limit_bd && iabs_(PX_Q(2) - q1) <= limit_bd;
+  if (flen >= 8) mask = mask && iabs_(PX_P(3) - PX_P(2)) <= limit_bd && iabs_(PX_Q(3) - PX_Q(2)) <= limit_bd;
+  if (!mask) return;
+  int flat = 0, flat2 = 0;
+  if (filter_size >= 8) {
+    flat = iabs_(p1 - p0) <= flat_bd && iabs_(q1 - q0) <= flat_bd && iabs_(PX_P(2) - p0) <= flat_bd && iabs_(PX_Q(2) - q0) <= flat_bd;
+    if (flen >= 8) flat = flat && iabs_(PX_P(3) - p0) <= flat_bd && iabs_(PX_Q(3) - q0) <= flat_bd;
+  }
+  if (filter_size >= 16)
+    flat2 = iabs_(PX_P(6) - p0) <= flat_bd && iabs_(PX_Q(6) - q0) <= flat_bd && iabs_(PX_P(5) - p0) <= flat_bd && iabs_(PX_Q(5) - q0) <= flat_bd &&
+            iabs_(PX_P(4) - p0) <= flat_bd && iabs_(PX_Q(4) - q0) <= flat_bd;
+  if (filter_size == 4 || !flat) {
+    const int lo = -(1 << (bd - 1)), hi = (1 << (bd - 1)) - 1, off = 0x80 << s8;
+    const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
+    int filt = hev ? iclamp_(ps1 - qs1, lo, hi) : 0;
+    filt = iclamp_(filt + 3 * (qs0 - ps0), lo, hi);
+    const int f1 = iclamp_(filt + 4, lo, hi) >> 3, f2 = iclamp_(filt + 3, lo, hi) >> 3;
+    px[0] = (uint16_t)(iclamp_(qs0 - f1, lo, hi) + off);
+    px[-step] = (uint16_t)(iclamp_(ps0 + f2, lo, hi) + off);
+    if (!hev) {
+      const int fo = round2_(f1, 1);
+      px[step] = (uint16_t)(iclamp_(qs1 - fo, lo, hi) + off);
+      px[-2 * step] = (uint16_t)(iclamp_(ps1 + fo, lo, hi) + off);
+    }
+    return;
+  }
+  const int log2size = (filter_size == 8 || !flat2) ? 3 : 4;
+  const int n = log2size == 4 ? 6 : (plane == 0 ? 3 : 2);
+  const int n2 = (log2size == 3 && plane == 0) ? 0 : 1;
+  int F[16], out[16];
+  for (int i = -(n + 1); i <= n; i++) F[i + 8] = i < 0 ? PX_P(-i - 1) : PX_Q(i);
+  for (int i = -n; i < n; i++) {
+    int t = 0;
+    for (int j = -n; j <= n; j++) { const int p = iclamp_(i + j, -(n + 1), n); t += F[p + 8] * (iabs_(j) <= n2 ? 2 : 1); }
+    out[i + 8] = round2_(t, log2size);
+  }
+  for (int i = -n; i < n; i++) px[i * step] = (uint16_t)out[i + 8];
+#undef PX_P
+#undef PX_Q
+}
+
+// pass 0: vertical edges (filter along x), pass 1: horizontal edges.  One thread per (plane, line, mi col).
+__global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *frames, int nframes, int pass) {
+  const FrameDev *f = frames + blockIdx.z;
+  const int plane = blockIdx.y;
+  if (plane >= f->np) return;
+  const int L = plane == 0 ? f->lf_level[pass] : f->lf_level[plane + 1];
+  if (!L) return;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int r, c, i;
+  if (pass == 0) {       // consecutive threads walk mi columns of one pixel row
+    const int line = (int)(tid / f->mi_cols); c = (int)(tid % f->mi_cols); r = line >> 2; i = line & 3;
+  } else {               // consecutive threads walk pixel columns of one mi row
+    const int col_px = (int)(tid % (f->mi_cols * 4)); r = (int)(tid / (f->mi_cols * 4)); c = col_px >> 2; i = col_px & 3;
+  }
+  if (r >= f->mi_rows || c >= f->mi_cols) return;
+  const int x = c * 4, y = r * 4;
+  if (x >= f->w || y >= f->h) return;
+  if (pass == 0 && c == 0) return;
+  if (pass == 1 && r == 0) return;
+  const int ms = f->mi_stride;
+  const int cur = imin_(64, 4 << f->m_bsize[r * ms + c]);
+  if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return;
+  const int prev = pass == 0 ? imin_(64, 4 << f->m_bsize[r * ms + c - 1]) : imin_(64, 4 << f->m_bsize[(r - 1) * ms + c]);
+  const int base = imin_(cur, prev);
+  const int fsz = plane == 0 ? imin_(16, base) : imin_(8, base);
+  uint16_t *px = pass == 0 ? f->rec[plane] + (size_t)(y + i) * f->stride + x : f->rec[plane] + (size_t)y * f->stride + x + i;
+  filter_edge_sample_dev(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);
+}
+
+// ---------------------------------------------------------------- CDEF
+__device__ __forceinline__ int cdef_dir_off(int dir, int k, int comp) {
+  const int8_t d[8][2][2] = { { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } }, { { 0, 1 }, { 1, 2 } },
+                              { { 1, 1 }, { 2, 2 } }, { { 1, 0 }, { 2, 1 } }, { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
+  return d[dir][k][comp];
+}
+__device__ __forceinline__ int constrain_dev(int diff, int thr, int damping) {
+  if (!thr) return 0;
+  const int adj = imax_(0, damping - (31 - __clz(thr))), mag = iabs_(diff);
+  const int v = iclamp_(thr - (mag >> adj), 0, mag);
+  return diff < 0 ? -v : v;
+}
+// one pixel of the CDEF filter (spec 7.15.3); in = deblocked plane
+__device__ __forceinline__ int cdef_pixel(const FrameDev *f, const uint16_t *in, int py, int px_, int pri, int sec, int damping, int dir) {
+  const int cs = f->bd - 8, st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
+  const int x = in[(size_t)py * st + px_];
+  int sum = 0, mx = x, mn = x;
+  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+#pragma unroll
+    for (int sg = -1; sg <= 1; sg += 2) {
+      int yy = py + sg * cdef_dir_off(dir, k, 0), xx = px_ + sg * cdef_dir_off(dir, k, 1);
+      if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) {
+        const int p = in[(size_t)yy * st + xx];
+        sum += (k == 0 ? pt0 : pt1) * constrain_dev(p - x, pri, damping);
+        mx = imax_(mx, p); mn = imin_(mn, p);
+      }
+#pragma unroll
+      for (int doff = -2; doff <= 2; doff += 4) {
+        const int d2 = (dir + doff) & 7;
+        yy = py + sg * cdef_dir_off(d2, k, 0); xx = px_ + sg * cdef_dir_off(d2, k, 1);
+        if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) {
+          const int s = in[(size_t)yy * st + xx];
+          sum += (k == 0 ? 2 : 1) * constrain_dev(s - x, sec, damping);
+          mx = imax_(mx, s); mn = imin_(mn, s);
+        }
+      }
+    }
+  }
+  return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx);
+}
+// direction search for one 8x8 luma block, executed by lanes 0..7 (one direction each); returns dir and var to all lanes
+__device__ inline int cdef_direction_dev(const uint16_t *img, int stride, int bd, int *var_out) {
+  const int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+  const int d = LANE & 7;
+  int partial[15];
+#pragma unroll
+  for (int i = 0; i < 15; i++) partial[i] = 0;
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) {
+    const int x = (img[(size_t)i * stride + j] >> (bd - 8)) - 128;
+    int idx;
+    switch (d) { case 0: idx = i + j; break; case 1: idx = i + j / 2; break; case 2: idx = i; break; case 3: idx = 3 + i - j / 2; break;
+                 case 4: idx = 7 + i - j; break; case 5: idx = 3 - i / 2 + j; break; case 6: idx = j; break; default: idx = i / 2 + j; break; }
+#pragma unroll
+    for (int q = 0; q < 15; q++) if (q == idx) partial[q] += x;
+  }
+  int cost = 0;
+  if (d == 2 || d == 6) { for (int i = 0; i < 8; i++) cost += partial[i] * partial[i]; cost *= div_table[8]; }
+  else if (d == 0 || d == 4) {
+    for (int i = 0; i < 7; i++) cost += (partial[i] * partial[i] + partial[14 - i] * partial[14 - i]) * div_table[i + 1];
+    cost += partial[7] * partial[7] * div_table[8];
+  } else {
+    for (int j = 0; j < 5; j++) cost += partial[3 + j] * partial[3 + j];
+    cost *= div_table[8];
+    for (int j = 0; j < 3; j++) cost += (partial[j] * partial[j] + partial[10 - j] * partial[10 - j]) * div_table[2 * j + 2];
+  }
+  int best = 0, dir = 0, costs[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) costs[q] = __shfl(cost, q, 64);
+#pragma unroll
+  for (int q = 0; q < 8; q++) if (costs[q] > best) { best = costs[q]; dir = q; }
+  int opp = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) if (q == ((dir + 4) & 7)) opp = costs[q];
+  *var_out = (best - opp) >> 10;
+  return dir;
+}
+__device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int idx, int var, int ydir, int *pri, int *sec, int *damping, int *dir) {
+  const int cs = f->bd - 8;
+  const int st = plane == 0 ? f->cdef_y[idx] : f->cdef_uv[idx];
+  int p = (st >> 2) << cs, s = st & 3; if (s == 3) s = 4; s <<= cs;
+  *dir = p == 0 ? 0 : ydir; *damping = f->cdef_damping + cs - (plane > 0);
+  if (plane == 0) { const int vs = (var >> 6) ? imin_(31 - __clz(var >> 6), 12) : 0; p = var ? (p * (4 + vs) + 8) >> 4 : 0; }
+  *pri = p; *sec = s;
+}
+
+// grid.x = sb index, grid.y = frame; 256 threads = 4 waves, wave w handles 8x8 blocks w, w+4, ...
+__global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int write_final) {
+  const FrameDev *f = frames + blockIdx.y;
+  const int sbi = blockIdx.x;
+  if (sbi >= f->sb_rows * f->sb_cols) return;
+  __shared__ unsigned long long costs[8];
+  __shared__ int any_blocks, best_idx;
+  const int wave = threadIdx.x >> 6, lane = LANE;
+  const int sr = sbi / f->sb_cols, sc = sbi % f->sb_cols, ms = f->mi_stride;
+  if (threadIdx.x < 8) costs[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { any_blocks = 0; best_idx = 0; }
+  __syncthreads();
+  const int py_l = lane >> 3, px_l = lane & 7;
+  if (f->enable_cdef) {
+    for (int b = wave; b < 64; b += 4) {
+      const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
+      if (r >= f->mi_rows || c >= f->mi_cols) continue;
+      const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
+      if (sk) continue;
+      int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, &var);
+      long long cst[8];
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++) cst[idx] = 0;
+      for (int p = 0; p < f->np; p++) {
+        const int y = r * 4 + py_l, x = c * 4 + px_l;
+        const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+          int pri, sec, damping, dir; cdef_strengths(f, p, idx, var, ydir, &pri, &sec, &damping, &dir);
+          const int v = (pri == 0 && sec == 0) ? un : cdef_pixel(f, f->rec[p], y, x, pri, sec, damping, dir);
+          const int d = v - sv;
+          const long long sse = wave_sum_i64((long long)d * d);
+          cst[idx] += (sse * f->wq[p]) >> 5;
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) atomicAdd(&costs[idx], (unsigned long long)cst[idx]);
+        any_blocks = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = -1;
+    if (any_blocks) { best = 0; unsigned long long bc = costs[0]; for (int idx = 1; idx < 8; idx++) if (costs[idx] < bc) { bc = costs[idx]; best = idx; } }
+    best_idx = best;
+    f->cdef_idx[sbi] = (int8_t)best;
+  }
+  __syncthreads();
+  if (!write_final) return;
+  const int best = best_idx;
+  for (int b = wave; b < 64; b += 4) {
+    const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
+    if (r >= f->mi_rows || c >= f->mi_cols) continue;
+    const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
+    int var = 0, ydir = 0;
+    const int filt = best >= 0 && !sk;
+    if (filt) ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, &var);
+    for (int p = 0; p < f->np; p++) {
+      const int y = r * 4 + py_l, x = c * 4 + px_l;
+      int v = f->rec[p][(size_t)y * f->stride + x];
+      if (filt) {
+        int pri, sec, damping, dir; cdef_strengths(f, p, best, var, ydir, &pri, &sec, &damping, &dir);
+        if (pri || sec) v = cdef_pixel(f, f->rec[p], y, x, pri, sec, damping, dir);
+      }
+      f->fin[p][(size_t)y * f->stride + x] = (uint16_t)v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- K0: front end
+// RGBA8/RGB8 (HBM) -> planar Y,Cb,Cr (BT.601 full range, f32 FMA exactly as ravif rgb_to_ycbcr,
+// av1encoder.rs:504-524) or G,B,R, 8->10 bit expansion, optional alpha plane, edge replication into the
+// 64-aligned padding.  One thread per output pixel of the padded plane; 4 B read, 3*2 (+2) B written.
+struct FrontParams { float sy_r, sy_g, sy_b, scale, kcb, kcr, shift; int depth, color_model, bpp; };
+__global__ __launch_bounds__(256) void frontend_kernel(const uint8_t *pix, int w, int h, int stride_px, FrontParams fp,
+                                                       uint16_t *p0, uint16_t *p1, uint16_t *p2, uint16_t *pa, int pw, int ph, int *alpha_flag) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= pw || y >= ph) return;
+  const int sx = imin_(x, w - 1), sy = imin_(y, h - 1);
+  const uint8_t *p = pix + ((size_t)sy * stride_px + sx) * fp.bpp;
+  const int R = p[0], G = p[1], B = p[2], A = fp.bpp == 4 ? p[3] : 255;
+  uint16_t o0, o1, o2;
+  if (fp.color_model == 1) {
+    if (fp.depth == 8) { o0 = (uint16_t)G; o1 = (uint16_t)B; o2 = (uint16_t)R; }
+    else { o0 = (uint16_t)((G << 2) | (G >> 6)); o1 = (uint16_t)((B << 2) | (B >> 6)); o2 = (uint16_t)((R << 2) | (R >> 6)); }
+  } else {
+    const float r = (float)R, g = (float)G, b = (float)B;
+    const float yv = fmaf(fp.sy_b, b, fmaf(fp.sy_r, r, fp.sy_g * g));
+    const float cb = fmaf(fmaf(b, fp.scale, -yv), fp.kcb, fp.shift);
+    const float cr = fmaf(fmaf(r, fp.scale, -yv), fp.kcr, fp.shift);
+    const float sat = fp.depth == 8 ? 255.f : 65535.f;
+    const float v0 = roundf(yv), v1 = roundf(cb), v2 = roundf(cr);
+    o0 = (uint16_t)(v0 < 0.f ? 0.f : (v0 > sat ? sat : v0));
+    o1 = (uint16_t)(v1 < 0.f ? 0.f : (v1 > sat ? sat : v1));
+    o2 = (uint16_t)(v2 < 0.f ? 0.f : (v2 > sat ? sat : v2));
+  }
+  const size_t o = (size_t)y * pw + x;
+  p0[o] = o0; p1[o] = o1; p2[o] = o2;
+  if (pa) pa[o] = fp.depth == 8 ? (uint16_t)A : (uint16_t)((A << 2) | (A >> 6));
+  if (A != 255 && x < w && y < h && alpha_flag) *alpha_flag = 1;
+}

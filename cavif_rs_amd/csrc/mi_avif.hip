@@ -1,0 +1,527 @@
+// mi_avif.hip -- the engine behind include/mi_avif.h: plans AV1 frames, owns the HBM arena of a batch,
+// launches the kernels (K0 front end, K1 tile search, K2 deblock, K3 CDEF, K4 tile entropy coding, pack),
+// and assembles OBUs + AVIF containers on the host.  One HIP stream per batch, no hidden device syncs
+// other than the two points where the host needs device results (alpha flags, tile lengths).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <memory>
+#include "host_av1.h"
+#include "tile_search.h"
+#include "tile_entropy.h"
+#include "loopfilter.h"
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "mi_avif: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MI_ENCODING_ERROR; } } while (0)
+
+namespace mi {
+
+__global__ void pack_tiles_kernel(const FrameDev *frames, const TileJob *jobs, int njobs, const uint32_t *offsets, uint8_t *packed) {
+  const int job = blockIdx.x;
+  if (job >= njobs) return;
+  const TileJob tj = jobs[job];
+  const FrameDev *f = frames + tj.frame;
+  const int ti = tj.tile_row * f->tile_cols + tj.tile_col;
+  const uint32_t len = f->tile_len[ti];
+  const uint8_t *src = f->tile_out + (size_t)ti * f->tile_out_cap;
+  uint8_t *dst = packed + offsets[job];
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- per-device read-only tables ----
+struct DeviceTables { uint16_t *cost[4] = { 0, 0, 0, 0 }; uint16_t *cdf0[4] = { 0, 0, 0, 0 }; bool ready = false; };
+static std::mutex g_tab_mu;
+static DeviceTables g_tabs[16];
+static int ensure_tables(int dev) {
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  if (dev < 0 || dev >= 16) return MI_INVALID_ARGUMENT;
+  DeviceTables &t = g_tabs[dev];
+  if (t.ready) return MI_OK;
+  for (int q = 0; q < 4; q++) {
+    const std::vector<uint16_t> cost = build_cost_table(q);
+    HIP_OK(hipMalloc(&t.cost[q], CDF_TOTAL * 2)); HIP_OK(hipMalloc(&t.cdf0[q], CDF_TOTAL * 2));
+    HIP_OK(hipMemcpy(t.cost[q], cost.data(), CDF_TOTAL * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(t.cdf0[q], av1_default_cdfs + (size_t)q * CDF_TOTAL, CDF_TOTAL * 2, hipMemcpyHostToDevice));
+  }
+  t.ready = true;
+  return MI_OK;
+}
+
+// ---- one AV1 frame (colour image or alpha plane) inside a batch ----
+struct FramePlan {
+  mi_av1_config cfg{}; int np = 3, image = 0; bool is_alpha = false;
+  int mi_cols = 0, mi_rows = 0, sb_cols = 0, sb_rows = 0, pw = 0, ph = 0, mi_stride = 0, mi_h = 0, ntiles = 0, maxbs = 2;
+  QuantSel q{}; Tiling tiles; FrameHeaderInfo hdr{};
+  FrameDev dev{};
+  size_t arena_bytes = 0; uint8_t *arena = nullptr;
+  std::vector<uint8_t> obu;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void plan_geometry(FramePlan &p) {
+  const mi_av1_config &c = p.cfg;
+  p.np = c.chroma == 1 ? 1 : 3;
+  p.mi_cols = 2 * ((c.width + 7) >> 3); p.mi_rows = 2 * ((c.height + 7) >> 3);
+  p.sb_cols = (p.mi_cols + 15) >> 4; p.sb_rows = (p.mi_rows + 15) >> 4;
+  p.pw = p.sb_cols * 64; p.ph = p.sb_rows * 64; p.mi_stride = p.pw / 4; p.mi_h = p.ph / 4;
+  int part_max = c.part_max, part_min = c.part_min;
+  if (p.np > 1 && part_max > 32) part_max = 32;       // 64x64 colour blocks need 4 chroma tx blocks: not modelled yet
+  if (part_min > part_max) part_min = part_max;
+  p.cfg.part_max = (uint8_t)part_max; p.cfg.part_min = (uint8_t)part_min;
+  p.maxbs = part_max <= 16 ? 2 : (part_max <= 32 ? 3 : 4);
+  p.q = select_quantizers(c.quantizer, c.bit_depth, p.np);
+  p.tiles = plan_tiles((int)c.width, (int)c.height, p.sb_cols, p.sb_rows, c.min_tile_size, c.threads, c.tiles_override);
+  p.ntiles = p.tiles.cols * p.tiles.rows;
+}
+
+// carve the frame's arena; returns bytes needed (dry run when base == nullptr)
+static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { uint8_t *ptr = base ? base + off : nullptr; off = align_up(off + bytes, 256); return ptr; };
+  const size_t npx = (size_t)p.pw * p.ph, nmi = (size_t)p.mi_stride * p.mi_h;
+  FrameDev &d = p.dev;
+  for (int i = 0; i < p.np; i++) {
+    d.src[i] = (uint16_t *)take(npx * 2); d.rec[i] = (uint16_t *)take(npx * 2); d.fin[i] = (uint16_t *)take(npx * 2);
+    d.coef[i] = (int32_t *)take(npx * 4);
+    d.m_lvl[i] = take(nmi); d.m_dc[i] = take(nmi); d.m_eob[i] = (uint16_t *)take(nmi * 2);
+  }
+  d.m_bsize = take(nmi); d.m_skip = take(nmi); d.m_ymode = take(nmi); d.m_uvmode = take(nmi); d.m_txtype = take(nmi);
+  d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi); d.m_decoded = take(nmi);
+  d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
+  d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
+  d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
+  d.tile_out = take((size_t)p.ntiles * tile_cap);
+  d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
+  d.tile_out_cap = tile_cap;
+  return off;
+}
+
+static uint32_t tile_capacity(const FramePlan &p) {
+  int tw = 0, th = 0;
+  for (int i = 0; i < p.tiles.cols; i++) tw = std::max(tw, p.tiles.col_start[i + 1] - p.tiles.col_start[i]);
+  for (int i = 0; i < p.tiles.rows; i++) th = std::max(th, p.tiles.row_start[i + 1] - p.tiles.row_start[i]);
+  const size_t px = (size_t)tw * th * 4096;
+  return (uint32_t)align_up(px * p.np * 2 + 4096, 256);
+}
+
+static void fill_dev(FramePlan &p, const DeviceTables &tab) {
+  FrameDev &d = p.dev; const mi_av1_config &c = p.cfg;
+  d.w = c.width; d.h = c.height; d.bd = c.bit_depth; d.np = p.np;
+  d.mi_cols = p.mi_cols; d.mi_rows = p.mi_rows; d.sb_cols = p.sb_cols; d.sb_rows = p.sb_rows;
+  d.pw = p.pw; d.ph = p.ph; d.stride = p.pw; d.mi_stride = p.mi_stride; d.mi_h = p.mi_h;
+  d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
+  for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; }
+  d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
+  d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef;
+  d.tile_cols = p.tiles.cols; d.tile_rows = p.tiles.rows; d.tile_cols_log2 = p.tiles.cols_log2; d.tile_rows_log2 = p.tiles.rows_log2;
+  for (int i = 0; i <= p.tiles.cols; i++) d.tile_col_start[i] = p.tiles.col_start[i];
+  for (int i = 0; i <= p.tiles.rows; i++) d.tile_row_start[i] = p.tiles.row_start[i];
+  d.cost = tab.cost[p.q.qctx]; d.cdf0 = tab.cdf0[p.q.qctx];
+  d.dbg = getenv("MI_DEBUG_LEVEL") ? atoi(getenv("MI_DEBUG_LEVEL")) : 0;
+  const int lvl = deblock_level_from_q(p.q.ac_q[0], c.bit_depth);
+  d.lf_level[0] = d.lf_level[1] = d.lf_level[2] = d.lf_level[3] = lvl; d.lf_sharp = 0;
+  static const int strengths[8] = { 0, 1 * 4 + 0, 2 * 4 + 1, 3 * 4 + 1, 5 * 4 + 2, 7 * 4 + 3, 10 * 4 + 3, 13 * 4 + 3 };   // rav1e's fixed list
+  d.cdef_damping = 3; d.cdef_bits = 3;
+  for (int i = 0; i < 8; i++) { d.cdef_y[i] = strengths[i]; d.cdef_uv[i] = strengths[i]; }
+  FrameHeaderInfo &h = p.hdr;
+  h.cfg = c; h.np = p.np; h.sb_cols = p.sb_cols; h.sb_rows = p.sb_rows; h.q = p.q; h.tiles = p.tiles;
+  for (int i = 0; i < 4; i++) h.lf_level[i] = d.lf_level[i];
+  h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3;
+  for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
+}
+
+template <int MAXBS> static hipError_t launch_search(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+  const size_t lds = sizeof(Scratch<(4 << MAXBS)>);
+  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tile_search_kernel<MAXBS>, dim3(njobs), dim3(64), lds, s, d_frames, d_jobs, njobs);
+  return hipGetLastError();
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+// ================================================================ batch object
+struct mi_batch {
+  mi_ravif_encoder enc{}; int n = 0; uint32_t w = 0, h = 0; int channels = 3, device = 0, depth = 10;
+  hipStream_t stream = nullptr;
+  uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // n * w*h*channels
+  int *d_alpha_flags = nullptr; std::vector<int> alpha_flags;
+  std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
+  uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
+  FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
+  uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0;
+  uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr;
+  std::vector<TileJob> jobs;
+  std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
+  hipEvent_t ev[8]{}; double stage_ms[8]{};
+  bool planned = false;
+};
+
+static int batch_plan(mi_batch *b, bool with_alpha_frames) {
+  // (re)build frame plans: colour for every image, alpha for flagged images
+  b->frames.clear(); b->jobs.clear();
+  const int quantizer = quality_to_quantizer(b->enc.quality), aquant = quality_to_quantizer(b->enc.alpha_quality);
+  auto make = [&](int image, bool alpha) {
+    FramePlan p; p.image = image; p.is_alpha = alpha;
+    mi_av1_config &c = p.cfg;
+    c.width = b->w; c.height = b->h; c.bit_depth = (uint8_t)b->depth; c.quantizer = (uint8_t)(alpha ? aquant : quantizer);
+    c.chroma = alpha ? 1 : 0; c.pixel_range = 1; c.threads = b->enc.threads; c.device = b->device; c.tiles_override = b->enc.tiles_override;
+    c.has_color_desc = alpha ? 0 : 1; c.primaries = 1; c.transfer = 13; c.matrix = b->enc.color_model == 1 ? 0 : 6;
+    tweaks_from_preset(b->enc.speed, c.quantizer, &c);
+    plan_geometry(p);
+    return p;
+  };
+  for (int i = 0; i < b->n; i++) b->frames.push_back(make(i, false));
+  if (with_alpha_frames) for (int i = 0; i < b->n; i++) if (b->alpha_flags[i]) b->frames.push_back(make(i, true));
+  return MI_OK;
+}
+
+static void batch_free_device(mi_batch *b) {
+  if (b->d_arena) hipFree(b->d_arena); b->d_arena = nullptr;
+  if (b->d_frames) hipFree(b->d_frames); b->d_frames = nullptr;
+  if (b->d_jobs) hipFree(b->d_jobs); b->d_jobs = nullptr;
+  if (b->d_precarry) hipFree(b->d_precarry); b->d_precarry = nullptr;
+  if (b->d_offsets) hipFree(b->d_offsets); b->d_offsets = nullptr;
+  if (b->d_packed) hipFree(b->d_packed); b->d_packed = nullptr;
+  if (b->h_packed) hipHostFree(b->h_packed); b->h_packed = nullptr;
+  if (b->h_lens) hipHostFree(b->h_lens); b->h_lens = nullptr;
+}
+
+// allocate arena for the worst case: every image has an alpha frame when channels == 4
+static int batch_alloc(mi_batch *b) {
+  const DeviceTables &tab = g_tabs[b->device];
+  std::vector<FramePlan> worst;
+  {
+    std::vector<int> save = b->alpha_flags;
+    if (b->channels == 4) std::fill(b->alpha_flags.begin(), b->alpha_flags.end(), 1);
+    batch_plan(b, b->channels == 4);
+    worst = b->frames;
+    b->alpha_flags = save;
+  }
+  size_t total = 0, max_tiles = 0; uint32_t max_cap = 0; size_t packed = 0;
+  for (auto &p : worst) {
+    const uint32_t cap = tile_capacity(p);
+    p.arena_bytes = carve(p, nullptr, cap);
+    total += align_up(p.arena_bytes, 4096); max_tiles += (size_t)p.ntiles; max_cap = std::max(max_cap, cap);
+    packed += (size_t)p.ntiles * cap;
+  }
+  (void)tab;
+  HIP_OK(hipMalloc(&b->d_arena, total)); b->arena_bytes = total;
+  HIP_OK(hipMalloc(&b->d_frames, sizeof(FrameDev) * worst.size()));
+  HIP_OK(hipMalloc(&b->d_jobs, sizeof(TileJob) * max_tiles));
+  b->pre_cap = max_cap;
+  HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * max_cap * 2));
+  HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
+  b->packed_cap = std::min<size_t>(packed, (size_t)1 << 31);
+  HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
+  HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
+  HIP_OK(hipHostMalloc(&b->h_lens, max_tiles * 4));
+  return MI_OK;
+}
+
+extern "C" {
+
+const char *mi_version(void) { return "mi_avif 0.1 (gfx950)"; }
+int mi_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+void mi_free(void *p) { free(p); }
+int mi_quality_to_quantizer(float q) { return quality_to_quantizer(q); }
+int mi_av1_tweaks_from_preset(uint8_t speed, uint8_t quantizer, mi_av1_config *cfg) { if (!cfg) return MI_INVALID_ARGUMENT; return tweaks_from_preset(speed, quantizer, cfg); }
+void mi_rgb_to_ycbcr(const uint8_t rgb[3], int depth, uint16_t out[3]) { rgb_to_ycbcr_host(rgb, depth, out); }
+
+void mi_ravif_encoder_default(mi_ravif_encoder *e) {     // Encoder::new, ravif/src/av1encoder.rs:88-102
+  memset(e, 0, sizeof(*e));
+  e->quality = 80.f; e->alpha_quality = 80.f; e->speed = 5; e->color_model = 0; e->depth = 0; e->alpha_mode = 1; e->threads = 0; e->device = 0;
+}
+
+size_t mi_avif_serialize(const uint8_t *color, size_t color_len, const uint8_t *alpha, size_t alpha_len, uint32_t w, uint32_t h,
+                         uint8_t depth, uint8_t matrix, int premultiplied, const uint8_t *exif, size_t exif_len, uint8_t **out) {
+  std::vector<uint8_t> v = avif_container(color, color_len, alpha, alpha_len, w, h, depth, matrix, premultiplied != 0, exif, exif_len);
+  *out = (uint8_t *)malloc(v.size()); memcpy(*out, v.data(), v.size());
+  return v.size();
+}
+
+mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels) {
+  if (!e || n_images < 1 || w < 1 || h < 1 || (channels != 3 && channels != 4)) return nullptr;
+  if (e->speed < 1 || e->speed > 10 || !(e->quality >= 1.f && e->quality <= 100.f) || !(e->alpha_quality >= 1.f && e->alpha_quality <= 100.f)) return nullptr;
+  if (mi_device_count() <= e->device) { fprintf(stderr, "mi_avif: no HIP device %d (the HIP path is mandatory; there is no CPU fallback)\n", e->device); return nullptr; }
+  if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+  if (ensure_tables(e->device) != MI_OK) return nullptr;
+  mi_batch *b = new mi_batch();
+  b->enc = *e; b->n = n_images; b->w = w; b->h = h; b->channels = channels; b->device = e->device; b->depth = e->depth == 8 ? 8 : 10;
+  b->alpha_flags.assign(n_images, 0);
+  b->pixel_bytes = (size_t)n_images * w * h * channels;
+  bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess &&
+            hipMalloc(&b->d_alpha_flags, sizeof(int) * n_images) == hipSuccess;
+  for (int i = 0; i < 8 && ok; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  if (ok) ok = batch_alloc(b) == MI_OK;
+  if (!ok) { mi_batch_destroy(b); return nullptr; }
+  b->files.resize(n_images); b->color_sz.assign(n_images, 0); b->alpha_sz.assign(n_images, 0);
+  return b;
+}
+
+int mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px) {
+  if (!b || index < 0 || index >= b->n || !pixels) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  const size_t row = (size_t)b->w * b->channels;
+  uint8_t *dst = b->d_pixels + (size_t)index * b->w * b->h * b->channels;
+  HIP_OK(hipMemcpy2DAsync(dst, row, pixels, stride_px * b->channels, row, b->h, hipMemcpyHostToDevice, b->stream));
+  HIP_OK(hipStreamSynchronize(b->stream));
+  return MI_OK;
+}
+
+int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
+double mi_batch_stage_ms(const mi_batch *b, int stage) { return (b && stage >= 0 && stage < 8) ? b->stage_ms[stage] : 0.0; }
+
+int mi_batch_encode(mi_batch *b) {
+  if (!b) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  const DeviceTables &tab = g_tabs[b->device];
+  hipStream_t s = b->stream;
+  // ---- plan colour frames (alpha frames are added once the front end has reported the flags)
+  batch_plan(b, false);
+  size_t off = 0;
+  auto place = [&](FramePlan &p) { const uint32_t cap = tile_capacity(p); p.arena = b->d_arena + off; p.arena_bytes = carve(p, p.arena, cap); off += align_up(p.arena_bytes, 4096); fill_dev(p, tab); };
+  for (auto &p : b->frames) place(p);
+  // ---- K0 front end: RGBA8 -> planes (+ alpha plane into a staging slot at the end of the colour frame's fin[] planes)
+  HIP_OK(hipEventRecord(b->ev[0], s));
+  HIP_OK(hipMemsetAsync(b->d_alpha_flags, 0, sizeof(int) * b->n, s));
+  const FrontConsts fc = front_consts(b->depth);
+  FrontParams fp{ fc.sy_r, fc.sy_g, fc.sy_b, fc.scale, fc.kcb, fc.kcr, fc.shift, b->depth, b->enc.color_model, b->channels };
+  for (int i = 0; i < b->n; i++) {
+    FramePlan &p = b->frames[i];
+    uint16_t *alpha_stage = b->channels == 4 ? p.dev.fin[0] : nullptr;      // fin[0] is free until CDEF runs
+    hipLaunchKernelGGL(frontend_kernel, dim3((p.pw + 255) / 256, p.ph), dim3(256), 0, s,
+                       b->d_pixels + (size_t)i * b->w * b->h * b->channels, (int)b->w, (int)b->h, (int)b->w, fp,
+                       p.dev.src[0], p.dev.src[1], p.dev.src[2], alpha_stage, p.pw, p.ph, b->d_alpha_flags + i);
+  }
+  HIP_OK(hipGetLastError());
+  if (b->channels == 4) {
+    HIP_OK(hipMemcpyAsync(b->alpha_flags.data(), b->d_alpha_flags, sizeof(int) * b->n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    const size_t ncolor = b->frames.size();
+    const int quantizer_a = quality_to_quantizer(b->enc.alpha_quality);
+    for (int i = 0; i < b->n; i++) if (b->alpha_flags[i]) {
+      FramePlan p; p.image = i; p.is_alpha = true; mi_av1_config &c = p.cfg;
+      c = b->frames[i].cfg; c.quantizer = (uint8_t)quantizer_a; c.chroma = 1; c.has_color_desc = 0; c.pixel_range = 1;
+      tweaks_from_preset(b->enc.speed, c.quantizer, &c);
+      plan_geometry(p);
+      b->frames.push_back(p);
+    }
+    for (size_t k = ncolor; k < b->frames.size(); k++) {
+      place(b->frames[k]);
+      FramePlan &a = b->frames[k], &col = b->frames[a.image];
+      HIP_OK(hipMemcpyAsync(a.dev.src[0], col.dev.fin[0], (size_t)a.pw * a.ph * 2, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  // ---- tile job list, frame descriptors
+  b->jobs.clear();
+  int maxbs = 2, max_mi_cells = 0, max_sb = 0;
+  for (size_t k = 0; k < b->frames.size(); k++) {
+    FramePlan &p = b->frames[k];
+    p.dev.tile_base = (int)b->jobs.size();
+    for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) b->jobs.push_back(TileJob{ (int)k, tr, tc });
+    maxbs = std::max(maxbs, p.maxbs); max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
+    // clear the state the kernels rely on being zero
+    HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
+  }
+  std::vector<FrameDev> hframes; for (auto &p : b->frames) hframes.push_back(p.dev);
+  HIP_OK(hipMemcpyAsync(b->d_frames, hframes.data(), sizeof(FrameDev) * hframes.size(), hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
+  const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
+  // ---- K1 tile search
+  HIP_OK(hipEventRecord(b->ev[1], s));
+  hipError_t le = maxbs == 2 ? launch_search<2>(b->d_frames, b->d_jobs, njobs, s) : (maxbs == 3 ? launch_search<3>(b->d_frames, b->d_jobs, njobs, s) : launch_search<4>(b->d_frames, b->d_jobs, njobs, s));
+  HIP_OK(le);
+  // ---- K2 deblock
+  HIP_OK(hipEventRecord(b->ev[2], s));
+  for (int pass = 0; pass < 2; pass++)
+    hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, b->d_frames, nframes, pass);
+  HIP_OK(hipGetLastError());
+  // ---- K3 CDEF
+  HIP_OK(hipEventRecord(b->ev[3], s));
+  hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, b->d_frames, 1);
+  HIP_OK(hipGetLastError());
+  // ---- K4 entropy coding
+  HIP_OK(hipEventRecord(b->ev[4], s));
+  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), 0, s, b->d_frames, b->d_jobs, njobs, b->d_precarry, b->pre_cap);
+  HIP_OK(hipGetLastError());
+  // ---- tile lengths -> offsets -> pack -> one D2H
+  HIP_OK(hipEventRecord(b->ev[5], s));
+  std::vector<uint32_t> offsets(njobs);
+  {
+    size_t o2 = 0;
+    for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + o2, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); o2 += p.ntiles; }
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  size_t total = 0;
+  for (int j = 0; j < njobs; j++) {
+    if (b->h_lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer\n", j); return MI_ENCODING_ERROR; }
+    offsets[j] = (uint32_t)total; total += b->h_lens[j];
+  }
+  if (total > b->packed_cap) return MI_ENCODING_ERROR;
+  HIP_OK(hipMemcpyAsync(b->d_offsets, offsets.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3(njobs), dim3(256), 0, s, b->d_frames, b->d_jobs, njobs, b->d_offsets, b->d_packed);
+  HIP_OK(hipMemcpyAsync(b->h_packed, b->d_packed, total, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipEventRecord(b->ev[6], s));
+  HIP_OK(hipStreamSynchronize(s));
+  // ---- host assembly
+  for (size_t k = 0; k < b->frames.size(); k++) {
+    FramePlan &p = b->frames[k];
+    std::vector<std::pair<const uint8_t *, size_t>> tl;
+    for (int t = 0; t < p.ntiles; t++) { const int j = p.dev.tile_base + t; tl.push_back({ b->h_packed + offsets[j], (size_t)b->h_lens[j] }); }
+    p.obu = assemble_obus(p.hdr, tl);
+  }
+  for (int i = 0; i < b->n; i++) {
+    const FramePlan *alpha = nullptr;
+    for (size_t k = b->n; k < b->frames.size(); k++) if (b->frames[k].image == i) alpha = &b->frames[k];
+    const FramePlan &col = b->frames[i];
+    b->files[i] = avif_container(col.obu.data(), col.obu.size(), alpha ? alpha->obu.data() : nullptr, alpha ? alpha->obu.size() : 0,
+                                 b->w, b->h, b->depth, col.cfg.matrix, b->enc.alpha_mode == 2, b->enc.exif, b->enc.exif_len);
+    b->color_sz[i] = col.obu.size(); b->alpha_sz[i] = alpha ? alpha->obu.size() : 0;
+  }
+  HIP_OK(hipEventRecord(b->ev[7], s));
+  HIP_OK(hipEventSynchronize(b->ev[7]));
+  for (int i = 0; i < 7; i++) { float ms = 0; hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]); b->stage_ms[i] = ms; }
+  return MI_OK;
+}
+
+int mi_batch_get(mi_batch *b, int index, mi_encoded_image *out) {
+  if (!b || !out || index < 0 || index >= b->n || b->files[index].empty()) return MI_INVALID_ARGUMENT;
+  const std::vector<uint8_t> &f = b->files[index];
+  out->avif_file = (uint8_t *)malloc(f.size()); memcpy(out->avif_file, f.data(), f.size());
+  out->avif_len = f.size(); out->color_byte_size = b->color_sz[index]; out->alpha_byte_size = b->alpha_sz[index];
+  return MI_OK;
+}
+
+int mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]) {
+  if (!b || index < 0 || index >= b->n) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  const FramePlan *p = nullptr;
+  if (!alpha) p = &b->frames[index]; else for (size_t k = b->n; k < b->frames.size(); k++) if (b->frames[k].image == index) p = &b->frames[k];
+  if (!p) return MI_INVALID_ARGUMENT;
+  for (int i = 0; i < 3; i++) planes[i] = nullptr;
+  for (int i = 0; i < p->np; i++) {
+    planes[i] = (uint16_t *)malloc((size_t)b->w * b->h * 2);
+    HIP_OK(hipMemcpy2D(planes[i], (size_t)b->w * 2, p->dev.fin[i], (size_t)p->pw * 2, (size_t)b->w * 2, b->h, hipMemcpyDeviceToHost));
+  }
+  return MI_OK;
+}
+
+void mi_batch_destroy(mi_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  batch_free_device(b);
+  if (b->d_pixels) hipFree(b->d_pixels);
+  if (b->d_alpha_flags) hipFree(b->d_alpha_flags);
+  for (int i = 0; i < 8; i++) if (b->ev[i]) hipEventDestroy(b->ev[i]);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+static int encode_one(const mi_ravif_encoder *e, const uint8_t *px, int channels, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) {
+  if (!e || !px || !out || w < 1 || h < 1) return MI_INVALID_ARGUMENT;
+  mi_batch *b = mi_batch_create(e, 1, w, h, channels);
+  if (!b) return mi_device_count() > e->device ? MI_INVALID_ARGUMENT : MI_NO_DEVICE;
+  int st = mi_batch_upload(b, 0, px, stride_px);
+  if (st == MI_OK) st = mi_batch_encode(b);
+  if (st == MI_OK) st = mi_batch_get(b, 0, out);
+  mi_batch_destroy(b);
+  return st;
+}
+int mi_ravif_encode_rgba(const mi_ravif_encoder *e, const uint8_t *rgba, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgba, 4, w, h, stride_px, out); }
+int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgb, 3, w, h, stride_px, out); }
+
+// level 1: caller-supplied planes (encode_to_av1). Planes go straight into the frame's src[] (edge-replicated on the host).
+int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], const size_t stride_bytes[3], uint8_t **out_obu, size_t *out_len, uint16_t *recon[3]) {
+  if (!cfg || !planes || !planes[0] || !out_obu || !out_len || cfg->width < 1 || cfg->height < 1 || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return MI_INVALID_ARGUMENT;
+  if (mi_device_count() <= cfg->device) { fprintf(stderr, "mi_avif: no HIP device %d (no CPU fallback)\n", cfg->device); return MI_NO_DEVICE; }
+  HIP_OK(hipSetDevice(cfg->device));
+  if (int st = ensure_tables(cfg->device)) return st;
+  const DeviceTables &tab = g_tabs[cfg->device];
+  FramePlan p; p.cfg = *cfg; plan_geometry(p);
+  const uint32_t cap = tile_capacity(p);
+  p.arena_bytes = carve(p, nullptr, cap);
+  hipStream_t s; HIP_OK(hipStreamCreate(&s));
+  uint8_t *arena = nullptr; HIP_OK(hipMalloc(&arena, p.arena_bytes));
+  carve(p, arena, cap); fill_dev(p, tab); p.dev.tile_base = 0;
+  const size_t npx = (size_t)p.pw * p.ph;
+  std::vector<uint16_t> host(npx);
+  for (int i = 0; i < p.np; i++) {
+    if (!planes[i]) { hipFree(arena); return MI_TOO_FEW_PIXELS; }
+    for (int y = 0; y < p.ph; y++) {
+      const uint8_t *row = (const uint8_t *)planes[i] + (size_t)std::min<int>(y, cfg->height - 1) * stride_bytes[i];
+      for (int x = 0; x < p.pw; x++) { const int sx = std::min<int>(x, cfg->width - 1); host[(size_t)y * p.pw + x] = cfg->bit_depth == 8 ? row[sx] : ((const uint16_t *)row)[sx]; }
+    }
+    HIP_OK(hipMemcpy(p.dev.src[i], host.data(), npx * 2, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
+  std::vector<TileJob> jobs;
+  for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
+  FrameDev *d_frame; TileJob *d_jobs; uint16_t *d_pre;
+  HIP_OK(hipMalloc(&d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&d_pre, (size_t)jobs.size() * cap * 2));
+  HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
+  const int njobs = (int)jobs.size();
+  hipError_t le = p.maxbs == 2 ? launch_search<2>(d_frame, d_jobs, njobs, s) : (p.maxbs == 3 ? launch_search<3>(d_frame, d_jobs, njobs, s) : launch_search<4>(d_frame, d_jobs, njobs, s));
+  HIP_OK(le);
+  const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
+#define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)
+  DBG_STAGE("tile_search");
+  for (int pass = 0; pass < 2; pass++) hipLaunchKernelGGL(deblock_kernel, dim3((p.mi_cols * p.mi_rows * 4 + 255) / 256, 3, 1), dim3(256), 0, s, d_frame, 1, pass);
+  DBG_STAGE("deblock");
+  hipLaunchKernelGGL(cdef_kernel, dim3(p.sb_cols * p.sb_rows, 1), dim3(256), 0, s, d_frame, 1);
+  DBG_STAGE("cdef");
+  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), 0, s, d_frame, d_jobs, njobs, d_pre, cap);
+  DBG_STAGE("entropy");
+  HIP_OK(hipGetLastError());
+  std::vector<uint32_t> lens(njobs);
+  HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  std::vector<std::vector<uint8_t>> td(njobs); std::vector<std::pair<const uint8_t *, size_t>> tl;
+  for (int j = 0; j < njobs; j++) {
+    if (lens[j] == 0xFFFFFFFFu) return MI_ENCODING_ERROR;
+    td[j].resize(lens[j]);
+    HIP_OK(hipMemcpy(td[j].data(), p.dev.tile_out + (size_t)j * cap, lens[j], hipMemcpyDeviceToHost));
+    tl.push_back({ td[j].data(), td[j].size() });
+  }
+  std::vector<uint8_t> obu = assemble_obus(p.hdr, tl);
+  *out_obu = (uint8_t *)malloc(obu.size()); memcpy(*out_obu, obu.data(), obu.size()); *out_len = obu.size();
+  if (recon) for (int i = 0; i < 3; i++) {
+    recon[i] = nullptr;
+    if (i < p.np) { recon[i] = (uint16_t *)malloc((size_t)cfg->width * cfg->height * 2); HIP_OK(hipMemcpy2D(recon[i], (size_t)cfg->width * 2, p.dev.fin[i], (size_t)p.pw * 2, (size_t)cfg->width * 2, cfg->height, hipMemcpyDeviceToHost)); }
+  }
+  hipFree(d_frame); hipFree(d_jobs); hipFree(d_pre); hipFree(arena); hipStreamDestroy(s);
+  return MI_OK;
+}
+
+static int raw_planes(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const void *yuv, const void *alpha, int depth, uint8_t range, uint8_t matrix, mi_encoded_image *out) {
+  if (!e || !yuv || !out || w < 1 || h < 1) return MI_INVALID_ARGUMENT;
+  const size_t n = (size_t)w * h, bps = depth == 8 ? 1 : 2;
+  std::vector<uint8_t> pl[3]; for (auto &v : pl) v.resize(n * bps);
+  for (size_t i = 0; i < n; i++) for (int c = 0; c < 3; c++) {
+    if (depth == 8) pl[c][i] = ((const uint8_t *)yuv)[i * 3 + c]; else ((uint16_t *)pl[c].data())[i] = ((const uint16_t *)yuv)[i * 3 + c];
+  }
+  mi_av1_config c{}; c.width = w; c.height = h; c.bit_depth = (uint8_t)depth; c.quantizer = (uint8_t)quality_to_quantizer(e->quality);
+  c.chroma = 0; c.pixel_range = range; c.threads = e->threads; c.has_color_desc = 1; c.primaries = 1; c.transfer = 13; c.matrix = matrix; c.device = e->device; c.tiles_override = e->tiles_override;
+  if (int st = tweaks_from_preset(e->speed, c.quantizer, &c)) return st;
+  const void *pp[3] = { pl[0].data(), pl[1].data(), pl[2].data() }; const size_t sb[3] = { w * bps, w * bps, w * bps };
+  uint8_t *cobu = nullptr, *aobu = nullptr; size_t clen = 0, alen = 0;
+  if (int st = mi_av1_encode_planes(&c, pp, sb, &cobu, &clen, nullptr)) return st;
+  if (alpha) {
+    mi_av1_config a = c; a.quantizer = (uint8_t)quality_to_quantizer(e->alpha_quality); a.chroma = 1; a.pixel_range = 1; a.has_color_desc = 0;
+    tweaks_from_preset(e->speed, a.quantizer, &a);
+    const void *ap[3] = { alpha, nullptr, nullptr };
+    if (int st = mi_av1_encode_planes(&a, ap, sb, &aobu, &alen, nullptr)) { free(cobu); return st; }
+  }
+  out->avif_len = mi_avif_serialize(cobu, clen, aobu, alen, w, h, (uint8_t)depth, matrix, e->alpha_mode == 2, e->exif, e->exif_len, &out->avif_file);
+  out->color_byte_size = clen; out->alpha_byte_size = alen;
+  free(cobu); free(aobu);
+  return MI_OK;
+}
+int mi_ravif_encode_raw_planes_8(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint8_t *yuv, const uint8_t *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out) { return raw_planes(e, w, h, yuv, alpha, 8, range, matrix, out); }
+int mi_ravif_encode_raw_planes_10(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint16_t *yuv, const uint16_t *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out) { return raw_planes(e, w, h, yuv, alpha, 10, range, matrix, out); }
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// tile_entropy.h -- kernel K4: the tile's final bitstream.  One wavefront per tile walks the mode-info
+// maps that K1 left in HBM (partition tree, modes, tx types, quantised levels) in AV1 coding order and
+// range-codes them with adaptive CDFs held in LDS (spec 5.11 syntax, 8.2 symbol coder, 8.3 CDF selection).
+// The walk is inherently serial per tile; the wave's lanes cooperate on staging each transform block's
+// levels + context map into LDS and on the CDF adaptation, lane 0 drives the range coder.
+// rav1e equivalents (absent from /root/reference): src/ec.rs (WriterBase), src/context/*.rs.
+#pragma once
+#include "dev_common.h"
+#include "dev_rate.h"
+
+struct RangeEncDev {
+  uint16_t *pre; uint32_t cap, offs;
+  unsigned long long low; uint32_t rng; int cnt; int overflow;
+};
+
+__device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
+  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->overflow = 0;
+}
+__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) { if (e->offs < e->cap) e->pre[e->offs] = v; else e->overflow = 1; e->offs++; }
+__device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, unsigned long long low, uint32_t rng) {
+  int c = e->cnt;
+  const int d = 16 - (32 - __clz(rng));
+  int s = c + d;
+  if (s >= 0) {
+    c += 16;
+    unsigned long long m = (1ULL << c) - 1;
+    if (s >= 8) { re_put16(e, (uint16_t)(low >> c)); low &= m; c -= 8; m >>= 8; }
+    re_put16(e, (uint16_t)(low >> c));
+    s = c + d - 24;
+    low &= m;
+  }
+  e->low = low << d; e->rng = rng << d; e->cnt = s;
+}
+__device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
+  unsigned long long l = e->low; uint32_t r = e->rng;
+  const int N = nsyms - 1;
+  if (fl < 32768) {
+    const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4 * (uint32_t)(N - (s - 1));
+    const uint32_t v = (((r >> 8) * (fh >> 6)) >> 1) + 4 * (uint32_t)(N - s);
+    l += r - u; r = u - v;
+  } else {
+    r -= (((r >> 8) * (fh >> 6)) >> 1) + 4 * (uint32_t)(N - s);
+  }
+  re_normalize_dev(e, l, r);
+}
+// encode + adapt (lane 0 only)
+__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s, uint16_t *icdf, int nsyms) {
+  re_encode_q15_dev(e, s > 0 ? icdf[s - 1] : 32768, icdf[s], s, nsyms);
+  const int cnt = icdf[nsyms];
+  const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
+  for (int i = 0; i < nsyms - 1; i++) {
+    if (i < s) icdf[i] += (uint16_t)((32768 - icdf[i]) >> rate);
+    else icdf[i] -= (uint16_t)(icdf[i] >> rate);
+  }
+  icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
+}
+__device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit, uint32_t icdf0) {
+  re_encode_q15_dev(e, bit ? icdf0 : 32768, bit ? 0 : icdf0, bit, 2);
+}
+__device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v, int nbits) {
+  for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
+}
+// returns number of bytes; out must hold them.  (lane 0)
+__device__ inline uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
+  unsigned long long l = e->low; int c = e->cnt; int s = 10;
+  const unsigned long long m = 0x3FFF;
+  unsigned long long x = ((l + m) & ~m) | (m + 1);
+  s += c;
+  if (s > 0) {
+    unsigned long long n = (1ULL << (c + 16)) - 1;
+    do { re_put16(e, (uint16_t)(x >> (c + 16))); x &= n; s -= 8; c -= 8; n >>= 8; } while (s > 0);
+  }
+  const uint32_t nb = e->offs;
+  if (e->overflow || nb > out_cap) return 0xFFFFFFFFu;
+  uint32_t carry = 0;
+  for (uint32_t i = nb; i-- > 0;) { carry = e->pre[i] + carry; out[i] = (uint8_t)carry; carry >>= 8; }
+  return nb;
+}
+
+struct TileWriter {
+  const FrameDev *f; TileB t; RangeEncDev ec; uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
+  int32_t *qc; uint8_t *lev;                                    // LDS staging
+  uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
+  int sb_cols_tile;
+};
+
+// lane 0: code one transform block's coefficients (levels + map already staged in LDS)
+__device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
+                                         int tx_off, int tx_sym, int tx_ns) {
+  RangeEncDev *e = &w->ec; uint16_t *cdf = w->cdf; const int32_t *qc = w->qc; const uint8_t *lev = w->lev;
+  const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
+  const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
+  re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
+  if (eob == 0) return;
+  if (tx_off >= 0) re_symbol_dev(e, tx_sym, cdf + tx_off, tx_ns);
+  const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
+  re_symbol_dev(e, eob_pt - 1, cdf + eob_pt_cdf(eob_multi, pt, cls), 5 + eob_multi);
+  if (eob_pt >= 3) {
+    const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+    re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
+    if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
+  }
+  const int st = n + 4, area = n * n;
+  for (int c = eob - 1; c >= 0; c--) {
+    const int p = scan_pos(n, cls, c), row = p >> bwl, col = p & (n - 1);
+    const int level = iabs_(qc[p]);
+    const uint8_t *L = lev + row * st + col;
+    if (c == eob - 1) {
+      const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
+      re_symbol_dev(e, imin_(level, 3) - 1, cdf + CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE, 3);
+    } else {
+      const int ctx = base_ctx(L, st, cls, row, col);
+      re_symbol_dev(e, imin_(level, 3), cdf + CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE, 4);
+    }
+    if (level > 2) {
+      const int ctx = br_ctx(L, st, cls, row, col, c);
+      uint16_t *bc = cdf + CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+      int rem = level - 3;
+      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
+    }
+  }
+  for (int c = 0; c < eob; c++) {
+    const int p = scan_pos(n, cls, c), v = qc[p], a = iabs_(v);
+    if (a) {
+      if (c == 0) re_symbol_dev(e, v < 0, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
+      else re_bool_dev(e, v < 0, 16384);
+      if (a > 14) { const uint32_t xg = (uint32_t)(a - 14); const int len = 32 - __clz(xg); re_literal_dev(e, 0, len - 1); re_literal_dev(e, xg, len); }
+    }
+  }
+}
+
+template <int BS> __device__ inline void write_block_dev(TileWriter *w, int r, int c) {
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride, mi = r * ms + c;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int skip = f->m_skip[mi], ymode = f->m_ymode[mi];
+  int uvmode = 0;
+  if (LANE == 0) {
+    RangeEncDev *e = &w->ec; uint16_t *cdf = w->cdf;
+    const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
+    re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
+    if (!skip && f->enable_cdef) {
+      const int lsb = ((r - t->mi_row_start) >> 4) * w->sb_cols_tile + ((c - t->mi_col_start) >> 4);
+      if (!w->cdef_done[lsb]) { w->cdef_done[lsb] = 1; re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }
+    }
+    const int *imc = intra_mode_ctx_tab();
+    const int am = imc[availU ? f->m_ymode[mi - ms] : DC_PRED], lm = imc[availL ? f->m_ymode[mi - 1] : DC_PRED];
+    re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
+    if (BS >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
+      re_symbol_dev(e, f->m_angle_y[mi] + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
+    if (f->np > 1) {
+      const int um = f->m_uvmode[mi];
+      if (BS <= BS_32) re_symbol_dev(e, um, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
+      else re_symbol_dev(e, um, cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
+      if (um == UV_CFL_PRED) {
+        const int js = f->m_cfl_sign[mi], su = (js + 1) / 3, sv = (js + 1) % 3;
+        re_symbol_dev(e, js, cdf + CDF_CFL_SIGN, 8);
+        if (su) re_symbol_dev(e, f->m_cfl_au[mi], cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
+        if (sv) re_symbol_dev(e, f->m_cfl_av[mi], cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
+      }
+      if (BS >= BS_8 && um >= V_PRED && um <= D67_PRED)
+        re_symbol_dev(e, f->m_angle_uv[mi] + 3, cdf + CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE, 7);
+    }
+  }
+  if (f->np > 1) uvmode = f->m_uvmode[mi];
+  if (skip) return;                                    // wave-uniform
+  constexpr int n = (4 << BS) < 32 ? (4 << BS) : 32;
+  for (int p = 0; p < f->np; p++) {
+    const int eob = f->m_eob[p][mi];
+    const int32_t *src = f->coef[p] + (size_t)(r * 4) * f->stride + c * 4;
+    WAVE_SYNC();
+    for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx / n) * f->stride + (idx % n)];
+    WAVE_SYNC();
+    build_level_map(w->qc, w->lev, n);
+    int txtype, off = -1, sym = 0, ns = 0, set;
+    if (p == 0) {
+      txtype = f->m_txtype[mi];
+      off = intra_tx_cdf(f, BS, ymode, &ns, &set);
+      if (off >= 0) sym = txtype_to_sym(set, txtype);
+    } else {
+      set = tx_set_of(BS, f->reduced_tx_set);
+      txtype = mode_to_txtype(uvmode);
+      if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
+    }
+    int sctx2, dctx;
+    txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx2, &dctx);
+    if (LANE == 0) code_coeffs_lane0(w, eob, p, BS, txtype, sctx2, dctx, off, sym, ns);
+  }
+  WAVE_SYNC();
+}
+
+template <int BS> struct WritePart {
+  static __device__ void run(TileWriter *w, int r, int c) {
+    const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride;
+    if (r >= f->mi_rows || c >= f->mi_cols) return;
+    constexpr int half = (1 << BS) >> 1;
+    const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
+    const int actual = f->m_bsize[r * ms + c];
+    int part = actual == BS ? 0 : 3;
+    if (LANE == 0) {
+      const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+      const int above = availU && f->m_bsize[(r - 1) * ms + c] < BS, left = availL && f->m_bsize[r * ms + c - 1] < BS;
+      uint16_t *cdf = w->cdf + CDF_PARTITION + ((BS - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
+      const int ns = BS == BS_8 ? 4 : 10;
+      if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
+      else if (has_rows || has_cols) {
+#define PP_(i) ((uint32_t)((i) > 0 ? cdf[(i) - 1] : 32768) - cdf[i])
+        uint32_t psum;
+        if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
+        else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
+#undef PP_
+        re_bool_dev(&w->ec, 1, psum);
+      }
+    }
+    if (!(has_rows && has_cols)) part = 3;
+    if (part == 0) write_block_dev<BS>(w, r, c);
+    else {
+      WritePart<BS - 1>::run(w, r, c); WritePart<BS - 1>::run(w, r, c + half);
+      WritePart<BS - 1>::run(w, r + half, c); WritePart<BS - 1>::run(w, r + half, c + half);
+    }
+  }
+};
+template <> struct WritePart<0> {
+  static __device__ void run(TileWriter *w, int r, int c) {
+    if (r >= w->f->mi_rows || c >= w->f->mi_cols) return;
+    write_block_dev<0>(w, r, c);
+  }
+};
+
+struct EntropyLds {
+  uint16_t cdf[CDF_TOTAL];
+  int32_t qc[32 * 32];
+  uint8_t lev[36 * 36 + 4];
+  uint8_t cdef_done[MI_MAX_TILE_COLS * MI_MAX_TILE_ROWS > 4096 ? 4096 : 4096];
+};
+
+__global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames, const TileJob *jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
+  __shared__ EntropyLds L;
+  const int job = blockIdx.x;
+  if (job >= njobs) return;
+  const TileJob tj = jobs[job];
+  const FrameDev *f = frames + tj.frame;
+  TileWriter w;
+  w.f = f;
+  w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
+  w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
+  w.cdf = L.cdf; w.qc = L.qc; w.lev = L.lev; w.cdef_done = L.cdef_done;
+  w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
+  for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
+  for (int i = LANE; i < 4096; i += 64) L.cdef_done[i] = 0;
+  re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
+  WAVE_SYNC();
+  for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
+    for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
+      WritePart<4>::run(&w, r, c);
+  WAVE_SYNC();
+  if (LANE == 0) {
+    const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
+    (void)ti;
+    uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
+    f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
+  }
+}

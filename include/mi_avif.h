@@ -1,0 +1,103 @@
+/* mi_avif.h -- C ABI of the MI355X-native AV1 still-picture encode path (libmi_avif.so).
+ *
+ * Drop-in boundary for the one hot path cavif-rs delegates to rav1e.  The reference has no FFI here: the
+ * path sits behind rav1e's Rust API, used in ravif/src/av1encoder.rs:749-771 (encode_to_av1) and configured
+ * at :662-708 (rav1e_config).  Each entry point below names the reference interface it stands in for; the
+ * Rust binding a ravif maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: every function is re-entrant and thread-safe (no global mutable state beyond per-device
+ * read-only tables built on first use); each call/batch owns its HIP stream.  All pointers are plain host
+ * pointers unless a name says `dev`.  Buffers returned through `uint8_t**` / mi_encoded_image are owned by
+ * the caller and released with mi_free().
+ *
+ * Status codes mirror ravif::Error (ravif/src/error.rs:7-25) plus the builder asserts (:117,146,159,188).
+ */
+#ifndef MI_AVIF_H
+#define MI_AVIF_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MI_OK = 0, MI_TOO_FEW_PIXELS = 1, MI_UNSUPPORTED = 2, MI_ENCODING_ERROR = 3, MI_INVALID_ARGUMENT = 4, MI_NO_DEVICE = 5 };
+
+/* ---- level 1: one AV1 frame; mirrors Av1EncodeConfig (:649-660) + SpeedTweaks (:533-552) ---- */
+typedef struct mi_av1_config {
+  uint32_t width, height;
+  uint8_t bit_depth;        /* 8 | 10 */
+  uint8_t quantizer;        /* rav1e quantizer 0..255 */
+  uint8_t speed;            /* 1..10 (informational once the tweaks below are filled) */
+  uint8_t chroma;           /* 0 = Cs444, 1 = Cs400 */
+  uint8_t pixel_range;      /* 0 = Limited, 1 = Full */
+  int32_t threads;          /* <=0: unspecified (only bounds the tile count, :665-668) */
+  int8_t has_color_desc; uint8_t matrix, transfer, primaries;
+  /* resolved SpeedTweaks (mi_av1_tweaks_from_preset fills them; callers may override) */
+  uint8_t part_min, part_max, complex_pred_modes, sgr_full, encode_bottomup, rdo_tx_decision,
+          reduced_tx_set, fine_directional_intra, fast_deblock, lrf, cdef, inter_tx_split, tx_domain_rate;
+  int8_t tx_domain_distortion;
+  uint16_t min_tile_size;
+  int32_t tiles_override;   /* >0 forces the tile target (tests) */
+  int32_t device;           /* HIP ordinal */
+} mi_av1_config;
+
+/* SpeedTweaks::from_my_preset (ravif/src/av1encoder.rs:554-606) */
+int mi_av1_tweaks_from_preset(uint8_t speed, uint8_t quantizer, mi_av1_config *cfg);
+/* quality_to_quantizer (ravif/src/av1encoder.rs:526-530) */
+int mi_quality_to_quantizer(float quality);
+/* rgb_to_ycbcr + casts (ravif/src/av1encoder.rs:504-524), host evaluation of the same f32 FMA chain (known-answer tests) */
+void mi_rgb_to_ycbcr(const uint8_t rgb[3], int depth, uint16_t out[3]);
+
+/* encode_to_av1 (ravif/src/av1encoder.rs:749-771): planes are host pointers to 8-bit (uint8) or 10-bit (uint16)
+ * samples, Y/U/V or a single plane for Cs400.  Returns the concatenated KEY-frame OBUs (TD + sequence header +
+ * frame).  recon (optional, may be NULL) receives malloc'd uint16 planes of the final reconstruction. */
+int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], const size_t stride_bytes[3],
+                         uint8_t **out_obu, size_t *out_len, uint16_t *recon[3]);
+
+/* ---- level 2: ravif::Encoder (:67-86) and EncodedImage (:54-61) ---- */
+typedef struct mi_ravif_encoder {
+  float quality, alpha_quality;   /* with_quality :116, with_alpha_quality :145 */
+  uint8_t speed;                  /* with_speed :158 */
+  uint8_t color_model;            /* 0 YCbCr, 1 RGB (with_internal_color_model :174) */
+  uint8_t depth;                  /* 8, 10, 0 = Auto (== 10, :266,:339) */
+  uint8_t alpha_mode;             /* 0 UnassociatedDirty, 1 UnassociatedClean, 2 Premultiplied (:197) */
+  int32_t threads;                /* with_num_threads :187; <=0 = None */
+  const uint8_t *exif; size_t exif_len;
+  int32_t device;
+  int32_t tiles_override;
+} mi_ravif_encoder;
+
+typedef struct mi_encoded_image { uint8_t *avif_file; size_t avif_len, color_byte_size, alpha_byte_size; } mi_encoded_image;
+
+void mi_ravif_encoder_default(mi_ravif_encoder *e);                      /* Encoder::new (:88-102) */
+int  mi_ravif_encode_rgba(const mi_ravif_encoder *e, const uint8_t *rgba, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out);  /* :243 */
+int  mi_ravif_encode_rgb (const mi_ravif_encoder *e, const uint8_t *rgb,  uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out);  /* :318 */
+/* encode_raw_planes_8_bit / _10_bit (:366,:390): interleaved [Y,U,V] triples + optional alpha plane */
+int  mi_ravif_encode_raw_planes_8 (const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint8_t  *yuv, const uint8_t  *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out);
+int  mi_ravif_encode_raw_planes_10(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint16_t *yuv, const uint16_t *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out);
+
+/* ---- batch: the data-parallel path (src/main.rs:223 files.into_par_iter()); images resident in HBM ---- */
+typedef struct mi_batch mi_batch;
+/* n images of w x h, channels 3 (RGB8) or 4 (RGBA8) on HIP device `e->device` */
+mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels);
+int  mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px);   /* H2D into the batch's HBM input slot */
+int  mi_batch_encode(mi_batch *b);                                                        /* the hot path over all resident images */
+int  mi_batch_get(mi_batch *b, int index, mi_encoded_image *out);                         /* copies; caller frees avif_file */
+int  mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]);          /* malloc'd w*h uint16 planes (tests) */
+/* per-kernel HIP-event time (ms) of the last mi_batch_encode: 0 front-end, 1 tile search, 2 deblock, 3 cdef, 4 entropy, 5 pack+D2H, 6 host assembly */
+double mi_batch_stage_ms(const mi_batch *b, int stage);
+int  mi_batch_num_tiles(const mi_batch *b);
+void mi_batch_destroy(mi_batch *b);
+
+/* AVIF container (avif-serialize Aviffy::to_vec, call site ravif/src/av1encoder.rs:457-473) */
+size_t mi_avif_serialize(const uint8_t *color, size_t color_len, const uint8_t *alpha, size_t alpha_len,
+                         uint32_t w, uint32_t h, uint8_t depth, uint8_t matrix, int premultiplied,
+                         const uint8_t *exif, size_t exif_len, uint8_t **out);
+int  mi_device_count(void);
+void mi_free(void *p);
+const char *mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
