@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- MPix/s of the AVIF still-image encode hot path (speed=4, quality=80, 1080p batch) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
+torch.distributed.run, one rank per GPU.  A step = one pass of the hot path (K0 front end -> K1 tile
+search -> K2 deblock -> K3 CDEF -> K4 entropy coding -> pack/D2H -> host OBU+container assembly) over one
+batch of synthetic images that is ALREADY RESIDENT in HBM (RGB8, uploaded before the timed region).
+Images shard across ranks with no data-path collective (weak scaling: --batch images per GPU).
+Rank 0 prints one JSON line; `roofline` is for the dominant kernel (tile search) from HIP events,
+`cpu_baseline` is the scalar C oracle (a port, not the reference) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_PX = {10: 10.0, 8: 7.0}   # 4 B RGBA8 in + 3*s source samples read once
+
+
+def _oracle_worker(job):
+    idx, w, h, speed, quality, depth = job
+    sys.path.insert(0, ROOT)
+    from cavif_rs_amd.synth import synth_image
+    from tests.helpers import oracle
+    img = synth_image(w, h, index=idx)
+    t = time.time()
+    data, cs, _ = oracle.ravif_encode(img, quality=quality, speed=speed, depth=depth)
+    return time.time() - t, len(data)
+
+
+def cpu_baseline(w, h, speed, quality, depth, max_seconds=30.0):
+    """Oracle (kind 'port') on the host cores: one image per worker process, bounded sample."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    try:
+        from tests.helpers import oracle
+        oracle.lib()
+    except Exception as e:      # oracle not built: report nothing rather than a fake number
+        return {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": "oracle unavailable: %s" % e}
+    jobs = [(i, w, h, speed, quality, depth) for i in range(cores)]
+    t = time.time()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        res = pool.map(_oracle_worker, jobs)
+    wall = time.time() - t
+    return {"value": round(len(jobs) * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, oracle/ scalar C, one process per image, %.1f s wall (%.1f s mean per image)"
+                      % (len(jobs), w, h, speed, quality, depth, wall, sum(r[0] for r in res) / len(res))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE config 4: 256 images / 8 GPUs)')
+    ap.add_argument('--width', type=int, default=1920)
+    ap.add_argument('--height', type=int, default=1080)
+    ap.add_argument('--speed', type=int, default=4)
+    ap.add_argument('--quality', type=float, default=80.0)
+    ap.add_argument('--depth', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-identity-check', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        # the path shards by image: the only cross-rank traffic is the barrier and the max-time reduction,
+        # so the CPU-side gloo group is enough (no RCCL collective exists on this data path).
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    import numpy as np
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+
+    ndev = m.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py: no HIP device visible; the HIP path is mandatory (no CPU fallback)')
+    device = local_rank % ndev
+    enc = m.Encoder().with_quality(args.quality).with_speed(args.speed).with_bit_depth(args.depth).with_device(device)
+    w, h, B = args.width, args.height, args.batch
+    batch = m.BatchEncoder(enc, B, w, h, channels=3)
+    first = None
+    for i in range(B):
+        img = synth_image(w, h, index=rank * B + i)
+        if i == 0:
+            first = img
+        batch.upload(i, img)          # H2D happens here, outside the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.encode()
+    barrier()
+    t0 = time.perf_counter()
+    search_ms, stage_acc = [], {}
+    for _ in range(args.steps):
+        batch.encode()                # returns after the stream is drained and the .avif bytes are on the host
+        st = batch.stage_ms()
+        search_ms.append(st['tile_search'])
+        for k_, v_ in st.items():
+            stage_acc[k_] = stage_acc.get(k_, 0.0) + v_
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    if rank == 0:
+        total_px = world * B * w * h * args.steps
+        value = total_px / 1e6 / elapsed
+        k1 = sum(search_ms) / len(search_ms) / 1e3                        # seconds per launch (HIP events, batch stream)
+        algo = ALGO_BYTES_PER_PX.get(args.depth, 10.0) * B * w * h           # algorithmic HBM-read bytes per launch
+        achieved = algo / k1 / 1e9
+        out = {
+            "metric": "MPix/s encoded at speed=4 q=80, 1080p batch; bit-exact vs CPU oracle",
+            "value": round(value, 3), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16 samples / i32 transform / i64 RD cost", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %dx%d RGB8 images per GPU, speed=%d quality=%g depth=%d, 4:4:4 BT.601, %d tiles per step per GPU"
+                                   % (B, w, h, args.speed, args.quality, args.depth, batch.num_tiles()),
+                       "images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth,
+                       "parallelism": "images sharded across %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(k1 * 1e3, 3)},
+            "stage_ms_per_step": {k_: round(v_ / args.steps, 3) for k_, v_ in stage_acc.items()},
+        }
+        if not args.no_identity_check:
+            try:
+                from tests.helpers import oracle
+                ref, _, _ = oracle.ravif_encode(first, quality=args.quality, speed=args.speed, depth=args.depth)
+                out["output_identity"] = bool(batch.get(0).avif_file == ref)
+            except Exception as e:
+                out["output_identity"] = "unchecked: %s" % e
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h, args.speed, args.quality, args.depth)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,39 @@
+"""The reference's own tests (ravif/src/lib.rs:43-147, tests/stdio.rs) re-expressed against the oracle: container
+well-formedness, payload size windows, determinism across entry points.  (The same windows are applied to the
+HIP path in test_gpu_parity.py through byte equality with the oracle.)"""
+import io
+import numpy as np
+from tests.helpers.images import rgba_gradient, rgba_opaque
+
+
+def test_encode8_with_alpha(oracle, avifdec):
+    """lib.rs:43-69: 256x200 RGBA, q22 / alpha q22, 8-bit, speed 1, dirty alpha, 2 threads."""
+    img = rgba_gradient()
+    data, color, alpha = oracle.ravif_encode(img, quality=22, alpha_quality=22, speed=1, depth=8, alpha_mode=0, threads=2)
+    assert 50 < color < 1000, color
+    assert 50 < alpha < 1000, alpha
+    d = avifdec.decode(data)
+    assert d['alpha'] is not None and d['depth'] == 8 and (d['width'], d['height']) == (256, 200)
+
+
+def test_encode8_opaque(oracle, avifdec):
+    """lib.rs:71-119: 129x101 opaque RGBA, q33, speed 10, auto depth (=10), 1 thread; RGB entry point is byte-identical."""
+    img = rgba_opaque()
+    data, color, alpha = oracle.ravif_encode(img, quality=33, speed=10, depth=0, threads=1)
+    assert alpha == 0
+    assert 150 < color < 500, 'size = %d; expected ~= 215' % color
+    d = avifdec.decode(data)
+    assert d['alpha'] is None and d['depth'] == 10 and (d['width'], d['height']) == (129, 101)
+    data2, color2, _ = oracle.ravif_encode(img[:, :, :3], quality=33, speed=10, depth=10, threads=1)
+    assert data2 == data and color2 == color
+
+
+def test_stdio_ftyp(oracle):
+    """tests/stdio.rs:23: bytes [4..12] == 'ftypavif' for the 128x85 fixture geometry at speed 10."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(85, 128, 3), dtype=np.uint8)
+    data, _, _ = oracle.ravif_encode(img, speed=10)
+    assert data[4:12] == b'ftypavif'
+    from PIL import Image
+    im = Image.open(io.BytesIO(data)); im.load()
+    assert im.size == (128, 85)

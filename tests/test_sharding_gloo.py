@@ -1,0 +1,45 @@
+"""N>1 path on CPU: the batch shards by image index across ranks with no data-path collective; the only
+cross-rank operations are a barrier and a MAX reduction of the elapsed time (bench.py).  world_size 2, gloo."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    import torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from cavif_rs_amd.synth import synth_image
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B = 3
+    mine = [rank * B + i for i in range(B)]                  # bench.py's shard rule
+    sig = [int(synth_image(32, 24, index=i).astype('int64').sum()) for i in mine]
+    got = [None] * world
+    dist.all_gather_object(got, (mine, sig))
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'shards': got, 'tmax': float(t[0])}))
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_two_rank_sharding(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29577', str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    idx = sorted(i for shard, _ in res['shards'] for i in shard)
+    assert idx == list(range(6))                         # disjoint cover of the global batch
+    sigs = [s for _, sg in res['shards'] for s in sg]
+    assert len(set(sigs)) == 6                           # every rank encodes different images
+    assert res['tmax'] == 2.0                            # MAX over ranks
