@@ -61,29 +61,28 @@ __device__ __forceinline__ int iclamp_(int v, int lo, int hi) { return v < lo ? 
 __device__ __forceinline__ int iabs_(int a) { return a < 0 ? -a : a; }
 __device__ __forceinline__ int round2_(int x, int n) { return n == 0 ? x : (x + (1 << (n - 1))) >> n; }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    int lo = __shfl_xor((int)(v & 0xffffffffLL), o, 64);
-    int hi = __shfl_xor((int)(v >> 32), o, 64);
-    v += ((long long)hi << 32) | (unsigned int)lo;
-  }
-  return v;
-}
+// Wave-wide reductions on the DPP network (no LDS round trips): quad_perm, row_half_mirror, row_mirror,
+// row_bcast:15, row_bcast:31; the total lands in lane 63 and is broadcast through an SGPR.
+#define DPP_(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rmask), 0xF, false)
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += DPP_(0, v, 0xB1, 0xF); v += DPP_(0, v, 0x4E, 0xF); v += DPP_(0, v, 0x141, 0xF); v += DPP_(0, v, 0x140, 0xF);
+  v += DPP_(0, v, 0x142, 0xA); v += DPP_(0, v, 0x143, 0xC);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = imax_(v, __shfl_xor(v, o, 64));
-  return v;
+  v = imax_(v, DPP_(v, v, 0xB1, 0xF)); v = imax_(v, DPP_(v, v, 0x4E, 0xF)); v = imax_(v, DPP_(v, v, 0x141, 0xF)); v = imax_(v, DPP_(v, v, 0x140, 0xF));
+  v = imax_(v, DPP_(v, v, 0x142, 0xA)); v = imax_(v, DPP_(v, v, 0x143, 0xC));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_or_i32(int v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
+  v |= DPP_(0, v, 0xB1, 0xF); v |= DPP_(0, v, 0x4E, 0xF); v |= DPP_(0, v, 0x141, 0xF); v |= DPP_(0, v, 0x140, 0xF);
+  v |= DPP_(0, v, 0x142, 0xA); v |= DPP_(0, v, 0x143, 0xC);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// 64-bit sum as two carry-free 32-bit sums of the 24-bit-split halves (each lane's partial must be < 2^40)
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+  const int lo = wave_sum_i32((int)(v & 0xFFFFFF)), hi = wave_sum_i32((int)(v >> 24));
+  return ((long long)hi << 24) + (long long)lo;
 }
 // single-wave workgroup: orders this wave's LDS/global traffic between phases
 #define WAVE_SYNC() __syncthreads()
@@ -111,12 +110,17 @@ __device__ __forceinline__ int tx_class_of(int t) {
   if (t == H_DCT || t == H_ADST || t == H_FLIPADST) return TXC_HORIZ;
   return TXC_2D;
 }
+// LDS copy of the default scans: [4x4 | 8x8 | 16x16 | 32x32] = 16 + 64 + 256 + 1024 entries
+#define SCAN_LDS_ENTRIES(maxn) ((maxn) >= 32 ? 1360 : 336)
+__device__ inline void load_scans_to_lds(uint16_t *ls, int maxn) {
+  for (int i = LANE; i < 16; i += 64) ls[i] = av1_default_scan_4x4[i];
+  for (int i = LANE; i < 64; i += 64) ls[16 + i] = av1_default_scan_8x8[i];
+  for (int i = LANE; i < 256; i += 64) ls[80 + i] = av1_default_scan_16x16[i];
+  if (maxn >= 32) for (int i = LANE; i < 1024; i += 64) ls[336 + i] = av1_default_scan_32x32[i];
+}
 // scan position i -> raster position within the n x n coded area (n = min(32, tx size))
-__device__ __forceinline__ int scan_pos(int n, int cls, int i) {
-  if (cls == TXC_2D) {
-    switch (n) { case 4: return av1_default_scan_4x4[i]; case 8: return av1_default_scan_8x8[i];
-                 case 16: return av1_default_scan_16x16[i]; default: return av1_default_scan_32x32[i]; }
-  }
+__device__ __forceinline__ int scan_pos(const uint16_t *ls, int n, int cls, int i) {
+  if (cls == TXC_2D) return ls[(n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336) + i];
   if (cls == TXC_VERT) return i;                       // mrow scan
   const int c = i / n, r = i - c * n; return r * n + c; // mcol scan
 }

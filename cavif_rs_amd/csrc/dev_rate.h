@@ -72,18 +72,17 @@ __device__ __forceinline__ int br_ctx(const uint8_t *L, int st, int cls, int row
 
 // Fills the padded level map (LDS, (n+4)^2 bytes) from qc; all lanes.
 __device__ inline void build_level_map(const int32_t *qc, uint8_t *lev, int n) {
-  const int st = n + 4, tot = st * st;
-  for (int i = LANE; i < tot; i += 64) {
-    const int r = i / st, c = i - r * st;
-    lev[i] = (r < n && c < n) ? (uint8_t)imin_(iabs_(qc[r * n + c]), 127) : 0;
-  }
+  const int st = n + 4, words = (st * st + 3) >> 2, bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
+  uint32_t *lw = (uint32_t *)lev;                       // lev is 4-byte aligned and padded to a whole word
+  for (int i = LANE; i < words; i += 64) lw[i] = 0;
+  WAVE_SYNC();
+  for (int i = LANE; i < n * n; i += 64) lev[(i >> bwl) * st + (i & (n - 1))] = (uint8_t)imin_(iabs_(qc[i]), 127);
   WAVE_SYNC();
 }
 
 // Rate (1/512 bit) of coeffs() for one transform block. tx_off >= 0: luma tx-type symbol is priced too.
-__device__ inline uint32_t coef_rate_dev(const FrameDev *f, const int32_t *qc, int eob, int plane, int txs, int txtype,
+__device__ inline uint32_t coef_rate_dev(const uint16_t *cost, const uint16_t *ls, const int32_t *qc, int eob, int plane, int txs, int txtype,
                                          int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint8_t *lev, int *cul_out, int *dc_cat) {
-  const uint16_t *cost = f->cost;
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   *cul_out = 0; *dc_cat = 0;
@@ -99,9 +98,9 @@ __device__ inline uint32_t coef_rate_dev(const FrameDev *f, const int32_t *qc, i
   }
   build_level_map(qc, lev, n);
   const int st = n + 4, area = n * n;
-  long long bits = 0; int cul = 0, dcc = 0;
+  int bits = 0; int cul = 0, dcc = 0;
   for (int c = LANE; c < eob; c += 64) {
-    const int p = scan_pos(n, cls, c), row = p >> bwl, col = p & (n - 1);
+    const int p = scan_pos(ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
     const int v = qc[p], level = iabs_(v);
     const uint8_t *L = lev + row * st + col;
     if (c == eob - 1) {
@@ -124,7 +123,7 @@ __device__ inline uint32_t coef_rate_dev(const FrameDev *f, const int32_t *qc, i
     }
     cul += level;
   }
-  bits = wave_sum_i64(bits);
+  bits = wave_sum_i32(bits);
   cul = wave_sum_i32(imin_(cul, 1 << 20));
   dcc = wave_max_i32(dcc);
   *cul_out = imin_(cul, 63); *dc_cat = dcc;

@@ -92,31 +92,31 @@ template <int N> __device__ inline void inv_txfm2d_add_dev(const int32_t *dq, in
   WAVE_SYNC();
 }
 
-// returns eob (wave-uniform); qc [CS*CS]
-__device__ inline int quantize_dev(const int32_t *coef, int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq) {
+// returns eob (wave-uniform); qc [CS*CS].  All magnitudes fit 32 bits (|coef| < 2^22, q < 2^13).
+__device__ inline int quantize_dev(const uint16_t *ls, const int32_t *coef, int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq) {
   const int nc = n * n, cls = tx_class_of(txtype);
-  const int ls = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
-  const int dc_off = dcq * 109 / 256, off0 = acq * 98 / 256, off1 = acq * 109 / 256, off_eob = acq * 88 / 256;
-  const long long thr = acq - off_eob;
+  const int lsh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
+  const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
+  const uint32_t thr = (uint32_t)acq - off_eob, uq = (uint32_t)acq;
   int last = 0;
   for (int i = LANE; i < nc; i += 64) {
-    if (i >= 1) { const int p = scan_pos(n, cls, i); if (((long long)iabs_(coef[p]) << ls) >= thr) last = i + 1; }
+    if (i >= 1) { const int p = scan_pos(ls, n, cls, i); if (((uint32_t)iabs_(coef[p]) << lsh) >= thr) last = i + 1; }
   }
   last = wave_max_i32(last);
-  const long long a0 = (long long)iabs_(coef[0]) << ls;
-  const int l0 = (int)((a0 + dc_off) / dcq);
+  const uint32_t a0 = (uint32_t)iabs_(coef[0]) << lsh;
+  const int l0 = (int)((a0 + dc_off) / (uint32_t)dcq);
   int eob = last;
   if (eob == 0) eob = l0 ? 1 : 0;
   for (int i = LANE; i < nc; i += 64) {
-    const int p = scan_pos(n, cls, i);
+    const int p = scan_pos(ls, n, cls, i);
     int v = 0;
     if (i < eob) {
       if (i == 0) v = coef[0] < 0 ? -l0 : l0;
       else {
-        const long long a = (long long)iabs_(coef[p]) << ls;
-        const int lv0 = (int)(a / acq);
-        const int off = lv0 > 0 ? off1 : off0;
-        const int lv = lv0 + ((a + off) >= (long long)(lv0 + 1) * acq);
+        const uint32_t a = (uint32_t)iabs_(coef[p]) << lsh;
+        const uint32_t lv0 = a / uq;
+        const uint32_t off = lv0 > 0 ? off1 : off0;
+        const int lv = (int)lv0 + ((a + off) >= (lv0 + 1) * uq);
         v = coef[p] < 0 ? -lv : lv;
       }
     }
@@ -130,11 +130,11 @@ __device__ inline void dequantize_dev(const int32_t *qc, int32_t *dq, int n, int
   const int nc = n * n, sh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
   const int mx = (1 << (7 + bd)) - 1, mn = -(1 << (7 + bd));
   for (int i = LANE; i < nc; i += 64) {
-    const int q = i == 0 ? dcq : acq;
-    long long v = (long long)iabs_(qc[i]) * q;
-    v &= 0xFFFFFF; v >>= sh;
-    if (qc[i] < 0) v = -v;
-    dq[i] = (int32_t)(v < mn ? mn : (v > mx ? mx : v));
+    const uint32_t q = (uint32_t)(i == 0 ? dcq : acq);
+    uint32_t m = (uint32_t)iabs_(qc[i]) * q;        // < 2^32 for every level this encoder can emit
+    m &= 0xFFFFFF; m >>= sh;
+    const int v = qc[i] < 0 ? -(int)m : (int)m;
+    dq[i] = v < mn ? mn : (v > mx ? mx : v);
   }
   WAVE_SYNC();
 }

@@ -132,7 +132,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 }
 
 template <int MAXBS> static hipError_t launch_search(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
-  const size_t lds = sizeof(Scratch<(4 << MAXBS)>);
+  const size_t lds = ((sizeof(Scratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + (CDF_TOTAL + SCAN_LDS_ENTRIES(4 << MAXBS)) * 2;
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_search_kernel<MAXBS>, dim3(njobs), dim3(64), lds, s, d_frames, d_jobs, njobs);

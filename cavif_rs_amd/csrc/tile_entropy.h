@@ -79,7 +79,7 @@ __device__ inline uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t 
 
 struct TileWriter {
   const FrameDev *f; TileB t; RangeEncDev ec; uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
-  int32_t *qc; uint8_t *lev;                                    // LDS staging
+  int32_t *qc; uint8_t *lev; const uint16_t *ls;               // LDS staging + LDS copy of the scan tables
   uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
   int sb_cols_tile;
 };
@@ -102,7 +102,7 @@ __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int 
   }
   const int st = n + 4, area = n * n;
   for (int c = eob - 1; c >= 0; c--) {
-    const int p = scan_pos(n, cls, c), row = p >> bwl, col = p & (n - 1);
+    const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
     const int level = iabs_(qc[p]);
     const uint8_t *L = lev + row * st + col;
     if (c == eob - 1) {
@@ -120,7 +120,7 @@ __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int 
     }
   }
   for (int c = 0; c < eob; c++) {
-    const int p = scan_pos(n, cls, c), v = qc[p], a = iabs_(v);
+    const int p = scan_pos(w->ls, n, cls, c), v = qc[p], a = iabs_(v);
     if (a) {
       if (c == 0) re_symbol_dev(e, v < 0, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
       else re_bool_dev(e, v < 0, 16384);
@@ -230,6 +230,7 @@ struct EntropyLds {
   uint16_t cdf[CDF_TOTAL];
   int32_t qc[32 * 32];
   uint8_t lev[36 * 36 + 4];
+  uint16_t scans[1360];
   uint8_t cdef_done[MI_MAX_TILE_COLS * MI_MAX_TILE_ROWS > 4096 ? 4096 : 4096];
 };
 
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   w.f = f;
   w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  w.cdf = L.cdf; w.qc = L.qc; w.lev = L.lev; w.cdef_done = L.cdef_done;
+  w.cdf = L.cdf; w.qc = L.qc; w.lev = L.lev; w.cdef_done = L.cdef_done; w.ls = L.scans;
+  load_scans_to_lds(L.scans, 32);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
   for (int i = LANE; i < 4096; i += 64) L.cdef_done[i] = 0;

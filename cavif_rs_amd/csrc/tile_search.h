@@ -27,6 +27,7 @@ struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
 
 template <int MAXN> struct Ctx {
   const FrameDev *f; TileB t; Scratch<MAXN> *s; uint8_t *snap;
+  const uint16_t *cost, *ls;      // LDS copies of the static rate table and the scan tables
 };
 
 __device__ __forceinline__ const int *intra_mode_ctx_tab() { static __device__ const int t[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }; return t; }
@@ -73,7 +74,7 @@ __device__ inline long long sse_dev(const uint16_t *a, const uint16_t *b, int nn
 }
 
 template <int MAXN, int BS>
-__device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int r, int c, const uint16_t *pred, int txtype, int tx_off, int tx_sym,
+__device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     uint16_t *rec_out, int32_t *qc_out, TxRes *tr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
   const FrameDev *f = k.f; Scratch<MAXN> *S = k.s;
@@ -85,10 +86,8 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int r, int c, const
   }
   WAVE_SYNC();
   fwd_txfm2d_dev<n>(S->tbuf, S->cbuf, txtype);
-  const int eob = quantize_dev(S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane]);
-  int sctx, dctx;
-  txb_ctx_dev(f, &k.t, plane, r, c, BS, BS, &sctx, &dctx);
-  tr->rate = coef_rate_dev(f, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
+  const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane]);
+  tr->rate = coef_rate_dev(k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
   if (eob > 0) {
     dequantize_dev(qc_out, S->dq, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
     inv_txfm2d_add_dev<n>(S->dq, S->tbuf, rec_out, txtype, f->bd);
@@ -129,13 +128,15 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
   const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
   const int *imc = intra_mode_ctx_tab();
-  const uint16_t *ycost = f->cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
+  const uint16_t *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
   const int ftype_y = (availU && IS_SMOOTH_(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH_(f->m_ymode[mi - 1]));
   int ftype_uv = 0;
   if (f->np > 1) ftype_uv = (availU && IS_SMOOTH_(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH_(f->m_uvmode[mi - 1]));
   uint16_t *ra = S->ra + EDGE_OFF, *rl = S->rl + EDGE_OFF, *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
 
   for (int p = 0; p < f->np; p++) load_src_block<MAXN, BS>(k, p, r, c);
+  int sctx_p[3] = { 0, 0, 0 }, dctx_p[3] = { 0, 0, 0 };      // all-zero / dc-sign contexts depend on the neighbours only
+  for (int p = 0; p < f->np; p++) txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx_p[p], &dctx_p[p]);
   if (f->dbg == 2) return 0;
   load_edges(f, 0, x, y, n, availL, availU, have_ar, have_bl, ra, rl);   // ends with WAVE_SYNC
   if (f->dbg == 3) return 0;
@@ -170,7 +171,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     }
     predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
     uint32_t mode_rate = ycost[m];
-    if (directional && BS >= BS_8) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+    if (directional && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
     const int tx_off = intra_tx_cdf(f, BS, m, &tx_ns, &tx_set);
     const int ntx = (f->rdo_tx && tx_off >= 0) ? tx_ns : 1;
     for (int ti = 0; ti < ntx; ti++) {
@@ -178,7 +179,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
       if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
       else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
       TxRes tr;
-      long long j = eval_tx<MAXN, BS>(k, 0, r, c, S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec_tmp, S->qc_tmp, &tr);
+      long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec_tmp, S->qc_tmp, &tr);
       j += ((long long)mode_rate * f->rdmult + 256) >> 9;
       if (j < best_j) {
         best_j = j; best_mode = m; best_delta = delta; best_tx = txtype; best_tr = tr;
@@ -200,7 +201,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   // ---- chroma ----
   if (f->np > 1) {
     const int cfl_allowed = BS <= BS_32;
-    const uint16_t *uvcost = cfl_allowed ? f->cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : f->cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
+    const uint16_t *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
     cands[nc++] = DC_PRED;
     if (best_mode != DC_PRED) cands[nc++] = best_mode;
@@ -215,7 +216,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
       const int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && BS >= BS_8) ? best_delta : 0;
       int alpha[3] = { 0, 0, 0 }, jsign = 0;
       uint32_t mode_rate = uvcost[um];
-      if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += f->cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+      if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       long long j = 0; TxRes trs[3]; int ok = 1;
@@ -255,9 +256,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
         else {
           const int su = alpha[1] == 0 ? 0 : (alpha[1] < 0 ? 1 : 2), sv = alpha[2] == 0 ? 0 : (alpha[2] < 0 ? 1 : 2);
           jsign = su * 3 + sv - 1;
-          mode_rate += f->cost[CDF_CFL_SIGN + jsign];
-          if (su) mode_rate += f->cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[1]) - 1];
-          if (sv) mode_rate += f->cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[2]) - 1];
+          mode_rate += k.cost[CDF_CFL_SIGN + jsign];
+          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[1]) - 1];
+          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[2]) - 1];
         }
       }
       if (!ok) continue;
@@ -270,7 +271,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
         } else {
           predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, ra, rl, wa, wl, S->etmp, S->pred);
         }
-        j += eval_tx<MAXN, BS>(k, p, r, c, S->pred, txtype, -1, 0, S->rec_best[p], S->qc_best[p], &trs[p]);
+        j += eval_tx<MAXN, BS>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec_best[p], S->qc_best[p], &trs[p]);
       }
       j += ((long long)mode_rate * f->rdmult + 256) >> 9;
       if (j < best_uv) {
@@ -297,7 +298,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   fill_map_dev(f->m_skip, ms, r, c, n4, skip);
   if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
   const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
-  total_j += ((long long)f->cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
+  total_j += ((long long)k.cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
   set_decoded_dev(f, r, c, n4, 1);
   return total_j;
 }
@@ -337,11 +338,11 @@ template <int BS> __device__ inline void area_copy_dev(const FrameDev *f, uint8_
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 16 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
-__device__ inline uint32_t partition_rate_dev(const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
+__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
-  return f->cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
+  return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
 template <int MAXN, int MAXBS, int BS> struct RdPart {
@@ -357,15 +358,15 @@ template <int MAXN, int MAXBS, int BS> struct RdPart {
     int do_split = must_split;
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        const long long j_none = try_block<MAXN, BS>(k, r, c) + (((long long)partition_rate_dev(f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
+        const long long j_none = try_block<MAXN, BS>(k, r, c) + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
         area_copy_dev<BS>(f, k.snap, r, c, 1);
         set_decoded_dev(f, r, c, n4, 0);
-        long long j_split = ((long long)partition_rate_dev(f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
+        long long j_split = ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
         for (int q = 0; q < 4 && j_split < j_none && f->dbg != 7; q++) {
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
           j_split += try_block<MAXN, BS - 1>(k, rr, cc);
-          if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
+          if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
         }
         if (j_split < j_none && f->dbg != 7 && f->dbg != 8 && !(f->dbg == 10 && BS == 1)) do_split = 1;
         else { area_copy_dev<BS>(f, k.snap, r, c, 0); set_decoded_dev(f, r, c, n4, 1); }
@@ -397,6 +398,14 @@ __global__ __launch_bounds__(64) void tile_search_kernel(const FrameDev *frames,
   const FrameDev *f = frames + tj.frame;
   Ctx<MAXN> k;
   k.f = f; k.s = (Scratch<MAXN> *)smem;
+  {
+    uint16_t *lc = (uint16_t *)(smem + ((sizeof(Scratch<MAXN>) + 15) & ~(size_t)15));
+    uint16_t *lsc = lc + CDF_TOTAL;
+    for (int i = LANE; i < CDF_TOTAL; i += 64) lc[i] = f->cost[i];
+    load_scans_to_lds(lsc, MAXN);
+    k.cost = lc; k.ls = lsc;
+    WAVE_SYNC();
+  }
   k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
