@@ -49,11 +49,14 @@ struct FrameDev {
   uint32_t tile_out_cap;
   int tile_base;             // index of this frame's first tile in the launch-wide tile list
   int dbg;                   // debug bisect level (0 = off)
+  unsigned long long *tile_clk;  // per tile: [start, end] of K1 and of K4 in wall_clock64 ticks (100 MHz), 4 values
 };
 
 struct TileJob { int frame; int tile_row, tile_col; };
 
 #define LANE ((int)(threadIdx.x & 63))
+// Explicit LDS address space: pointers carrying it compile to ds_read/ds_write instead of flat_* accesses.
+#define LDS __attribute__((address_space(3)))
 
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
@@ -112,14 +115,14 @@ __device__ __forceinline__ int tx_class_of(int t) {
 }
 // LDS copy of the default scans: [4x4 | 8x8 | 16x16 | 32x32] = 16 + 64 + 256 + 1024 entries
 #define SCAN_LDS_ENTRIES(maxn) ((maxn) >= 32 ? 1360 : 336)
-__device__ inline void load_scans_to_lds(uint16_t *ls, int maxn) {
+__device__ inline void load_scans_to_lds(LDS uint16_t *ls, int maxn) {
   for (int i = LANE; i < 16; i += 64) ls[i] = av1_default_scan_4x4[i];
   for (int i = LANE; i < 64; i += 64) ls[16 + i] = av1_default_scan_8x8[i];
   for (int i = LANE; i < 256; i += 64) ls[80 + i] = av1_default_scan_16x16[i];
   if (maxn >= 32) for (int i = LANE; i < 1024; i += 64) ls[336 + i] = av1_default_scan_32x32[i];
 }
 // scan position i -> raster position within the n x n coded area (n = min(32, tx size))
-__device__ __forceinline__ int scan_pos(const uint16_t *ls, int n, int cls, int i) {
+__device__ __forceinline__ int scan_pos(const LDS uint16_t *ls, int n, int cls, int i) {
   if (cls == TXC_2D) return ls[(n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336) + i];
   if (cls == TXC_VERT) return i;                       // mrow scan
   const int c = i / n, r = i - c * n; return r * n + c; // mcol scan

@@ -55,7 +55,7 @@ __device__ __forceinline__ int edge_upsample_sel_dev(int w, int h, int ft, int d
 
 // Raw (unfiltered) edges of the block at pixel (x,y) of `plane`: above[-1..2n-1], left[-1..2n-1]. (spec 7.11.2 steps 1-4)
 __device__ inline void load_edges(const FrameDev *f, int plane, int x, int y, int n, int have_left, int have_above,
-                                  int have_ar, int have_bl, uint16_t *above /* +EDGE_OFF */, uint16_t *left) {
+                                  int have_ar, int have_bl, LDS uint16_t *above /* +EDGE_OFF */, LDS uint16_t *left) {
   const int bd = f->bd, rs = f->stride;
   const uint16_t *rec = f->rec[plane];
   const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
@@ -81,7 +81,7 @@ __device__ inline void load_edges(const FrameDev *f, int plane, int x, int y, in
   WAVE_SYNC();
 }
 
-__device__ inline void edge_filter_dev(uint16_t *buf, int sz, int strength, uint16_t *tmp) {
+__device__ inline void edge_filter_dev(LDS uint16_t *buf, int sz, int strength, LDS uint16_t *tmp) {
   if (!strength) return;
   for (int i = LANE; i < sz; i += 64) tmp[i] = buf[i - 1];
   WAVE_SYNC();
@@ -97,7 +97,7 @@ __device__ inline void edge_filter_dev(uint16_t *buf, int sz, int strength, uint
   }
   WAVE_SYNC();
 }
-__device__ inline void edge_upsample_dev(uint16_t *buf, int num_px, int bd, uint16_t *tmp) {
+__device__ inline void edge_upsample_dev(LDS uint16_t *buf, int num_px, int bd, LDS uint16_t *tmp) {
   // dup[0] = buf[-1]; dup[i+2] = buf[i] (i=-1..num_px-1); dup[num_px+2] = buf[num_px-1]
   for (int i = LANE; i < num_px + 3; i += 64) {
     uint16_t v;
@@ -118,8 +118,8 @@ __device__ inline void edge_upsample_dev(uint16_t *buf, int num_px, int bd, uint
 
 // Predict an n x n block into pred[n*n] from raw edges. wa/wl are working copies (modified by filters).
 __device__ inline void predict_block(const FrameDev *f, int x, int y, int log2w, int have_left, int have_above,
-                                     int mode, int angle_delta, int ftype, const uint16_t *ra, const uint16_t *rl,
-                                     uint16_t *wa, uint16_t *wl, uint16_t *tmp, uint16_t *pred) {
+                                     int mode, int angle_delta, int ftype, const LDS uint16_t *ra, const LDS uint16_t *rl,
+                                     LDS uint16_t *wa, LDS uint16_t *wl, LDS uint16_t *tmp, LDS uint16_t *pred) {
   const int n = 1 << log2w, bd = f->bd, nn = n * n;
   const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
   if (mode == PAETH_PRED) {
@@ -204,7 +204,7 @@ __device__ inline void predict_block(const FrameDev *f, int x, int y, int log2w,
 }
 
 // spec 7.11.5 (4:4:4): pred holds the DC prediction on entry; luma reconstruction read from f->rec[0].
-__device__ inline void predict_cfl_dev(const FrameDev *f, int x, int y, int log2w, int alpha, const uint16_t *dcp, uint16_t *out) {
+__device__ inline void predict_cfl_dev(const FrameDev *f, int x, int y, int log2w, int alpha, const LDS uint16_t *dcp, LDS uint16_t *out) {
   const int n = 1 << log2w, nn = n * n, mx = (1 << f->bd) - 1, rs = f->stride;
   const uint16_t *luma = f->rec[0] + y * rs + x;
   int s = 0;

@@ -45,7 +45,7 @@ __device__ __forceinline__ int eob_pt_cdf(int eob_multi, int pt, int cls) {
   return off[eob_multi] + (pt * 2 + (cls == TXC_2D ? 0 : 1)) * str[eob_multi];
 }
 // context of coeff_base (not the eob position) from the padded level map; L points at this coefficient
-__device__ __forceinline__ int base_ctx(const uint8_t *L, int st, int cls, int row, int col) {
+__device__ __forceinline__ int base_ctx(const LDS uint8_t *L, int st, int cls, int row, int col) {
   int mag = imin_(L[1], 3) + imin_(L[st], 3);
   if (cls == TXC_2D) {
     mag += imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3);
@@ -63,7 +63,7 @@ __device__ __forceinline__ int base_ctx(const uint8_t *L, int st, int cls, int r
   const int m = imin_((mag + 1) >> 1, 4);
   return m + (col == 0 ? 26 : (col == 1 ? 31 : 36));
 }
-__device__ __forceinline__ int br_ctx(const uint8_t *L, int st, int cls, int row, int col, int c) {
+__device__ __forceinline__ int br_ctx(const LDS uint8_t *L, int st, int cls, int row, int col, int c) {
   int mag = imin_(L[1], 15) + imin_(L[st], 15);
   if (cls == TXC_2D) { mag += imin_(L[st + 1], 15); mag = imin_((mag + 1) >> 1, 6); return c == 0 ? mag : ((row < 2 && col < 2) ? mag + 7 : mag + 14); }
   if (cls == TXC_HORIZ) { mag += imin_(L[2], 15); mag = imin_((mag + 1) >> 1, 6); return c == 0 ? mag : (col == 0 ? mag + 7 : mag + 14); }
@@ -71,9 +71,9 @@ __device__ __forceinline__ int br_ctx(const uint8_t *L, int st, int cls, int row
 }
 
 // Fills the padded level map (LDS, (n+4)^2 bytes) from qc; all lanes.
-__device__ inline void build_level_map(const int32_t *qc, uint8_t *lev, int n) {
+__device__ inline void build_level_map(const LDS int32_t *qc, LDS uint8_t *lev, int n) {
   const int st = n + 4, words = (st * st + 3) >> 2, bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
-  uint32_t *lw = (uint32_t *)lev;                       // lev is 4-byte aligned and padded to a whole word
+  LDS uint32_t *lw = (LDS uint32_t *)lev;                       // lev is 4-byte aligned and padded to a whole word
   for (int i = LANE; i < words; i += 64) lw[i] = 0;
   WAVE_SYNC();
   for (int i = LANE; i < n * n; i += 64) lev[(i >> bwl) * st + (i & (n - 1))] = (uint8_t)imin_(iabs_(qc[i]), 127);
@@ -81,8 +81,8 @@ __device__ inline void build_level_map(const int32_t *qc, uint8_t *lev, int n) {
 }
 
 // Rate (1/512 bit) of coeffs() for one transform block. tx_off >= 0: luma tx-type symbol is priced too.
-__device__ inline uint32_t coef_rate_dev(const uint16_t *cost, const uint16_t *ls, const int32_t *qc, int eob, int plane, int txs, int txtype,
-                                         int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint8_t *lev, int *cul_out, int *dc_cat) {
+template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(CostPtr cost, const LDS uint16_t *ls, const LDS int32_t *qc, int eob, int plane, int txs, int txtype,
+                                         int skip_ctx, int dc_ctx, int tx_off, int tx_sym, LDS uint8_t *lev, int *cul_out, int *dc_cat) {
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   *cul_out = 0; *dc_cat = 0;
@@ -102,7 +102,7 @@ __device__ inline uint32_t coef_rate_dev(const uint16_t *cost, const uint16_t *l
   for (int c = LANE; c < eob; c += 64) {
     const int p = scan_pos(ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
     const int v = qc[p], level = iabs_(v);
-    const uint8_t *L = lev + row * st + col;
+    const LDS uint8_t *L = lev + row * st + col;
     if (c == eob - 1) {
       const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
       bits += cost[CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];

@@ -34,7 +34,7 @@ __device__ __forceinline__ void tx_kinds(int t, int *col, int *row) {
 __device__ __forceinline__ int32_t rshift_round_(int32_t v, int s) { return s <= 0 ? (int32_t)((uint32_t)v << -s) : (v + (1 << (s - 1))) >> s; }
 
 // tbuf: int32 [N][N+1] holding the residual on entry; coef out: [CS][CS], CS = min(N,32)
-template <int N> __device__ inline void fwd_txfm2d_dev(int32_t *tbuf, int32_t *coef, int txtype) {
+template <int N> __device__ inline void fwd_txfm2d_dev(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) {
   constexpr int P = N + 1, CS = N < 32 ? N : 32;
   constexpr int TXS = N == 4 ? 0 : N == 8 ? 1 : N == 16 ? 2 : N == 32 ? 3 : 4;
   const int8_t sh[5][3] = { { 2, 0, 0 }, { 2, -1, 0 }, { 2, -2, 0 }, { 2, -4, 0 }, { 0, -2, -2 } };
@@ -60,7 +60,7 @@ template <int N> __device__ inline void fwd_txfm2d_dev(int32_t *tbuf, int32_t *c
 }
 
 // dq in: [CS][CS] dequantised; adds the residual to rec[N*N] (u16, pitch N) in place.
-template <int N> __device__ inline void inv_txfm2d_add_dev(const int32_t *dq, int32_t *tbuf, uint16_t *rec, int txtype, int bd) {
+template <int N> __device__ inline void inv_txfm2d_add_dev(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) {
   constexpr int P = N + 1, CS = N < 32 ? N : 32;
   constexpr int ROWSH = N == 4 ? 0 : N == 8 ? 1 : 2;
   int ck, rk; tx_kinds(txtype, &ck, &rk);
@@ -93,7 +93,7 @@ template <int N> __device__ inline void inv_txfm2d_add_dev(const int32_t *dq, in
 }
 
 // returns eob (wave-uniform); qc [CS*CS].  All magnitudes fit 32 bits (|coef| < 2^22, q < 2^13).
-__device__ inline int quantize_dev(const uint16_t *ls, const int32_t *coef, int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq) {
+__device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *coef, LDS int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq) {
   const int nc = n * n, cls = tx_class_of(txtype);
   const int lsh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
   const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
@@ -126,7 +126,7 @@ __device__ inline int quantize_dev(const uint16_t *ls, const int32_t *coef, int3
   return eob;
 }
 
-__device__ inline void dequantize_dev(const int32_t *qc, int32_t *dq, int n, int txs, int dcq, int acq, int bd) {
+__device__ inline void dequantize_dev(const LDS int32_t *qc, LDS int32_t *dq, int n, int txs, int dcq, int acq, int bd) {
   const int nc = n * n, sh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
   const int mx = (1 << (7 + bd)) - 1, mn = -(1 << (7 + bd));
   for (int i = LANE; i < nc; i += 64) {

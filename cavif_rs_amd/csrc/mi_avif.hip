@@ -93,6 +93,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
+  d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
   d.tile_out_cap = tile_cap;
   return off;
 }
@@ -132,7 +133,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 }
 
 template <int MAXBS> static hipError_t launch_search(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
-  const size_t lds = ((sizeof(Scratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + (CDF_TOTAL + SCAN_LDS_ENTRIES(4 << MAXBS)) * 2;
+  const size_t lds = ((sizeof(Scratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + ((MI_COST_IN_LDS ? CDF_TOTAL : 0) + SCAN_LDS_ENTRIES(4 << MAXBS)) * 2;
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_search_kernel<MAXBS>, dim3(njobs), dim3(64), lds, s, d_frames, d_jobs, njobs);
@@ -272,6 +273,14 @@ int mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride
   return MI_OK;
 }
 
+// debug/profiling: per-tile [K1 start, K1 end, K4 start, K4 end] ticks of the last encode; out must hold 4*num_tiles values
+int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
+  if (!b || !out) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  size_t o = 0;
+  for (auto &p : b->frames) { HIP_OK(hipMemcpy(out + o, p.dev.tile_clk, (size_t)p.ntiles * 32, hipMemcpyDeviceToHost)); o += (size_t)p.ntiles * 4; }
+  return MI_OK;
+}
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
 double mi_batch_stage_ms(const mi_batch *b, int stage) { return (b && stage >= 0 && stage < 8) ? b->stage_ms[stage] : 0.0; }
 

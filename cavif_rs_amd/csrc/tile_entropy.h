@@ -44,7 +44,7 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
   re_normalize_dev(e, l, r);
 }
 // encode + adapt (lane 0 only)
-__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s, uint16_t *icdf, int nsyms) {
+__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s, LDS uint16_t *icdf, int nsyms) {
   re_encode_q15_dev(e, s > 0 ? icdf[s - 1] : 32768, icdf[s], s, nsyms);
   const int cnt = icdf[nsyms];
   const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
@@ -78,16 +78,16 @@ __device__ inline uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t 
 }
 
 struct TileWriter {
-  const FrameDev *f; TileB t; RangeEncDev ec; uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
-  int32_t *qc; uint8_t *lev; const uint16_t *ls;               // LDS staging + LDS copy of the scan tables
-  uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
+  const FrameDev *f; TileB t; RangeEncDev ec; LDS uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
+  LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
+  LDS uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
   int sb_cols_tile;
 };
 
 // lane 0: code one transform block's coefficients (levels + map already staged in LDS)
 __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
                                          int tx_off, int tx_sym, int tx_ns) {
-  RangeEncDev *e = &w->ec; uint16_t *cdf = w->cdf; const int32_t *qc = w->qc; const uint8_t *lev = w->lev;
+  RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
@@ -104,7 +104,7 @@ __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int 
   for (int c = eob - 1; c >= 0; c--) {
     const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
     const int level = iabs_(qc[p]);
-    const uint8_t *L = lev + row * st + col;
+    const LDS uint8_t *L = lev + row * st + col;
     if (c == eob - 1) {
       const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
       re_symbol_dev(e, imin_(level, 3) - 1, cdf + CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE, 3);
@@ -114,7 +114,7 @@ __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int 
     }
     if (level > 2) {
       const int ctx = br_ctx(L, st, cls, row, col, c);
-      uint16_t *bc = cdf + CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+      LDS uint16_t *bc = cdf + CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
       int rem = level - 3;
       for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
     }
@@ -135,7 +135,7 @@ template <int BS> __device__ inline void write_block_dev(TileWriter *w, int r, i
   const int skip = f->m_skip[mi], ymode = f->m_ymode[mi];
   int uvmode = 0;
   if (LANE == 0) {
-    RangeEncDev *e = &w->ec; uint16_t *cdf = w->cdf;
+    RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
     const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
     re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
     if (!skip && f->enable_cdef) {
@@ -199,7 +199,7 @@ template <int BS> struct WritePart {
     if (LANE == 0) {
       const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
       const int above = availU && f->m_bsize[(r - 1) * ms + c] < BS, left = availL && f->m_bsize[r * ms + c - 1] < BS;
-      uint16_t *cdf = w->cdf + CDF_PARTITION + ((BS - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
+      LDS uint16_t *cdf = w->cdf + CDF_PARTITION + ((BS - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
       const int ns = BS == BS_8 ? 4 : 10;
       if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
       else if (has_rows || has_cols) {
@@ -244,12 +244,13 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   w.f = f;
   w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  w.cdf = L.cdf; w.qc = L.qc; w.lev = L.lev; w.cdef_done = L.cdef_done; w.ls = L.scans;
-  load_scans_to_lds(L.scans, 32);
+  w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_done = (LDS uint8_t *)L.cdef_done; w.ls = (LDS uint16_t *)L.scans;
+  load_scans_to_lds((LDS uint16_t *)L.scans, 32);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
   for (int i = LANE; i < 4096; i += 64) L.cdef_done[i] = 0;
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
+  const unsigned long long clk0 = wall_clock64();
   WAVE_SYNC();
   for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
     for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
@@ -260,5 +261,6 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
     (void)ti;
     uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
     f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
+    unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[2] = clk0; tc[3] = wall_clock64();
   }
 }

@@ -12,6 +12,13 @@
 #include "dev_txfm.h"
 #include "dev_rate.h"
 
+#ifndef MI_K1_WAVES_PER_SIMD
+#define MI_K1_WAVES_PER_SIMD 1
+#endif
+#ifndef MI_COST_IN_LDS
+#define MI_COST_IN_LDS 1
+#endif
+
 template <int N> struct Scratch {
   static constexpr int CS = N < 32 ? N : 32;
   uint16_t ra[EDGE_LEN(N)], rl[EDGE_LEN(N)], wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
@@ -26,8 +33,13 @@ template <int N> struct Scratch {
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
 
 template <int MAXN> struct Ctx {
-  const FrameDev *f; TileB t; Scratch<MAXN> *s; uint8_t *snap;
-  const uint16_t *cost, *ls;      // LDS copies of the static rate table and the scan tables
+  const FrameDev *f; TileB t; LDS Scratch<MAXN> *s; uint8_t *snap;
+#if MI_COST_IN_LDS
+  const LDS uint16_t *cost;
+#else
+  const uint16_t *cost;
+#endif
+  const LDS uint16_t *ls;      // LDS copies of the static rate table and the scan tables
 };
 
 __device__ __forceinline__ const int *intra_mode_ctx_tab() { static __device__ const int t[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }; return t; }
@@ -42,7 +54,7 @@ __device__ inline void set_decoded_dev(const FrameDev *f, int r, int c, int n4, 
 }
 
 // 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n
-__device__ inline long long satd_dev(const uint16_t *src, const uint16_t *pred, int n) {
+__device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t *pred, int n) {
   const int nb = n >> 2, tot = nb * nb;
   long long total = 0;
   for (int b = LANE; b < tot; b += 64) {
@@ -67,18 +79,18 @@ __device__ inline long long satd_dev(const uint16_t *src, const uint16_t *pred, 
   }
   return wave_sum_i64(total);
 }
-__device__ inline long long sse_dev(const uint16_t *a, const uint16_t *b, int nn) {
+__device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b, int nn) {
   long long s = 0;
   for (int i = LANE; i < nn; i += 64) { const int d = (int)a[i] - (int)b[i]; s += (long long)d * d; }
   return wave_sum_i64(s);
 }
 
 template <int MAXN, int BS>
-__device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const uint16_t *pred, int txtype, int tx_off, int tx_sym,
-                                    uint16_t *rec_out, int32_t *qc_out, TxRes *tr) {
+__device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+                                    LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
-  const FrameDev *f = k.f; Scratch<MAXN> *S = k.s;
-  const uint16_t *src = S->srcb[plane];
+  const FrameDev *f = k.f; LDS Scratch<MAXN> *S = k.s;
+  const LDS uint16_t *src = S->srcb[plane];
   for (int idx = LANE; idx < n * n; idx += 64) {
     const int i = idx / n, j = idx % n;
     S->tbuf[i * P + j] = (int)src[idx] - (int)pred[idx];
@@ -98,7 +110,7 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
 }
 
 template <int MAXN, int BS>
-__device__ inline void commit_plane(Ctx<MAXN> &k, int plane, int r, int c, const uint16_t *rec, const int32_t *qc, const TxRes *tr) {
+__device__ inline void commit_plane(Ctx<MAXN> &k, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, const TxRes *tr) {
   constexpr int n = 4 << BS, CS = n < 32 ? n : 32, n4 = 1 << BS;
   const FrameDev *f = k.f;
   uint16_t *gr = f->rec[plane] + (size_t)(r * 4) * f->stride + c * 4;
@@ -121,18 +133,18 @@ __device__ inline void load_src_block(Ctx<MAXN> &k, int plane, int r, int c) {
 template <int MAXN, int BS>
 __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
-  const FrameDev *f = k.f; const TileB *t = &k.t; Scratch<MAXN> *S = k.s;
+  const FrameDev *f = k.f; const TileB *t = &k.t; LDS Scratch<MAXN> *S = k.s;
   const int ms = f->mi_stride, mi = r * ms + c, x = c * 4, y = r * 4;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int have_ar = availU && (c + n4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + n4];
   const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
   const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
   const int *imc = intra_mode_ctx_tab();
-  const uint16_t *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
+  const auto *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
   const int ftype_y = (availU && IS_SMOOTH_(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH_(f->m_ymode[mi - 1]));
   int ftype_uv = 0;
   if (f->np > 1) ftype_uv = (availU && IS_SMOOTH_(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH_(f->m_uvmode[mi - 1]));
-  uint16_t *ra = S->ra + EDGE_OFF, *rl = S->rl + EDGE_OFF, *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
+  LDS uint16_t *ra = S->ra + EDGE_OFF, *rl = S->rl + EDGE_OFF, *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
 
   for (int p = 0; p < f->np; p++) load_src_block<MAXN, BS>(k, p, r, c);
   int sctx_p[3] = { 0, 0, 0 }, dctx_p[3] = { 0, 0, 0 };      // all-zero / dc-sign contexts depend on the neighbours only
@@ -201,7 +213,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   // ---- chroma ----
   if (f->np > 1) {
     const int cfl_allowed = BS <= BS_32;
-    const uint16_t *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
+    const auto *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
     cands[nc++] = DC_PRED;
     if (best_mode != DC_PRED) cands[nc++] = best_mode;
@@ -338,7 +350,7 @@ template <int BS> __device__ inline void area_copy_dev(const FrameDev *f, uint8_
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 16 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
-__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
+template <typename CostPtr> __device__ inline uint32_t partition_rate_dev(CostPtr cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
@@ -389,7 +401,7 @@ template <int MAXN, int MAXBS> struct RdPart<MAXN, MAXBS, 0> {
 };
 
 template <int MAXBS>
-__global__ __launch_bounds__(64) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
+__global__ __launch_bounds__(64, MI_K1_WAVES_PER_SIMD) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
   const int job = blockIdx.x;
@@ -397,20 +409,27 @@ __global__ __launch_bounds__(64) void tile_search_kernel(const FrameDev *frames,
   const TileJob tj = jobs[job];
   const FrameDev *f = frames + tj.frame;
   Ctx<MAXN> k;
-  k.f = f; k.s = (Scratch<MAXN> *)smem;
+  k.f = f; k.s = (LDS Scratch<MAXN> *)smem;
   {
-    uint16_t *lc = (uint16_t *)(smem + ((sizeof(Scratch<MAXN>) + 15) & ~(size_t)15));
-    uint16_t *lsc = lc + CDF_TOTAL;
+    LDS uint16_t *lc = (LDS uint16_t *)(smem + ((sizeof(Scratch<MAXN>) + 15) & ~(size_t)15));
+    LDS uint16_t *lsc = lc + CDF_TOTAL;
+#if MI_COST_IN_LDS
     for (int i = LANE; i < CDF_TOTAL; i += 64) lc[i] = f->cost[i];
+    k.cost = lc;
+#else
+    lsc = lc; k.cost = f->cost;
+#endif
     load_scans_to_lds(lsc, MAXN);
-    k.cost = lc; k.ls = lsc;
+    k.ls = lsc;
     WAVE_SYNC();
   }
   k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
   if (f->dbg == 1) return;
+  const unsigned long long clk0 = wall_clock64();
   for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
     for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)
       RdPart<MAXN, MAXBS, 4>::run(k, r, c);
+  if (LANE == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 }

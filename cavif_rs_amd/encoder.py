@@ -45,7 +45,7 @@ class _EncodedImage(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, 'libmi_avif.so')
+    return os.environ.get('MI_AVIF_LIB') or os.path.join(_HERE, 'libmi_avif.so')
 
 
 def load_library():
@@ -77,6 +77,7 @@ def load_library():
     L.mi_batch_stage_ms.argtypes = [C.c_void_p, C.c_int]
     L.mi_batch_stage_ms.restype = C.c_double
     L.mi_batch_num_tiles.argtypes = [C.c_void_p]
+    L.mi_batch_tile_clocks.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_batch_destroy.argtypes = [C.c_void_p]
     L.mi_avif_serialize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
                                     C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8))]
@@ -305,6 +306,13 @@ class BatchEncoder:
 
     def num_tiles(self):
         return self._L.mi_batch_num_tiles(self._h)
+
+    def tile_clocks(self):
+        a = np.zeros((self.num_tiles(), 4), dtype=np.uint64)
+        st = self._L.mi_batch_tile_clocks(self._h, a.ctypes.data)
+        if st:
+            raise AvifError(st)
+        return a
 
     def close(self):
         if self._h:

@@ -87,6 +87,8 @@ int  mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]);
 /* per-kernel HIP-event time (ms) of the last mi_batch_encode: 0 front-end, 1 tile search, 2 deblock, 3 cdef, 4 entropy, 5 pack+D2H, 6 host assembly */
 double mi_batch_stage_ms(const mi_batch *b, int stage);
 int  mi_batch_num_tiles(const mi_batch *b);
+/* profiling aid: per tile [K1 start, K1 end, K4 start, K4 end] in wall_clock64 ticks (100 MHz) of the last encode */
+int  mi_batch_tile_clocks(mi_batch *b, unsigned long long *out);
 void mi_batch_destroy(mi_batch *b);
 
 /* AVIF container (avif-serialize Aviffy::to_vec, call site ravif/src/av1encoder.rs:457-473) */
