@@ -87,8 +87,10 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
   const int lo = wave_sum_i32((int)(v & 0xFFFFFF)), hi = wave_sum_i32((int)(v >> 24));
   return ((long long)hi << 24) + (long long)lo;
 }
-// single-wave workgroup: orders this wave's LDS/global traffic between phases
-#define WAVE_SYNC() __syncthreads()
+// WAVE_SYNC: orders one wavefront's own LDS/global traffic between phases (no cross-wave rendezvous);
+// WG_SYNC: workgroup barrier, used where the waves of a tile exchange results.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define WG_SYNC() __syncthreads()
 
 struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };
 

@@ -132,12 +132,19 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
-template <int MAXBS> static hipError_t launch_search(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
-  const size_t lds = ((sizeof(Scratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + ((MI_COST_IN_LDS ? CDF_TOTAL : 0) + SCAN_LDS_ENTRIES(4 << MAXBS)) * 2;
-  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int MAXBS, int NW> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+  const size_t lds = k1_lds_bytes<MAXBS, NW>();
+  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tile_search_kernel<MAXBS>, dim3(njobs), dim3(64), lds, s, d_frames, d_jobs, njobs);
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW>), dim3(njobs), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs);
   return hipGetLastError();
+}
+// jobs must all belong to frames of the same block-size class
+static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  if (maxbs <= 2) return launch_search_t<2, 4>(d_frames, d_jobs, njobs, s);
+  if (maxbs == 3) return launch_search_t<3, 4>(d_frames, d_jobs, njobs, s);
+  return launch_search_t<4, 1>(d_frames, d_jobs, njobs, s);     // 64x64 blocks: alpha (4:0:0) frames only
 }
 
 }  // namespace mi
@@ -278,7 +285,7 @@ int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
   if (!b || !out) return MI_INVALID_ARGUMENT;
   hipSetDevice(b->device);
   size_t o = 0;
-  for (auto &p : b->frames) { HIP_OK(hipMemcpy(out + o, p.dev.tile_clk, (size_t)p.ntiles * 32, hipMemcpyDeviceToHost)); o += (size_t)p.ntiles * 4; }
+  for (auto &p : b->frames) { HIP_OK(hipMemcpy(out + (size_t)p.dev.tile_base * 4, p.dev.tile_clk, (size_t)p.ntiles * 32, hipMemcpyDeviceToHost)); o += (size_t)p.ntiles * 4; }
   return MI_OK;
 }
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
@@ -327,12 +334,21 @@ int mi_batch_encode(mi_batch *b) {
   }
   // ---- tile job list, frame descriptors
   b->jobs.clear();
-  int maxbs = 2, max_mi_cells = 0, max_sb = 0;
+  int max_mi_cells = 0, max_sb = 0, class_begin[6] = { 0, 0, 0, 0, 0, 0 };
+  // tile jobs grouped by block-size class (one K1 instantiation per class); tile_base indexes the grouped list
+  for (int cls = 2; cls <= 4; cls++) {
+    class_begin[cls] = (int)b->jobs.size();
+    for (size_t k = 0; k < b->frames.size(); k++) {
+      FramePlan &p = b->frames[k];
+      if (std::max(p.maxbs, 2) != cls) continue;
+      p.dev.tile_base = (int)b->jobs.size();
+      for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) b->jobs.push_back(TileJob{ (int)k, tr, tc });
+    }
+  }
+  class_begin[5] = (int)b->jobs.size();
   for (size_t k = 0; k < b->frames.size(); k++) {
     FramePlan &p = b->frames[k];
-    p.dev.tile_base = (int)b->jobs.size();
-    for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) b->jobs.push_back(TileJob{ (int)k, tr, tc });
-    maxbs = std::max(maxbs, p.maxbs); max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
+    max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
     // clear the state the kernels rely on being zero
     HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
   }
@@ -342,8 +358,7 @@ int mi_batch_encode(mi_batch *b) {
   const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
   // ---- K1 tile search
   HIP_OK(hipEventRecord(b->ev[1], s));
-  hipError_t le = maxbs == 2 ? launch_search<2>(b->d_frames, b->d_jobs, njobs, s) : (maxbs == 3 ? launch_search<3>(b->d_frames, b->d_jobs, njobs, s) : launch_search<4>(b->d_frames, b->d_jobs, njobs, s));
-  HIP_OK(le);
+  for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
   // ---- K2 deblock
   HIP_OK(hipEventRecord(b->ev[2], s));
   for (int pass = 0; pass < 2; pass++)
@@ -361,8 +376,7 @@ int mi_batch_encode(mi_batch *b) {
   HIP_OK(hipEventRecord(b->ev[5], s));
   std::vector<uint32_t> offsets(njobs);
   {
-    size_t o2 = 0;
-    for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + o2, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); o2 += p.ntiles; }
+    for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); }
   }
   HIP_OK(hipStreamSynchronize(s));
   size_t total = 0;
@@ -474,8 +488,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
-  hipError_t le = p.maxbs == 2 ? launch_search<2>(d_frame, d_jobs, njobs, s) : (p.maxbs == 3 ? launch_search<3>(d_frame, d_jobs, njobs, s) : launch_search<4>(d_frame, d_jobs, njobs, s));
-  HIP_OK(le);
+  HIP_OK(launch_search(p.maxbs, d_frame, d_jobs, njobs, s));
   const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
 #define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)
   DBG_STAGE("tile_search");

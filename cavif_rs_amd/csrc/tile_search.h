@@ -1,62 +1,68 @@
-// tile_search.h -- kernel K1: the AV1 intra encode loop for one tile, run by one wavefront.
+// tile_search.h -- kernel K1: the AV1 intra encode loop for one tile.
 //   superblocks in raster order -> top-down partition RDO (rav1e encode_partition_topdown /
 //   rdo_partition_decision) -> per block: 13-mode SATD pre-filter, angle-delta refinement, full RD over
 //   (mode x tx type) with forward transform, quantise, static-table rate, dequantise, inverse transform,
 //   SSE (rdo_mode_decision / rdo_tx_type_decision), chroma DC / same-as-luma / CfL with alpha search
-//   (rdo_cfl_alpha).  Source block, prediction, residual and candidate reconstructions live in LDS; the
-//   frame-sized recon / coefficient / mode-info maps live in HBM and are touched only by the owning tile.
-// The decisions are bit-identical to oracle/av1o_search.c (the CPU checker), which is how parity is tested.
+//   (rdo_cfl_alpha).
+// Mapping: one WORKGROUP of NW wavefronts per tile.  The serial spine (block after block) is walked by all
+// waves in lock step; inside a block the RDO candidates are dealt round-robin to the waves -- one wavefront
+// per candidate -- and the winner is picked through LDS with the oracle's tie-break (lowest candidate
+// index among equal costs), so the decisions are bit-identical to oracle/av1o_search.c.
+// Source block, edges, prediction, residual and candidate reconstructions live in LDS; the frame-sized
+// recon / coefficient / mode-info maps live in HBM and are touched only by the owning tile.
 #pragma once
 #include "dev_common.h"
 #include "dev_predict.h"
 #include "dev_txfm.h"
 #include "dev_rate.h"
 
-#ifndef MI_K1_WAVES_PER_SIMD
-#define MI_K1_WAVES_PER_SIMD 1
+#ifndef MI_K1_WG_PER_CU
+#define MI_K1_WG_PER_CU 4
 #endif
-#ifndef MI_COST_IN_LDS
-#define MI_COST_IN_LDS 1
-#endif
+#define WAVE_ID ((int)(threadIdx.x >> 6))
 
-template <int N> struct Scratch {
+template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32;
-  uint16_t ra[EDGE_LEN(N)], rl[EDGE_LEN(N)], wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
-  uint16_t srcb[3][N * N];
-  uint16_t pred[N * N], dcp[N * N], rec_tmp[N * N], rec_best[3][N * N], rec_c[2][N * N];
-  int32_t tbuf[N * (N + 1)], cbuf[CS * CS], dq[CS * CS], qc_tmp[CS * CS], qc_best[3][CS * CS], qc_c[2][CS * CS];
+  uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
+  uint16_t pred[N * N], dcp[N * N], rec[2][N * N];
+  int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];      // cbuf doubles as the dequantised block
   uint8_t lev[(CS + 4) * (CS + 4) + 4];
-  long long satd[13];
-  int order[13];
+};
+template <int N> struct SharedScratch {          // shared by the waves of the tile
+  uint16_t ra[3][EDGE_LEN(N)], rl[3][EDGE_LEN(N)];
+  uint16_t srcb[3][N * N];
+  uint16_t luma_rec[N * N];
+  long long satd[13], dsd[7][6];
+  long long wbest_j[4], cj[16][2], pbest_j[2];
+  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16];
+  int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2];
 };
 
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
 
 template <int MAXN> struct Ctx {
-  const FrameDev *f; TileB t; LDS Scratch<MAXN> *s; uint8_t *snap;
-#if MI_COST_IN_LDS
-  const LDS uint16_t *cost;
-#else
-  const uint16_t *cost;
-#endif
-  const LDS uint16_t *ls;      // LDS copies of the static rate table and the scan tables
+  const FrameDev *f; TileB t; LDS WaveScratch<MAXN> *s; LDS SharedScratch<MAXN> *sh; uint8_t *snap;
+  const uint16_t *cost; const LDS uint16_t *ls;
 };
 
 __device__ __forceinline__ const int *intra_mode_ctx_tab() { static __device__ const int t[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }; return t; }
 #define IS_SMOOTH_(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
+#define J_INF 0x7fffffffffffffffLL
 
+// one wave fills an n4 x n4 area of a byte map
 __device__ inline void fill_map_dev(uint8_t *m, int ms, int r, int c, int n4, int v) {
   for (int i = LANE; i < n4 * n4; i += 64) m[(r + i / n4) * ms + c + (i % n4)] = (uint8_t)v;
 }
-__device__ inline void set_decoded_dev(const FrameDev *f, int r, int c, int n4, int v) {
-  fill_map_dev(f->m_decoded, f->mi_stride, r, c, n4, v);
-  WAVE_SYNC();
+// whole workgroup
+template <int NW> __device__ inline void set_decoded_wg(const FrameDev *f, int r, int c, int n4, int v) {
+  for (int i = threadIdx.x; i < n4 * n4; i += 64 * NW) f->m_decoded[(r + i / n4) * f->mi_stride + c + (i % n4)] = (uint8_t)v;
+  WG_SYNC();
 }
 
 // 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n
 __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t *pred, int n) {
   const int nb = n >> 2, tot = nb * nb;
-  long long total = 0;
+  int total = 0;
   for (int b = LANE; b < tot; b += 64) {
     const int by = (b / nb) * 4, bx = (b % nb) * 4;
     int d[16], t[16];
@@ -75,9 +81,9 @@ __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t
       const int a = t[j] + t[4 + j], b2 = t[j] - t[4 + j], c2 = t[8 + j] + t[12 + j], e = t[8 + j] - t[12 + j];
       s += iabs_(a + c2) + iabs_(b2 + e) + iabs_(a - c2) + iabs_(b2 - e);
     }
-    total += s;
+    total += s;                                   // <= 64x64 block: 4 sub-blocks per lane * 16 * 4 * 1023 * 4 fits int
   }
-  return wave_sum_i64(total);
+  return wave_sum_i64((long long)total);
 }
 __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b, int nn) {
   long long s = 0;
@@ -85,12 +91,13 @@ __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b
   return wave_sum_i64(s);
 }
 
+// One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
 template <int MAXN, int BS>
 __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
-  const FrameDev *f = k.f; LDS Scratch<MAXN> *S = k.s;
-  const LDS uint16_t *src = S->srcb[plane];
+  const FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
+  const LDS uint16_t *src = k.sh->srcb[plane];
   for (int idx = LANE; idx < n * n; idx += 64) {
     const int i = idx / n, j = idx % n;
     S->tbuf[i * P + j] = (int)src[idx] - (int)pred[idx];
@@ -101,231 +108,283 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane]);
   tr->rate = coef_rate_dev(k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
   if (eob > 0) {
-    dequantize_dev(qc_out, S->dq, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
-    inv_txfm2d_add_dev<n>(S->dq, S->tbuf, rec_out, txtype, f->bd);
+    dequantize_dev(qc_out, S->cbuf, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
+    inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
   }
   tr->eob = eob;
   tr->sse = sse_dev(src, rec_out, n * n);
   return ((tr->sse * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
 }
 
-template <int MAXN, int BS>
-__device__ inline void commit_plane(Ctx<MAXN> &k, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, const TxRes *tr) {
+// one wave writes a plane's result back to the frame buffers
+template <int BS>
+__device__ inline void commit_plane(const FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
   constexpr int n = 4 << BS, CS = n < 32 ? n : 32, n4 = 1 << BS;
-  const FrameDev *f = k.f;
   uint16_t *gr = f->rec[plane] + (size_t)(r * 4) * f->stride + c * 4;
   int32_t *gc = f->coef[plane] + (size_t)(r * 4) * f->stride + c * 4;
   for (int idx = LANE; idx < n * n; idx += 64) gr[(idx / n) * f->stride + (idx % n)] = rec[idx];
   for (int idx = LANE; idx < CS * CS; idx += 64) gc[(idx / CS) * f->stride + (idx % CS)] = qc[idx];
-  fill_map_dev(f->m_lvl[plane], f->mi_stride, r, c, n4, tr->cul);
-  fill_map_dev(f->m_dc[plane], f->mi_stride, r, c, n4, tr->dcc);
-  if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)tr->eob;
+  fill_map_dev(f->m_lvl[plane], f->mi_stride, r, c, n4, cul);
+  fill_map_dev(f->m_dc[plane], f->mi_stride, r, c, n4, dcc);
+  if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
 }
 
-template <int MAXN, int BS>
-__device__ inline void load_src_block(Ctx<MAXN> &k, int plane, int r, int c) {
-  constexpr int n = 4 << BS;
-  const FrameDev *f = k.f;
-  const uint16_t *g = f->src[plane] + (size_t)(r * 4) * f->stride + c * 4;
-  for (int idx = LANE; idx < n * n; idx += 64) k.s->srcb[plane][idx] = g[(idx / n) * f->stride + (idx % n)];
-}
-
-template <int MAXN, int BS>
+template <int MAXN, int BS, int NW>
 __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
-  const FrameDev *f = k.f; const TileB *t = &k.t; LDS Scratch<MAXN> *S = k.s;
+  const FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
+  const int W = NW > 1 ? WAVE_ID : 0;
   const int ms = f->mi_stride, mi = r * ms + c, x = c * 4, y = r * 4;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int have_ar = availU && (c + n4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + n4];
   const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
   const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
   const int *imc = intra_mode_ctx_tab();
-  const auto *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
+  const uint16_t *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
   const int ftype_y = (availU && IS_SMOOTH_(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH_(f->m_ymode[mi - 1]));
   int ftype_uv = 0;
   if (f->np > 1) ftype_uv = (availU && IS_SMOOTH_(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH_(f->m_uvmode[mi - 1]));
-  LDS uint16_t *ra = S->ra + EDGE_OFF, *rl = S->rl + EDGE_OFF, *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
-
-  for (int p = 0; p < f->np; p++) load_src_block<MAXN, BS>(k, p, r, c);
+  LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
   int sctx_p[3] = { 0, 0, 0 }, dctx_p[3] = { 0, 0, 0 };      // all-zero / dc-sign contexts depend on the neighbours only
   for (int p = 0; p < f->np; p++) txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx_p[p], &dctx_p[p]);
-  if (f->dbg == 2) return 0;
-  load_edges(f, 0, x, y, n, availL, availU, have_ar, have_bl, ra, rl);   // ends with WAVE_SYNC
-  if (f->dbg == 3) return 0;
 
-  // ---- luma: SATD pre-filter over the 13 modes ----
-  for (int m = 0; m < 13; m++) {
+  // ---- stage the source block and the raw edges of every plane (plane p by wave p % NW) ----
+  for (int p = 0; p < f->np; p++) if (p % NW == W) {
+    const uint16_t *g = f->src[p] + (size_t)y * f->stride + x;
+    for (int idx = LANE; idx < nn; idx += 64) SH->srcb[p][idx] = g[(idx / n) * f->stride + (idx % n)];
+    load_edges(f, p, x, y, n, availL, availU, have_ar, have_bl, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF);
+  }
+  WG_SYNC();
+  if (f->dbg == 3) return 0;
+  const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
+
+  // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
+  for (int m = W; m < 13; m += NW) {
     predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
-    const long long sd = satd_dev(S->srcb[0], S->pred, n);
-    if (LANE == 0) { S->satd[m] = sd; S->order[m] = m; }
+    const long long sd = satd_dev(SH->srcb[0], S->pred, n);
+    if (LANE == 0) SH->satd[m] = sd;
   }
-  WAVE_SYNC();
-  if (LANE == 0) {
-    for (int i = 1; i < 13; i++) { const int v = S->order[i]; int j = i; while (j > 0 && S->satd[S->order[j - 1]] > S->satd[v]) { S->order[j] = S->order[j - 1]; j--; } S->order[j] = v; }
+  WG_SYNC();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 13; i++) SH->order[i] = i;
+    for (int i = 1; i < 13; i++) { const int v = SH->order[i]; int j = i; while (j > 0 && SH->satd[SH->order[j - 1]] > SH->satd[v]) { SH->order[j] = SH->order[j - 1]; j--; } SH->order[j] = v; }
   }
-  WAVE_SYNC();
-  if (f->dbg == 4) return 0;
+  WG_SYNC();
   const int ncand = f->complex_modes ? 7 : 3;
-  long long best_j = 0x7fffffffffffffffLL; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
-  int tx_ns = 0, tx_set = 0;
-  for (int ci = 0; ci < ncand; ci++) {
-    const int m = S->order[ci];
-    int delta = 0;
-    const int directional = m >= V_PRED && m <= D67_PRED;
-    if (directional && BS >= BS_8 && f->fine_directional) {
-      long long bsd = S->satd[m];
-      const int dl[6] = { -1, 1, -2, 2, -3, 3 };
-      for (int q = 0; q < 6; q++) {
+  // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
+  const int dl[6] = { -1, 1, -2, 2, -3, 3 };
+  const int refine = BS >= BS_8 && f->fine_directional;
+  if (refine) {
+    for (int u = W; u < ncand * 6; u += NW) {
+      const int ci = u / 6, q = u - ci * 6, m = SH->order[ci];
+      if (m >= V_PRED && m <= D67_PRED) {
         predict_block(f, x, y, log2w, availL, availU, m, dl[q], ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
-        const long long sd = satd_dev(S->srcb[0], S->pred, n);
-        if (sd < bsd) { bsd = sd; delta = dl[q]; }
+        const long long sd = satd_dev(SH->srcb[0], S->pred, n);
+        if (LANE == 0) SH->dsd[ci][q] = sd;
       }
+    }
+    WG_SYNC();
+  }
+  // ---- full RD over surviving (mode, delta) x tx type: eval e = ci*ntx + ti by wave e % NW ----
+  int tx_ns = 0, tx_set = 0;
+  const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
+  const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
+  for (int e = W; e < ncand * ntx; e += NW) {
+    const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
+    const int directional = m >= V_PRED && m <= D67_PRED;
+    int delta = 0;
+    if (directional && refine) {
+      long long bsd = SH->satd[m];
+      for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
     }
     predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
     uint32_t mode_rate = ycost[m];
     if (directional && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
-    const int tx_off = intra_tx_cdf(f, BS, m, &tx_ns, &tx_set);
-    const int ntx = (f->rdo_tx && tx_off >= 0) ? tx_ns : 1;
-    for (int ti = 0; ti < ntx; ti++) {
-      int txtype;
-      if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
-      else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
-      TxRes tr;
-      long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec_tmp, S->qc_tmp, &tr);
-      j += ((long long)mode_rate * f->rdmult + 256) >> 9;
-      if (j < best_j) {
-        best_j = j; best_mode = m; best_delta = delta; best_tx = txtype; best_tr = tr;
-        for (int i = LANE; i < nn; i += 64) S->rec_best[0][i] = S->rec_tmp[i];
-        for (int i = LANE; i < qn; i += 64) S->qc_best[0][i] = S->qc_tmp[i];
-        WAVE_SYNC();
-      }
-    }
+    int ns2, set2;
+    const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
+    int txtype;
+    if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
+    else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
+    TxRes tr;
+    long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
+    j += ((long long)mode_rate * f->rdmult + 256) >> 9;
+    if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; cur ^= 1; }
   }
+  if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
+  WG_SYNC();
+  int win = 0;
+  for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
+  const long long best_j = SH->wbest_j[win];
+  if (W == win) {
+    const int b = cur ^ 1;                                  // buffer holding this wave's best
+    commit_plane<BS>(f, 0, r, c, S->rec[b], S->qc[b], my_tr.eob, my_tr.cul, my_tr.dcc);
+    fill_map_dev(f->m_ymode, ms, r, c, n4, my_mode);
+    fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
+    fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
+    fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
+    if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = S->rec[b][i];
+    if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; }
+  }
+  WG_SYNC();
   if (f->dbg == 5) return 0;
-  commit_plane<MAXN, BS>(k, 0, r, c, S->rec_best[0], S->qc_best[0], &best_tr);
-  fill_map_dev(f->m_ymode, ms, r, c, n4, best_mode);
-  fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)best_delta);
-  fill_map_dev(f->m_txtype, ms, r, c, n4, best_tr.eob ? best_tx : DCT_DCT);
-  fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
-  WAVE_SYNC();
-  long long total_j = best_j; int any_coef = best_tr.eob > 0;
+  const int best_mode = SH->lm_mode, best_delta = SH->lm_delta;
+  long long total_j = best_j; int any_coef = SH->lm_eob > 0;
 
-  // ---- chroma ----
-  if (f->np > 1) {
+  // ---- chroma: candidate ci2 by wave pair (ci2 & 1), plane (W & 1) + 1 within the pair ----
+  if constexpr (NW >= 2) if (f->np > 1) {
     const int cfl_allowed = BS <= BS_32;
-    const auto *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
+    const uint16_t *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
     cands[nc++] = DC_PRED;
     if (best_mode != DC_PRED) cands[nc++] = best_mode;
     if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) cands[nc++] = m;
     if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
-    long long best_uv = 0x7fffffffffffffffLL; int buv = DC_PRED, bdelta = 0, bsign = 0, bau = 0, bav = 0; TxRes btr[3];
-    btr[1] = best_tr; btr[2] = best_tr;
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
-    // luma average for CfL (same for every alpha)
-    for (int ci = 0; ci < nc; ci++) {
-      const int um = cands[ci];
+    constexpr int NPAIR = 2;
+    const int pair = (W >> 1) & 1, active = W < 4;
+    long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
+    for (int base = 0; base < nc; base += NPAIR) {
+      const int ci2 = base + pair, valid = active && ci2 < nc;
+      const int um = valid ? cands[ci2] : DC_PRED;
       const int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && BS >= BS_8) ? best_delta : 0;
-      int alpha[3] = { 0, 0, 0 }, jsign = 0;
-      uint32_t mode_rate = uvcost[um];
-      if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      long long j = 0; TxRes trs[3]; int ok = 1;
-      if (um == UV_CFL_PRED) {
-        // rdo_cfl_alpha: per plane the alpha in -16..16 minimising prediction SSE
-        const uint16_t *luma = f->rec[0] + (size_t)y * f->stride + x;
-        int ls = 0;
-        for (int idx = LANE; idx < nn; idx += 64) ls += luma[(idx / n) * f->stride + (idx % n)] << 3;
-        ls = wave_sum_i32(ls);
-        const int avg = round2_(ls, 2 * log2w), mx = (1 << f->bd) - 1;
-        for (int p = 1; p < 3; p++) {
-          load_edges(f, p, x, y, n, availL, availU, have_ar, have_bl, ra, rl);
-          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, ra, rl, wa, wl, S->etmp, S->dcp);
-          long long e0 = 0, e[32];
+      {
+        const int p = (W & 1) + 1;
+        if (valid && um == UV_CFL_PRED) {
+          // rdo_cfl_alpha: the alpha in -16..16 minimising this plane's prediction SSE
+          const LDS uint16_t *luma = SH->luma_rec;
+          int lsum = 0;
+          for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
+          lsum = wave_sum_i32(lsum);
+          const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
+          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
+          long long e0 = 0;
+          for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += (long long)d * d; }
+          long long best_sse = wave_sum_i64(e0); int best_a = 0;
+          for (int a0 = 0; a0 < 32; a0 += 8) {
+            long long e[8];
 #pragma unroll
-          for (int a = 0; a < 32; a++) e[a] = 0;
-          for (int idx = LANE; idx < nn; idx += 64) {
-            const int l = (luma[(idx / n) * f->stride + (idx % n)] << 3) - avg, dcv = S->dcp[idx], sv = S->srcb[p][idx];
-            { const int d = sv - dcv; e0 += (long long)d * d; }
+            for (int a = 0; a < 8; a++) e[a] = 0;
+            for (int idx = LANE; idx < nn; idx += 64) {
+              const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
 #pragma unroll
-            for (int a = 0; a < 32; a++) {
-              const int al = (a & 1) ? -((a >> 1) + 1) : ((a >> 1) + 1);
-              const int v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-              const int d = sv - iclamp_(dcv + sc, 0, mx);
-              e[a] += (long long)d * d;
+              for (int a = 0; a < 8; a++) {
+                const int aa = a0 + a, al = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1);
+                const int v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+                const int d = sv - iclamp_(dcv + sc, 0, mx);
+                e[a] += (long long)d * d;
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+              const long long ea = wave_sum_i64(e[a]);
+              const int aa = a0 + a;
+              if (ea < best_sse) { best_sse = ea; best_a = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1); }
             }
           }
-          long long best_sse = wave_sum_i64(e0); int best_a = 0;
-#pragma unroll
-          for (int a = 0; a < 32; a++) {
-            const long long ea = wave_sum_i64(e[a]);
-            if (ea < best_sse) { best_sse = ea; best_a = (a & 1) ? -((a >> 1) + 1) : ((a >> 1) + 1); }
-          }
-          alpha[p] = best_a;
+          if (LANE == 0) SH->calpha[pair][p - 1] = best_a;
         }
-        if (alpha[1] == 0 && alpha[2] == 0) ok = 0;
+      }
+      WG_SYNC();                                            // (A) alphas of both planes visible
+      int alpha_u = 0, alpha_v = 0, jsign = 0, ok = valid;
+      uint32_t mode_rate = uvcost[um];
+      if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+      if (valid && um == UV_CFL_PRED) {
+        alpha_u = SH->calpha[pair][0]; alpha_v = SH->calpha[pair][1];
+        if (alpha_u == 0 && alpha_v == 0) ok = 0;
         else {
-          const int su = alpha[1] == 0 ? 0 : (alpha[1] < 0 ? 1 : 2), sv = alpha[2] == 0 ? 0 : (alpha[2] < 0 ? 1 : 2);
+          const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
           jsign = su * 3 + sv - 1;
           mode_rate += k.cost[CDF_CFL_SIGN + jsign];
-          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[1]) - 1];
-          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha[2]) - 1];
+          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_u) - 1];
+          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_v) - 1];
         }
       }
-      if (!ok) continue;
-      for (int p = 1; p < 3; p++) {
-        load_edges(f, p, x, y, n, availL, availU, have_ar, have_bl, ra, rl);
-        if (um == UV_CFL_PRED) {
-          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, ra, rl, wa, wl, S->etmp, S->dcp);
-          if (alpha[p]) predict_cfl_dev(f, x, y, log2w, alpha[p], S->dcp, S->pred);
-          else { for (int i = LANE; i < nn; i += 64) S->pred[i] = S->dcp[i]; WAVE_SYNC(); }
-        } else {
-          predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, ra, rl, wa, wl, S->etmp, S->pred);
+      TxRes trp = { 0, 0, 0, 0, 0 };
+      if (ok) {
+        {
+          const int p = (W & 1) + 1;
+          const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
+          if (um == UV_CFL_PRED) {
+            const int al = p == 1 ? alpha_u : alpha_v;
+            predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->dcp);
+            if (al) {
+              // predict_cfl against the LDS copy of the luma reconstruction
+              int lsum = 0;
+              for (int idx = LANE; idx < nn; idx += 64) lsum += SH->luma_rec[idx] << 3;
+              lsum = wave_sum_i32(lsum);
+              const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
+              for (int idx = LANE; idx < nn; idx += 64) {
+                const int l = ((int)SH->luma_rec[idx] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+                S->pred[idx] = (uint16_t)iclamp_((int)S->dcp[idx] + sc, 0, mx);
+              }
+            } else { for (int i = LANE; i < nn; i += 64) S->pred[i] = S->dcp[i]; }
+            WAVE_SYNC();
+          } else {
+            predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
+          }
+          const long long jp = eval_tx<MAXN, BS>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &trp);
+          if (LANE == 0) SH->cj[ci2][p - 1] = jp;
         }
-        j += eval_tx<MAXN, BS>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec_best[p], S->qc_best[p], &trs[p]);
       }
-      j += ((long long)mode_rate * f->rdmult + 256) >> 9;
-      if (j < best_uv) {
-        best_uv = j; buv = um; bdelta = delta; bsign = jsign; bau = alpha[1]; bav = alpha[2]; btr[1] = trs[1]; btr[2] = trs[2];
-        for (int p = 1; p < 3; p++) {
-          for (int i = LANE; i < nn; i += 64) S->rec_c[p - 1][i] = S->rec_best[p][i];
-          for (int i = LANE; i < qn; i += 64) S->qc_c[p - 1][i] = S->qc_best[p][i];
-        }
-        WAVE_SYNC();
+      if (valid && LANE == 0 && (W & 1) == 0) SH->cok[ci2] = ok;
+      WG_SYNC();                                            // (B) both planes' costs visible
+      if (valid && ok) {
+        const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        if (j < pb_j) { pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp; ccur ^= 1; }
       }
     }
-    for (int p = 1; p < 3; p++) { commit_plane<MAXN, BS>(k, p, r, c, S->rec_c[p - 1], S->qc_c[p - 1], &btr[p]); any_coef |= btr[p].eob > 0; }
-    fill_map_dev(f->m_uvmode, ms, r, c, n4, buv);
-    fill_map_dev((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)bdelta);
-    fill_map_dev(f->m_cfl_sign, ms, r, c, n4, bsign);
-    fill_map_dev(f->m_cfl_au, ms, r, c, n4, bau ? iabs_(bau) - 1 : 0);
-    fill_map_dev(f->m_cfl_av, ms, r, c, n4, bav ? iabs_(bav) - 1 : 0);
+    if (LANE == 0 && (W & 1) == 0 && W < 4) { SH->pbest_j[pair] = pb_j; SH->pbest_c[pair] = pb_c; }
+    WG_SYNC();
+    int wp = 0;
+    if ((SH->pbest_j[1] < SH->pbest_j[0] || (SH->pbest_j[1] == SH->pbest_j[0] && SH->pbest_c[1] < SH->pbest_c[0]))) wp = 1;
+    const long long best_uv = SH->pbest_j[wp];
+    if (active && pair == wp) {
+      const int p = (W & 1) + 1, b = ccur ^ 1;
+      commit_plane<BS>(f, p, r, c, S->rec[b], S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
+      if (LANE == 0) SH->ceob[p - 1] = pb_tr.eob;
+      if (p == 1) {
+        const int buv = cands[pb_c];
+        fill_map_dev(f->m_uvmode, ms, r, c, n4, buv);
+        fill_map_dev((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)pb_delta);
+        fill_map_dev(f->m_cfl_sign, ms, r, c, n4, pb_sign);
+        fill_map_dev(f->m_cfl_au, ms, r, c, n4, pb_au ? iabs_(pb_au) - 1 : 0);
+        fill_map_dev(f->m_cfl_av, ms, r, c, n4, pb_av ? iabs_(pb_av) - 1 : 0);
+      }
+    }
+    WG_SYNC();
+    any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
     total_j += best_uv;
+    (void)qn;
   }
   if (f->dbg == 6) return 0;
   // ---- skip flag ----
   const int skip = !any_coef;
-  WAVE_SYNC();
-  fill_map_dev(f->m_skip, ms, r, c, n4, skip);
-  if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
+  if (W == 0) {
+    fill_map_dev(f->m_skip, ms, r, c, n4, skip);
+    if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
+    fill_map_dev(f->m_decoded, ms, r, c, n4, 1);
+  }
   const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
   total_j += ((long long)k.cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
-  set_decoded_dev(f, r, c, n4, 1);
+  WG_SYNC();
   return total_j;
 }
 
-// ---- area snapshot (NONE-vs-SPLIT comparison), kept in the tile's HBM scratch ----
-template <int BS> __device__ inline void area_copy_dev(const FrameDev *f, uint8_t *snap, int r, int c, int save) {
-  constexpr int n = 4 << BS, n4 = 1 << BS;
+// ---- area snapshot (NONE-vs-SPLIT comparison), kept in the tile's HBM scratch; whole workgroup ----
+template <int BS, int NW> __device__ inline void area_copy_dev(const FrameDev *f, uint8_t *snap, int r, int c, int save) {
+  constexpr int n = 4 << BS, n4 = 1 << BS, T = 64 * NW;
   uint16_t *srec = (uint16_t *)snap;                         // [3][n*n]
   int32_t *scoef = (int32_t *)(snap + 3 * n * n * 2);        // [3][n*n]
   uint8_t *smaps = snap + 3 * n * n * 6;                     // 16 byte-maps [n4*n4]
   uint16_t *seob = (uint16_t *)(smaps + 16 * n4 * n4);       // [3][n4*n4]
+  const int tid = threadIdx.x;
   for (int p = 0; p < f->np; p++) {
     uint16_t *gr = f->rec[p] + (size_t)(r * 4) * f->stride + c * 4;
     int32_t *gc = f->coef[p] + (size_t)(r * 4) * f->stride + c * 4;
-    for (int idx = LANE; idx < n * n; idx += 64) {
+    for (int idx = tid; idx < n * n; idx += T) {
       const int o = (idx / n) * f->stride + (idx % n);
       if (save) { srec[p * n * n + idx] = gr[o]; scoef[p * n * n + idx] = gc[o]; }
       else { gr[o] = srec[p * n * n + idx]; gc[o] = scoef[p * n * n + idx]; }
@@ -333,31 +392,32 @@ template <int BS> __device__ inline void area_copy_dev(const FrameDev *f, uint8_
   }
   uint8_t *maps[16] = { f->m_bsize, f->m_skip, f->m_ymode, f->m_uvmode, f->m_txtype, f->m_cfl_sign, f->m_cfl_au, f->m_cfl_av,
                         (uint8_t *)f->m_angle_y, (uint8_t *)f->m_angle_uv, f->m_lvl[0], f->m_lvl[1], f->m_lvl[2], f->m_dc[0], f->m_dc[1], f->m_dc[2] };
+#pragma unroll
   for (int m = 0; m < 16; m++) {
     if (f->np == 1 && (m == 11 || m == 12 || m == 14 || m == 15)) continue;
     uint8_t *g = maps[m];
-    for (int i = LANE; i < n4 * n4; i += 64) {
+    for (int i = tid; i < n4 * n4; i += T) {
       const int o = (r + i / n4) * f->mi_stride + c + (i % n4);
       if (save) smaps[m * n4 * n4 + i] = g[o]; else g[o] = smaps[m * n4 * n4 + i];
     }
   }
   for (int p = 0; p < f->np; p++)
-    for (int i = LANE; i < n4 * n4; i += 64) {
+    for (int i = tid; i < n4 * n4; i += T) {
       const int o = (r + i / n4) * f->mi_stride + c + (i % n4);
       if (save) seob[p * n4 * n4 + i] = f->m_eob[p][o]; else f->m_eob[p][o] = seob[p * n4 * n4 + i];
     }
-  WAVE_SYNC();
+  WG_SYNC();
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 16 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
-template <typename CostPtr> __device__ inline uint32_t partition_rate_dev(CostPtr cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
+__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
   return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
-template <int MAXN, int MAXBS, int BS> struct RdPart {
+template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   static __device__ void run(Ctx<MAXN> &k, int r, int c) {
     const FrameDev *f = k.f;
     if (r >= f->mi_rows || c >= f->mi_cols) return;
@@ -365,43 +425,47 @@ template <int MAXN, int MAXBS, int BS> struct RdPart {
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
     const int must_split = px > f->part_max || !has_rows || !has_cols;
     const int can_split = px > f->part_min || must_split;
-    set_decoded_dev(f, r, c, n4, 0);
-    if (!can_split || (f->dbg == 9 && BS == 1)) { if constexpr (BS <= MAXBS) try_block<MAXN, BS>(k, r, c); return; }
+    set_decoded_wg<NW>(f, r, c, n4, 0);
+    if (!can_split || (f->dbg == 9 && BS == 1)) { if constexpr (BS <= MAXBS) try_block<MAXN, BS, NW>(k, r, c); return; }
     int do_split = must_split;
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        const long long j_none = try_block<MAXN, BS>(k, r, c) + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
-        area_copy_dev<BS>(f, k.snap, r, c, 1);
-        set_decoded_dev(f, r, c, n4, 0);
+        const long long j_none = try_block<MAXN, BS, NW>(k, r, c) + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
+        area_copy_dev<BS, NW>(f, k.snap, r, c, 1);
+        set_decoded_wg<NW>(f, r, c, n4, 0);
         long long j_split = ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
         for (int q = 0; q < 4 && j_split < j_none && f->dbg != 7; q++) {
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-          j_split += try_block<MAXN, BS - 1>(k, rr, cc);
+          j_split += try_block<MAXN, BS - 1, NW>(k, rr, cc);
           if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
         }
         if (j_split < j_none && f->dbg != 7 && f->dbg != 8 && !(f->dbg == 10 && BS == 1)) do_split = 1;
-        else { area_copy_dev<BS>(f, k.snap, r, c, 0); set_decoded_dev(f, r, c, n4, 1); }
+        else { area_copy_dev<BS, NW>(f, k.snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
       }
     }
     if (do_split) {
-      set_decoded_dev(f, r, c, n4, 0);
-      RdPart<MAXN, MAXBS, BS - 1>::run(k, r, c); RdPart<MAXN, MAXBS, BS - 1>::run(k, r, c + half);
-      RdPart<MAXN, MAXBS, BS - 1>::run(k, r + half, c); RdPart<MAXN, MAXBS, BS - 1>::run(k, r + half, c + half);
+      set_decoded_wg<NW>(f, r, c, n4, 0);
+      RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r, c); RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r, c + half);
+      RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + half, c); RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + half, c + half);
     }
   }
 };
-template <int MAXN, int MAXBS> struct RdPart<MAXN, MAXBS, 0> {
+template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
   static __device__ void run(Ctx<MAXN> &k, int r, int c) {
     const FrameDev *f = k.f;
     if (r >= f->mi_rows || c >= f->mi_cols) return;
-    set_decoded_dev(f, r, c, 1, 0);
-    try_block<MAXN, 0>(k, r, c);
+    set_decoded_wg<NW>(f, r, c, 1, 0);
+    try_block<MAXN, 0, NW>(k, r, c);
   }
 };
 
-template <int MAXBS>
-__global__ __launch_bounds__(64, MI_K1_WAVES_PER_SIMD) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
+template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
+  return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2;
+}
+
+template <int MAXBS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
   const int job = blockIdx.x;
@@ -409,27 +473,20 @@ __global__ __launch_bounds__(64, MI_K1_WAVES_PER_SIMD) void tile_search_kernel(c
   const TileJob tj = jobs[job];
   const FrameDev *f = frames + tj.frame;
   Ctx<MAXN> k;
-  k.f = f; k.s = (LDS Scratch<MAXN> *)smem;
-  {
-    LDS uint16_t *lc = (LDS uint16_t *)(smem + ((sizeof(Scratch<MAXN>) + 15) & ~(size_t)15));
-    LDS uint16_t *lsc = lc + CDF_TOTAL;
-#if MI_COST_IN_LDS
-    for (int i = LANE; i < CDF_TOTAL; i += 64) lc[i] = f->cost[i];
-    k.cost = lc;
-#else
-    lsc = lc; k.cost = f->cost;
-#endif
-    load_scans_to_lds(lsc, MAXN);
-    k.ls = lsc;
-    WAVE_SYNC();
-  }
+  constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
+  k.f = f; k.sh = (LDS SharedScratch<MAXN> *)smem;
+  k.s = (LDS WaveScratch<MAXN> *)(smem + SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * WS_BYTES);
+  LDS uint16_t *lsc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES);
+  if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
+  k.cost = f->cost; k.ls = lsc;
   k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
+  WG_SYNC();
   if (f->dbg == 1) return;
   const unsigned long long clk0 = wall_clock64();
   for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
     for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)
-      RdPart<MAXN, MAXBS, 4>::run(k, r, c);
-  if (LANE == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
+      RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c);
+  if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 }
