@@ -16,7 +16,7 @@ struct RangeEncDev {
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
   e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->overflow = 0;
 }
-__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) { if (e->offs < e->cap) e->pre[e->offs] = v; else e->overflow = 1; e->offs++; }
+__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) { if (e->offs < e->cap) { if (LANE == 0) e->pre[e->offs] = v; } else e->overflow = 1; e->offs++; }
 __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, unsigned long long low, uint32_t rng) {
   int c = e->cnt;
   const int d = 16 - (32 - __clz(rng));
@@ -43,16 +43,19 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
   }
   re_normalize_dev(e, l, r);
 }
-// encode + adapt (lane 0 only)
+// encode + adapt.  Executed by the whole wave with identical (wave-uniform) operands: the coder state lives in
+// registers on every lane, lane i adapts CDF entry i (spec 8.3.2 update rule, one step instead of a loop).
 __device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s, LDS uint16_t *icdf, int nsyms) {
-  re_encode_q15_dev(e, s > 0 ? icdf[s - 1] : 32768, icdf[s], s, nsyms);
+  const uint32_t fl = s > 0 ? icdf[s - 1] : 32768u, fh = icdf[s];
   const int cnt = icdf[nsyms];
+  re_encode_q15_dev(e, fl, fh, s, nsyms);
   const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
-  for (int i = 0; i < nsyms - 1; i++) {
-    if (i < s) icdf[i] += (uint16_t)((32768 - icdf[i]) >> rate);
-    else icdf[i] -= (uint16_t)(icdf[i] >> rate);
-  }
-  icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
+  const int i = LANE;
+  if (i < nsyms - 1) {
+    const int v = icdf[i];
+    icdf[i] = (uint16_t)(i < s ? v + ((32768 - v) >> rate) : v - (v >> rate));
+  } else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
+  WAVE_SYNC();
 }
 __device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit, uint32_t icdf0) {
   re_encode_q15_dev(e, bit ? icdf0 : 32768, bit ? 0 : icdf0, bit, 2);
@@ -61,7 +64,7 @@ __device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v, int n
   for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
 }
 // returns number of bytes; out must hold them.  (lane 0)
-__device__ inline uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
+__device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
   unsigned long long l = e->low; int c = e->cnt; int s = 10;
   const unsigned long long m = 0x3FFF;
   unsigned long long x = ((l + m) & ~m) | (m + 1);
@@ -84,8 +87,8 @@ struct TileWriter {
   int sb_cols_tile;
 };
 
-// lane 0: code one transform block's coefficients (levels + map already staged in LDS)
-__device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
+// code one transform block's coefficients (levels + map already staged in LDS); wave-uniform control flow
+__device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
                                          int tx_off, int tx_sym, int tx_ns) {
   RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
@@ -129,18 +132,18 @@ __device__ inline void code_coeffs_lane0(TileWriter *w, int eob, int plane, int 
   }
 }
 
-template <int BS> __device__ inline void write_block_dev(TileWriter *w, int r, int c) {
+template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int skip = f->m_skip[mi], ymode = f->m_ymode[mi];
   int uvmode = 0;
-  if (LANE == 0) {
+  {
     RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
     const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
     re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
     if (!skip && f->enable_cdef) {
       const int lsb = ((r - t->mi_row_start) >> 4) * w->sb_cols_tile + ((c - t->mi_col_start) >> 4);
-      if (!w->cdef_done[lsb]) { w->cdef_done[lsb] = 1; re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }
+      if (!w->cdef_done[lsb]) { WAVE_SYNC(); if (LANE == 0) w->cdef_done[lsb] = 1; WAVE_SYNC(); re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }
     }
     const int *imc = intra_mode_ctx_tab();
     const int am = imc[availU ? f->m_ymode[mi - ms] : DC_PRED], lm = imc[availL ? f->m_ymode[mi - 1] : DC_PRED];
@@ -183,48 +186,70 @@ template <int BS> __device__ inline void write_block_dev(TileWriter *w, int r, i
     }
     int sctx2, dctx;
     txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx2, &dctx);
-    if (LANE == 0) code_coeffs_lane0(w, eob, p, BS, txtype, sctx2, dctx, off, sym, ns);
+    code_coeffs_lane0(w, eob, p, BS, txtype, sctx2, dctx, off, sym, ns);
   }
   WAVE_SYNC();
 }
 
-template <int BS> struct WritePart {
-  static __device__ void run(TileWriter *w, int r, int c) {
-    const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride;
-    if (r >= f->mi_rows || c >= f->mi_cols) return;
-    constexpr int half = (1 << BS) >> 1;
-    const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
-    const int actual = f->m_bsize[r * ms + c];
-    int part = actual == BS ? 0 : 3;
-    if (LANE == 0) {
-      const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-      const int above = availU && f->m_bsize[(r - 1) * ms + c] < BS, left = availL && f->m_bsize[r * ms + c - 1] < BS;
-      LDS uint16_t *cdf = w->cdf + CDF_PARTITION + ((BS - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
-      const int ns = BS == BS_8 ? 4 : 10;
-      if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
-      else if (has_rows || has_cols) {
+// Partition symbol of the node (r, c, bs >= 1); returns 0 (NONE) or 3 (SPLIT).  spec 5.11.4
+__device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int c, int bs) {
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride;
+  const int half = (1 << bs) >> 1;
+  const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
+  const int actual = f->m_bsize[r * ms + c];
+  int part = actual == bs ? 0 : 3;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+  LDS uint16_t *cdf = w->cdf + CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
+  const int ns = bs == BS_8 ? 4 : 10;
+  if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
+  else if (has_rows || has_cols) {
 #define PP_(i) ((uint32_t)((i) > 0 ? cdf[(i) - 1] : 32768) - cdf[i])
-        uint32_t psum;
-        if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
-        else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
+    uint32_t psum;
+    if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
+    else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
 #undef PP_
-        re_bool_dev(&w->ec, 1, psum);
+    re_bool_dev(&w->ec, 1, psum);
+  }
+  if (!(has_rows && has_cols)) part = 3;
+  return part;
+}
+
+// Iterative Z-order walk of one superblock (explicit stack, depth <= 5) so that every block-size instance of
+// write_block_dev is inlined exactly once and the range-coder state stays in registers.
+__device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) {
+  const FrameDev *f = w->f;
+  int sr[5], sc[5], sk[5];
+  int sp = 0; sr[0] = r0; sc[0] = c0; sk[0] = 0;
+  while (sp >= 0) {
+    const int bs = 4 - sp;
+    int r = 0, c = 0, kk = 0;
+#pragma unroll
+    for (int q = 0; q < 5; q++) if (q == sp) { r = sr[q]; c = sc[q]; kk = sk[q]; }
+    if (kk == 0) {
+      if (r >= f->mi_rows || c >= f->mi_cols) { sp--; continue; }
+      const int part = bs == 0 ? 0 : write_partition_symbol(w, r, c, bs);
+      if (part == 0) {
+        switch (bs) {
+          case 0: write_block_dev<0>(w, r, c); break;
+          case 1: write_block_dev<1>(w, r, c); break;
+          case 2: write_block_dev<2>(w, r, c); break;
+          case 3: write_block_dev<3>(w, r, c); break;
+          default: write_block_dev<4>(w, r, c); break;
+        }
+        sp--; continue;
       }
     }
-    if (!(has_rows && has_cols)) part = 3;
-    if (part == 0) write_block_dev<BS>(w, r, c);
-    else {
-      WritePart<BS - 1>::run(w, r, c); WritePart<BS - 1>::run(w, r, c + half);
-      WritePart<BS - 1>::run(w, r + half, c); WritePart<BS - 1>::run(w, r + half, c + half);
-    }
+    if (kk == 4) { sp--; continue; }
+    const int half = (1 << bs) >> 1;
+#pragma unroll
+    for (int q = 0; q < 5; q++) if (q == sp) sk[q] = kk + 1;
+    const int nr = r + (kk >> 1) * half, ncol = c + (kk & 1) * half;
+#pragma unroll
+    for (int q = 0; q < 5; q++) if (q == sp + 1) { sr[q] = nr; sc[q] = ncol; sk[q] = 0; }
+    sp++;
   }
-};
-template <> struct WritePart<0> {
-  static __device__ void run(TileWriter *w, int r, int c) {
-    if (r >= w->f->mi_rows || c >= w->f->mi_cols) return;
-    write_block_dev<0>(w, r, c);
-  }
-};
+}
 
 struct EntropyLds {
   uint16_t cdf[CDF_TOTAL];
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   WAVE_SYNC();
   for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
     for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
-      WritePart<4>::run(&w, r, c);
+      write_superblock(&w, r, c);
   WAVE_SYNC();
   if (LANE == 0) {
     const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
