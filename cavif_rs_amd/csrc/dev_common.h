@@ -49,6 +49,7 @@ struct FrameDev {
   uint32_t tile_out_cap;
   int tile_base;             // index of this frame's first tile in the launch-wide tile list
   int dbg;                   // debug bisect level (0 = off)
+  unsigned long long *prof_out;  // profiling builds: per launch-wide tile job, 4 waves x 16 phase cycle counters
   unsigned long long *tile_clk;  // per tile: [start, end] of K1 and of K4 in wall_clock64 ticks (100 MHz), 4 values
 };
 

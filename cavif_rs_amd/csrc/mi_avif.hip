@@ -94,6 +94,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
+  d.prof_out = nullptr;
   d.tile_out_cap = tile_cap;
   return off;
 }
@@ -160,7 +161,7 @@ struct mi_batch {
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
   uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
-  uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0;
+  uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0; unsigned long long *d_prof = nullptr;
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr;
   std::vector<TileJob> jobs;
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
@@ -193,6 +194,7 @@ static void batch_free_device(mi_batch *b) {
   if (b->d_jobs) hipFree(b->d_jobs); b->d_jobs = nullptr;
   if (b->d_precarry) hipFree(b->d_precarry); b->d_precarry = nullptr;
   if (b->d_offsets) hipFree(b->d_offsets); b->d_offsets = nullptr;
+  if (b->d_prof) hipFree(b->d_prof); b->d_prof = nullptr;
   if (b->d_packed) hipFree(b->d_packed); b->d_packed = nullptr;
   if (b->h_packed) hipHostFree(b->h_packed); b->h_packed = nullptr;
   if (b->h_lens) hipHostFree(b->h_lens); b->h_lens = nullptr;
@@ -223,6 +225,7 @@ static int batch_alloc(mi_batch *b) {
   b->pre_cap = max_cap;
   HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * max_cap * 2));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
+  HIP_OK(hipMalloc(&b->d_prof, max_tiles * 64 * 8));
   b->packed_cap = std::min<size_t>(packed, (size_t)1 << 31);
   HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
@@ -288,6 +291,13 @@ int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
   for (auto &p : b->frames) { HIP_OK(hipMemcpy(out + (size_t)p.dev.tile_base * 4, p.dev.tile_clk, (size_t)p.ntiles * 32, hipMemcpyDeviceToHost)); o += (size_t)p.ntiles * 4; }
   return MI_OK;
 }
+// profiling builds (MI_PROFILE=1): K1 phase cycle counters, 64 values per tile job of the last encode
+int mi_batch_phase_profile(mi_batch *b, unsigned long long *out) {
+  if (!b || !out || !b->d_prof) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  HIP_OK(hipMemcpy(out, b->d_prof, b->jobs.size() * 64 * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
 double mi_batch_stage_ms(const mi_batch *b, int stage) { return (b && stage >= 0 && stage < 8) ? b->stage_ms[stage] : 0.0; }
 
@@ -342,6 +352,7 @@ int mi_batch_encode(mi_batch *b) {
       FramePlan &p = b->frames[k];
       if (std::max(p.maxbs, 2) != cls) continue;
       p.dev.tile_base = (int)b->jobs.size();
+      p.dev.prof_out = b->d_prof;
       for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) b->jobs.push_back(TileJob{ (int)k, tr, tc });
     }
   }

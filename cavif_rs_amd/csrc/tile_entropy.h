@@ -83,18 +83,39 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
 struct TileWriter {
   const FrameDev *f; TileB t; RangeEncDev ec; LDS uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
+  LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient records of the current transform block
   LDS uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
   int sb_cols_tile;
 };
 
-// code one transform block's coefficients (levels + map already staged in LDS); wave-uniform control flow
+// Code one transform block's coefficients (levels + padded level map already staged in LDS).
+// Two phases: (P) every lane derives the CDF rows (contexts) of its own scan positions -- they depend only on the
+// level map, not on the coder state -- and leaves (cdf offset, level, sign) records in LDS; (S) the wave walks
+// the records in coding order and drives the adaptive range coder, wave-uniform.
 __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
-                                         int tx_off, int tx_sym, int tx_ns) {
+                                                  int tx_off, int tx_sym, int tx_ns) {
   RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
   if (eob == 0) return;
+  // ---- (P) contexts, lane-parallel
+  const int st = n + 4, area = n * n;
+  for (int c = LANE; c < eob; c += 64) {
+    const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
+    const int v = qc[p], level = iabs_(v);
+    const LDS uint8_t *L = lev + row * st + col;
+    int off;
+    if (c == eob - 1) {
+      const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
+      off = CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE;
+    } else off = CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + base_ctx(L, st, cls, row, col)) * CDF_COEFF_BASE_STRIDE;
+    int boff = 0;
+    if (level > 2) boff = CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + br_ctx(L, st, cls, row, col, c)) * CDF_COEFF_BR_STRIDE;
+    w->rec_off[c] = (uint16_t)off; w->rec_br[c] = (uint16_t)boff; w->rec_lv[c] = ((uint32_t)level << 1) | (uint32_t)(v < 0);
+  }
+  WAVE_SYNC();
+  // ---- (S) serial coding
   if (tx_off >= 0) re_symbol_dev(e, tx_sym, cdf + tx_off, tx_ns);
   const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
   re_symbol_dev(e, eob_pt - 1, cdf + eob_pt_cdf(eob_multi, pt, cls), 5 + eob_multi);
@@ -103,30 +124,22 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int pl
     re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
     if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
   }
-  const int st = n + 4, area = n * n;
   for (int c = eob - 1; c >= 0; c--) {
-    const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
-    const int level = iabs_(qc[p]);
-    const LDS uint8_t *L = lev + row * st + col;
-    if (c == eob - 1) {
-      const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
-      re_symbol_dev(e, imin_(level, 3) - 1, cdf + CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE, 3);
-    } else {
-      const int ctx = base_ctx(L, st, cls, row, col);
-      re_symbol_dev(e, imin_(level, 3), cdf + CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE, 4);
-    }
+    const int level = (int)(w->rec_lv[c] >> 1);
+    LDS uint16_t *bc0 = cdf + w->rec_off[c];
+    if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, bc0, 3);
+    else re_symbol_dev(e, imin_(level, 3), bc0, 4);
     if (level > 2) {
-      const int ctx = br_ctx(L, st, cls, row, col, c);
-      LDS uint16_t *bc = cdf + CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+      LDS uint16_t *bc = cdf + w->rec_br[c];
       int rem = level - 3;
       for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
     }
   }
   for (int c = 0; c < eob; c++) {
-    const int p = scan_pos(w->ls, n, cls, c), v = qc[p], a = iabs_(v);
+    const uint32_t m = w->rec_lv[c]; const int a = (int)(m >> 1), neg = (int)(m & 1);
     if (a) {
-      if (c == 0) re_symbol_dev(e, v < 0, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
-      else re_bool_dev(e, v < 0, 16384);
+      if (c == 0) re_symbol_dev(e, neg, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
+      else re_bool_dev(e, neg, 16384);
       if (a > 14) { const uint32_t xg = (uint32_t)(a - 14); const int len = 32 - __clz(xg); re_literal_dev(e, 0, len - 1); re_literal_dev(e, xg, len); }
     }
   }
@@ -256,6 +269,8 @@ struct EntropyLds {
   int32_t qc[32 * 32];
   uint8_t lev[36 * 36 + 4];
   uint16_t scans[1360];
+  uint16_t rec_off[1024], rec_br[1024];
+  uint32_t rec_lv[1024];
   uint8_t cdef_done[MI_MAX_TILE_COLS * MI_MAX_TILE_ROWS > 4096 ? 4096 : 4096];
 };
 
@@ -270,6 +285,7 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_done = (LDS uint8_t *)L.cdef_done; w.ls = (LDS uint16_t *)L.scans;
+  w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
   load_scans_to_lds((LDS uint16_t *)L.scans, 32);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];

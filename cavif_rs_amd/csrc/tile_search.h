@@ -20,6 +20,17 @@
 #define MI_K1_WG_PER_CU 4
 #endif
 #define WAVE_ID ((int)(threadIdx.x >> 6))
+#ifndef MI_PROFILE
+#define MI_PROFILE 0
+#endif
+// phase timers (profiling builds only): per wave, accumulated in LDS, flushed to the tile's clock record
+#if MI_PROFILE
+#define PH_BEGIN() unsigned long long ph_t_ = clock64()
+#define PH(i) do { const unsigned long long n_ = clock64(); if (LANE == 0) SH->prof[W][i] += n_ - ph_t_; ph_t_ = n_; } while (0)
+#else
+#define PH_BEGIN() do {} while (0)
+#define PH(i) do {} while (0)
+#endif
 
 template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32;
@@ -35,7 +46,10 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   long long satd[13], dsd[7][6];
   long long wbest_j[4], cj[16][2], pbest_j[2];
   int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16];
-  int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2];
+  int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
+#if MI_PROFILE
+  unsigned long long prof[4][16];
+#endif
 };
 
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
@@ -145,17 +159,23 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   int ftype_uv = 0;
   if (f->np > 1) ftype_uv = (availU && IS_SMOOTH_(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH_(f->m_uvmode[mi - 1]));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
-  int sctx_p[3] = { 0, 0, 0 }, dctx_p[3] = { 0, 0, 0 };      // all-zero / dc-sign contexts depend on the neighbours only
-  for (int p = 0; p < f->np; p++) txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx_p[p], &dctx_p[p]);
+  PH_BEGIN();
 
   // ---- stage the source block and the raw edges of every plane (plane p by wave p % NW) ----
   for (int p = 0; p < f->np; p++) if (p % NW == W) {
+    int sc_, dc_;                                            // all-zero / dc-sign contexts depend on the neighbours only
+    txb_ctx_dev(f, t, p, r, c, BS, BS, &sc_, &dc_);
+    if (LANE == 0) { SH->sctx[p] = sc_; SH->dctx[p] = dc_; }
     const uint16_t *g = f->src[p] + (size_t)y * f->stride + x;
     for (int idx = LANE; idx < nn; idx += 64) SH->srcb[p][idx] = g[(idx / n) * f->stride + (idx % n)];
     load_edges(f, p, x, y, n, availL, availU, have_ar, have_bl, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF);
   }
+  PH(1);
   WG_SYNC();
+  PH(2);
   if (f->dbg == 3) return 0;
+  int sctx_p[3], dctx_p[3];
+  for (int p = 0; p < 3; p++) { sctx_p[p] = SH->sctx[p]; dctx_p[p] = SH->dctx[p]; }
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
@@ -164,12 +184,16 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     const long long sd = satd_dev(SH->srcb[0], S->pred, n);
     if (LANE == 0) SH->satd[m] = sd;
   }
+  PH(3);
   WG_SYNC();
+  PH(2);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 13; i++) SH->order[i] = i;
     for (int i = 1; i < 13; i++) { const int v = SH->order[i]; int j = i; while (j > 0 && SH->satd[SH->order[j - 1]] > SH->satd[v]) { SH->order[j] = SH->order[j - 1]; j--; } SH->order[j] = v; }
   }
+  PH(4);
   WG_SYNC();
+  PH(2);
   const int ncand = f->complex_modes ? 7 : 3;
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
   const int dl[6] = { -1, 1, -2, 2, -3, 3 };
@@ -183,7 +207,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
         if (LANE == 0) SH->dsd[ci][q] = sd;
       }
     }
+    PH(5);
     WG_SYNC();
+    PH(2);
   }
   // ---- full RD over surviving (mode, delta) x tx type: eval e = ci*ntx + ti by wave e % NW ----
   int tx_ns = 0, tx_set = 0;
@@ -212,7 +238,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; cur ^= 1; }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
+  PH(6);
   WG_SYNC();
+  PH(2);
   int win = 0;
   for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
   const long long best_j = SH->wbest_j[win];
@@ -226,7 +254,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = S->rec[b][i];
     if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; }
   }
+  PH(7);
   WG_SYNC();
+  PH(2);
   if (f->dbg == 5) return 0;
   const int best_mode = SH->lm_mode, best_delta = SH->lm_delta;
   long long total_j = best_j; int any_coef = SH->lm_eob > 0;
@@ -244,8 +274,18 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     constexpr int NPAIR = 2;
     const int pair = (W >> 1) & 1, active = W < 4;
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
-    for (int base = 0; base < nc; base += NPAIR) {
-      const int ci2 = base + pair, valid = active && ci2 < nc;
+    // pair 0: candidates 0 and the odd ones; pair 1: the even ones from 2 on and CfL (always last) -- the winner rule
+    // below only looks at (cost, candidate index), so the dealing order does not change the decision.
+    int mine[16], nmine = 0, nother = 0;
+    for (int i = 0; i < nc; i++) {
+      const int pr = (cands[i] == UV_CFL_PRED) ? 1 : (i == 0 || (i & 1)) ? 0 : 1;
+      if (pr == pair) mine[nmine++] = i; else nother++;
+    }
+    const int rounds = imax_(nmine, nother);
+    for (int rd = 0; rd < rounds; rd++) {
+      const int valid = active && rd < nmine;
+      int ci2 = 0;
+      for (int q = 0; q < 16; q++) if (q == rd && valid) ci2 = mine[q];
       const int um = valid ? cands[ci2] : DC_PRED;
       const int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && BS >= BS_8) ? best_delta : 0;
       int txtype = mode_to_txtype(um);
@@ -287,7 +327,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
           if (LANE == 0) SH->calpha[pair][p - 1] = best_a;
         }
       }
+      PH(8);
       WG_SYNC();                                            // (A) alphas of both planes visible
+      PH(2);
       int alpha_u = 0, alpha_v = 0, jsign = 0, ok = valid;
       uint32_t mode_rate = uvcost[um];
       if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
@@ -330,7 +372,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
         }
       }
       if (valid && LANE == 0 && (W & 1) == 0) SH->cok[ci2] = ok;
+      PH(9);
       WG_SYNC();                                            // (B) both planes' costs visible
+      PH(2);
       if (valid && ok) {
         const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (j < pb_j) { pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp; ccur ^= 1; }
@@ -338,6 +382,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
     }
     if (LANE == 0 && (W & 1) == 0 && W < 4) { SH->pbest_j[pair] = pb_j; SH->pbest_c[pair] = pb_c; }
     WG_SYNC();
+    PH(2);
     int wp = 0;
     if ((SH->pbest_j[1] < SH->pbest_j[0] || (SH->pbest_j[1] == SH->pbest_j[0] && SH->pbest_c[1] < SH->pbest_c[0]))) wp = 1;
     const long long best_uv = SH->pbest_j[wp];
@@ -354,7 +399,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
         fill_map_dev(f->m_cfl_av, ms, r, c, n4, pb_av ? iabs_(pb_av) - 1 : 0);
       }
     }
+    PH(10);
     WG_SYNC();
+    PH(2);
     any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
     total_j += best_uv;
     (void)qn;
@@ -369,7 +416,9 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   }
   const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
   total_j += ((long long)k.cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
+  PH(11);
   WG_SYNC();
+  PH(2);
   return total_j;
 }
 
@@ -482,6 +531,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
+#if MI_PROFILE
+  if (threadIdx.x < 64) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
+#endif
   WG_SYNC();
   if (f->dbg == 1) return;
   const unsigned long long clk0 = wall_clock64();
@@ -489,4 +541,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)
       RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c);
   if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
+#if MI_PROFILE
+  WG_SYNC();
+  if (f->prof_out && threadIdx.x < 64) f->prof_out[(size_t)job * 64 + threadIdx.x] = ((LDS unsigned long long *)k.sh->prof)[threadIdx.x];
+#endif
 }

@@ -78,6 +78,8 @@ def load_library():
     L.mi_batch_stage_ms.restype = C.c_double
     L.mi_batch_num_tiles.argtypes = [C.c_void_p]
     L.mi_batch_tile_clocks.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(L, 'mi_batch_phase_profile'):
+        L.mi_batch_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_batch_destroy.argtypes = [C.c_void_p]
     L.mi_avif_serialize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
                                     C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8))]
@@ -310,6 +312,13 @@ class BatchEncoder:
     def tile_clocks(self):
         a = np.zeros((self.num_tiles(), 4), dtype=np.uint64)
         st = self._L.mi_batch_tile_clocks(self._h, a.ctypes.data)
+        if st:
+            raise AvifError(st)
+        return a
+
+    def phase_profile(self):
+        a = np.zeros((self.num_tiles(), 4, 16), dtype=np.uint64)
+        st = self._L.mi_batch_phase_profile(self._h, a.ctypes.data)
         if st:
             raise AvifError(st)
         return a
