@@ -65,6 +65,7 @@ def main():
     ap.add_argument('--depth', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-identity-check', action='store_true')
+    ap.add_argument('--pipeline', type=int, default=2, help='resident batches driven alternately (2 = double buffering: one batch entropy-codes while the next searches)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -89,31 +90,45 @@ def main():
     device = local_rank % ndev
     enc = m.Encoder().with_quality(args.quality).with_speed(args.speed).with_bit_depth(args.depth).with_device(device)
     w, h, B = args.width, args.height, args.batch
-    batch = m.BatchEncoder(enc, B, w, h, channels=3)
+    depth_q = max(1, args.pipeline)
+    batches = [m.BatchEncoder(enc, B, w, h, channels=3) for _ in range(depth_q)]
+    batch = batches[0]
     first = None
     for i in range(B):
         img = synth_image(w, h, index=rank * B + i)
         if i == 0:
             first = img
-        batch.upload(i, img)          # H2D happens here, outside the timed region
+        for bt in batches:
+            bt.upload(i, img)         # H2D happens here, outside the timed region (every pipeline slot holds the same batch)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        batch.encode()
+    def run_steps(n):
+        """n steps; step k runs on slot k % depth_q; a slot is waited for right before it is reused and at the end."""
+        stats = []
+        inflight = []
+        for k_ in range(n):
+            bt = batches[k_ % depth_q]
+            if len(inflight) == depth_q:
+                old = inflight.pop(0); old.wait(); stats.append(old.stage_ms())
+            bt.encode_async(); inflight.append(bt)
+        for old in inflight:
+            old.wait(); stats.append(old.stage_ms())   # returns after the stream is drained and the .avif bytes are on the host
+        return stats
+
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
+    stats = run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
     search_ms, stage_acc = [], {}
-    for _ in range(args.steps):
-        batch.encode()                # returns after the stream is drained and the .avif bytes are on the host
-        st = batch.stage_ms()
+    for st in stats:
         search_ms.append(st['tile_search'])
         for k_, v_ in st.items():
             stage_acc[k_] = stage_acc.get(k_, 0.0) + v_
-    barrier()
-    elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -134,7 +149,7 @@ def main():
             "config": {"workload": "batch of %d synthetic %dx%d RGB8 images per GPU, speed=%d quality=%g depth=%d, 4:4:4 BT.601, %d tiles per step per GPU"
                                    % (B, w, h, args.speed, args.quality, args.depth, batch.num_tiles()),
                        "images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth,
-                       "parallelism": "images sharded across %d GPU(s), no collective" % world},
+                       "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU driven alternately" % (world, depth_q)},
             "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(k1 * 1e3, 3)},
@@ -150,7 +165,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, args.speed, args.quality, args.depth)
         print(json.dumps(out), flush=True)
-    batch.close()
+    for bt in batches:
+        bt.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

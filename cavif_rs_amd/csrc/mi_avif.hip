@@ -163,10 +163,10 @@ struct mi_batch {
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
   uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0; unsigned long long *d_prof = nullptr;
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr;
-  std::vector<TileJob> jobs;
+  std::vector<TileJob> jobs; std::vector<FrameDev> hframes;
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
   hipEvent_t ev[8]{}; double stage_ms[8]{};
-  bool planned = false;
+  bool planned = false, in_flight = false;
 };
 
 static int batch_plan(mi_batch *b, bool with_alpha_frames) {
@@ -301,8 +301,10 @@ int mi_batch_phase_profile(mi_batch *b, unsigned long long *out) {
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
 double mi_batch_stage_ms(const mi_batch *b, int stage) { return (b && stage >= 0 && stage < 8) ? b->stage_ms[stage] : 0.0; }
 
-int mi_batch_encode(mi_batch *b) {
+// Enqueues the GPU part of the hot path (K0..K4 + tile-length readback) on the batch's stream and returns.
+int mi_batch_encode_async(mi_batch *b) {
   if (!b) return MI_INVALID_ARGUMENT;
+  if (b->in_flight) return MI_INVALID_ARGUMENT;
   hipSetDevice(b->device);
   const DeviceTables &tab = g_tabs[b->device];
   hipStream_t s = b->stream;
@@ -363,8 +365,8 @@ int mi_batch_encode(mi_batch *b) {
     // clear the state the kernels rely on being zero
     HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
   }
-  std::vector<FrameDev> hframes; for (auto &p : b->frames) hframes.push_back(p.dev);
-  HIP_OK(hipMemcpyAsync(b->d_frames, hframes.data(), sizeof(FrameDev) * hframes.size(), hipMemcpyHostToDevice, s));
+  b->hframes.clear(); for (auto &p : b->frames) b->hframes.push_back(p.dev);     // must outlive the async copy
+  HIP_OK(hipMemcpyAsync(b->d_frames, b->hframes.data(), sizeof(FrameDev) * b->hframes.size(), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
   // ---- K1 tile search
@@ -385,10 +387,19 @@ int mi_batch_encode(mi_batch *b) {
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
+  for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); }
+  b->in_flight = true;
+  return MI_OK;
+}
+
+// Waits for the enqueued work, compacts + downloads the tile payloads (one D2H) and assembles OBUs and containers.
+int mi_batch_wait(mi_batch *b) {
+  if (!b || !b->in_flight) return MI_INVALID_ARGUMENT;
+  hipSetDevice(b->device);
+  hipStream_t s = b->stream;
+  b->in_flight = false;
+  const int njobs = (int)b->jobs.size();
   std::vector<uint32_t> offsets(njobs);
-  {
-    for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); }
-  }
   HIP_OK(hipStreamSynchronize(s));
   size_t total = 0;
   for (int j = 0; j < njobs; j++) {
@@ -420,6 +431,11 @@ int mi_batch_encode(mi_batch *b) {
   HIP_OK(hipEventSynchronize(b->ev[7]));
   for (int i = 0; i < 7; i++) { float ms = 0; hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]); b->stage_ms[i] = ms; }
   return MI_OK;
+}
+
+int mi_batch_encode(mi_batch *b) {
+  const int st = mi_batch_encode_async(b);
+  return st ? st : mi_batch_wait(b);
 }
 
 int mi_batch_get(mi_batch *b, int index, mi_encoded_image *out) {

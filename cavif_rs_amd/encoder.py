@@ -72,6 +72,8 @@ def load_library():
     L.mi_batch_create.restype = C.c_void_p
     L.mi_batch_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.mi_batch_encode.argtypes = [C.c_void_p]
+    L.mi_batch_encode_async.argtypes = [C.c_void_p]
+    L.mi_batch_wait.argtypes = [C.c_void_p]
     L.mi_batch_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(_EncodedImage)]
     L.mi_batch_get_recon.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint16))]
     L.mi_batch_stage_ms.argtypes = [C.c_void_p, C.c_int]
@@ -280,6 +282,16 @@ class BatchEncoder:
 
     def encode(self):
         st = self._L.mi_batch_encode(self._h)
+        if st:
+            raise AvifError(st)
+
+    def encode_async(self):
+        st = self._L.mi_batch_encode_async(self._h)
+        if st:
+            raise AvifError(st)
+
+    def wait(self):
+        st = self._L.mi_batch_wait(self._h)
         if st:
             raise AvifError(st)
 

@@ -82,6 +82,10 @@ typedef struct mi_batch mi_batch;
 mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels);
 int  mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px);   /* H2D into the batch's HBM input slot */
 int  mi_batch_encode(mi_batch *b);                                                        /* the hot path over all resident images */
+/* split form: enqueue the GPU work and return; wait = sync + one packed D2H + OBU/container assembly.  Two batches
+ * driven alternately overlap one batch's entropy coding / loop filters with the next batch's tile search. */
+int  mi_batch_encode_async(mi_batch *b);
+int  mi_batch_wait(mi_batch *b);
 int  mi_batch_get(mi_batch *b, int index, mi_encoded_image *out);                         /* copies; caller frees avif_file */
 int  mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]);          /* malloc'd w*h uint16 planes (tests) */
 /* per-kernel HIP-event time (ms) of the last mi_batch_encode: 0 front-end, 1 tile search, 2 deblock, 3 cdef, 4 entropy, 5 pack+D2H, 6 host assembly */
