@@ -131,7 +131,7 @@ __device__ __forceinline__ int scan_pos(const LDS uint16_t *ls, int n, int cls, 
   const int c = i / n, r = i - c * n; return r * n + c; // mcol scan
 }
 // intra tx-type CDF row for luma; returns -1 when the type is not signalled
-__device__ __forceinline__ int intra_tx_cdf(const FrameDev *f, int txs, int ymode, int *nsyms, int *set_out) {
+template <typename FP> __device__ __forceinline__ int intra_tx_cdf(FP f, int txs, int ymode, int *nsyms, int *set_out) {
   const int set = tx_set_of(txs, f->reduced_tx_set);
   *set_out = set;
   if (set == 0 || f->base_q_idx == 0) { *nsyms = 0; return -1; }

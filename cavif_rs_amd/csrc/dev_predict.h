@@ -54,7 +54,7 @@ __device__ __forceinline__ int edge_upsample_sel_dev(int w, int h, int ft, int d
 }
 
 // Raw (unfiltered) edges of the block at pixel (x,y) of `plane`: above[-1..2n-1], left[-1..2n-1]. (spec 7.11.2 steps 1-4)
-__device__ inline void load_edges(const FrameDev *f, int plane, int x, int y, int n, int have_left, int have_above,
+__device__ inline void load_edges(const LDS FrameDev *f, int plane, int x, int y, int n, int have_left, int have_above,
                                   int have_ar, int have_bl, LDS uint16_t *above /* +EDGE_OFF */, LDS uint16_t *left) {
   const int bd = f->bd, rs = f->stride;
   const uint16_t *rec = f->rec[plane];
@@ -117,7 +117,7 @@ __device__ inline void edge_upsample_dev(LDS uint16_t *buf, int num_px, int bd, 
 }
 
 // Predict an n x n block into pred[n*n] from raw edges. wa/wl are working copies (modified by filters).
-__device__ inline void predict_block(const FrameDev *f, int x, int y, int log2w, int have_left, int have_above,
+__device__ inline void predict_block(const LDS FrameDev *f, int x, int y, int log2w, int have_left, int have_above,
                                      int mode, int angle_delta, int ftype, const LDS uint16_t *ra, const LDS uint16_t *rl,
                                      LDS uint16_t *wa, LDS uint16_t *wl, LDS uint16_t *tmp, LDS uint16_t *pred) {
   const int n = 1 << log2w, bd = f->bd, nn = n * n;
@@ -204,7 +204,7 @@ __device__ inline void predict_block(const FrameDev *f, int x, int y, int log2w,
 }
 
 // spec 7.11.5 (4:4:4): pred holds the DC prediction on entry; luma reconstruction read from f->rec[0].
-__device__ inline void predict_cfl_dev(const FrameDev *f, int x, int y, int log2w, int alpha, const LDS uint16_t *dcp, LDS uint16_t *out) {
+__device__ inline void predict_cfl_dev(const LDS FrameDev *f, int x, int y, int log2w, int alpha, const LDS uint16_t *dcp, LDS uint16_t *out) {
   const int n = 1 << log2w, nn = n * n, mx = (1 << f->bd) - 1, rs = f->stride;
   const uint16_t *luma = f->rec[0] + y * rs + x;
   int s = 0;

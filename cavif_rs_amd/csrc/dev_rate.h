@@ -6,7 +6,7 @@
 #include "dev_common.h"
 
 // all_zero and dc_sign contexts from the level/dc maps left by the neighbours (inside the tile only)
-__device__ inline void txb_ctx_dev(const FrameDev *f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
+template <typename FP> __device__ inline void txb_ctx_dev(FP f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
   const int w4 = 1 << txs, ms = f->mi_stride;
   int top = 0, left = 0, dcs = 0, any_a = 0, any_l = 0;
   const int k = LANE;
@@ -81,19 +81,48 @@ __device__ inline void build_level_map(const LDS int32_t *qc, LDS uint8_t *lev, 
 }
 
 // Rate (1/512 bit) of coeffs() for one transform block. tx_off >= 0: luma tx-type symbol is priced too.
-template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(CostPtr cost, const LDS uint16_t *ls, const LDS int32_t *qc, int eob, int plane, int txs, int txtype,
+// LDS-resident slices of the static rate table that coefficient coding touches (tx sizes 0..max only)
+struct CoefCost { const LDS uint16_t *txb, *eobx, *dcs, *br, *base, *beob, *eobpt[4]; };
+__device__ __forceinline__ int coef_cost_entries(int maxtxs) {
+  const int t = maxtxs + 1, tb = imin_(maxtxs, 3) + 1;
+  return t * 13 * CDF_TXB_SKIP_STRIDE + t * 18 * CDF_EOB_EXTRA_STRIDE + 6 * CDF_DC_SIGN_STRIDE + tb * 42 * CDF_COEFF_BR_STRIDE +
+         t * 84 * CDF_COEFF_BASE_STRIDE + t * 8 * CDF_COEFF_BASE_EOB_STRIDE + 4 * (CDF_EOB_PT_16_STRIDE + CDF_EOB_PT_64_STRIDE + CDF_EOB_PT_256_STRIDE + CDF_EOB_PT_1024_STRIDE);
+}
+#define COEF_COST_MAX_ENTRIES(maxtxs) (((maxtxs) + 1) * (13 * 3 + 18 * 3 + 84 * 5 + 8 * 4) + 18 + ((maxtxs) < 3 ? (maxtxs) + 1 : 4) * 42 * 5 + 4 * (6 + 8 + 10 + 12))
+// all threads of the workgroup copy; returns the table pointers
+__device__ inline void load_coef_cost(CoefCost *cc, LDS uint16_t *dst, const uint16_t *cost, int maxtxs, int tid, int nthreads) {
+  const int t = maxtxs + 1, tb = imin_(maxtxs, 3) + 1;
+  int o = 0;
+  auto take = [&](int src_off, int count) { LDS uint16_t *p = dst + o; for (int i = tid; i < count; i += nthreads) p[i] = cost[src_off + i]; o += count; return (const LDS uint16_t *)p; };
+  cc->txb = take(CDF_TXB_SKIP, t * 13 * CDF_TXB_SKIP_STRIDE);
+  cc->eobx = take(CDF_EOB_EXTRA, t * 18 * CDF_EOB_EXTRA_STRIDE);
+  cc->dcs = take(CDF_DC_SIGN, 6 * CDF_DC_SIGN_STRIDE);
+  cc->br = take(CDF_COEFF_BR, tb * 42 * CDF_COEFF_BR_STRIDE);
+  cc->base = take(CDF_COEFF_BASE, t * 84 * CDF_COEFF_BASE_STRIDE);
+  cc->beob = take(CDF_COEFF_BASE_EOB, t * 8 * CDF_COEFF_BASE_EOB_STRIDE);
+  cc->eobpt[0] = take(CDF_EOB_PT_16, 4 * CDF_EOB_PT_16_STRIDE);
+  cc->eobpt[1] = take(CDF_EOB_PT_64, 4 * CDF_EOB_PT_64_STRIDE);
+  cc->eobpt[2] = take(CDF_EOB_PT_256, 4 * CDF_EOB_PT_256_STRIDE);
+  cc->eobpt[3] = take(CDF_EOB_PT_1024, 4 * CDF_EOB_PT_1024_STRIDE);
+}
+
+template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(const CoefCost &cc, CostPtr cost, const LDS uint16_t *ls, const LDS int32_t *qc, int eob, int plane, int txs, int txtype,
                                          int skip_ctx, int dc_ctx, int tx_off, int tx_sym, LDS uint8_t *lev, int *cul_out, int *dc_cat) {
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   *cul_out = 0; *dc_cat = 0;
-  uint32_t head = cost[CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
   if (eob == 0) return head;
   if (tx_off >= 0) head += cost[tx_off + tx_sym];
   const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
-  head += cost[eob_pt_cdf(eob_multi, pt, cls) + eob_pt - 1];
+  {
+    const int strs[4] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_1024_STRIDE };
+    const int sq = eob_multi >> 1;                        // square transforms: 16 / 64 / 256 / 1024 coefficients
+    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * strs[sq] + eob_pt - 1];
+  }
   if (eob_pt >= 3) {
     const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
-    head += cost[CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
+    head += cc.eobx[((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
     head += 512u * (uint32_t)(nb - 1);
   }
   build_level_map(qc, lev, n);
@@ -105,19 +134,19 @@ template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(CostPtr cos
     const LDS uint8_t *L = lev + row * st + col;
     if (c == eob - 1) {
       const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
-      bits += cost[CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+      bits += cc.beob[((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
     } else {
       const int ctx = base_ctx(L, st, cls, row, col);
-      bits += cost[CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+      bits += cc.base[((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
     }
     if (level > 2) {
       const int ctx = br_ctx(L, st, cls, row, col, c);
-      const int off = CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+      const int off = ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
       int rem = level - 3;
-      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); bits += cost[off + s]; rem -= s; if (s < 3) break; }
+      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); bits += cc.br[off + s]; rem -= s; if (s < 3) break; }
     }
     if (level) {
-      if (c == 0) { bits += cost[CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + (v < 0)]; dcc = v < 0 ? 1 : 2; }
+      if (c == 0) { bits += cc.dcs[(pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + (v < 0)]; dcc = v < 0 ? 1 : 2; }
       else bits += 512;
       if (level > 14) { const int len = 32 - __clz(level - 14); bits += 512 * (2 * len - 1); }
     }

@@ -105,6 +105,7 @@ __device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *co
   last = wave_max_i32(last);
   const uint32_t a0 = (uint32_t)iabs_(coef[0]) << lsh;
   const int l0 = (int)((a0 + dc_off) / (uint32_t)dcq);
+  const uint32_t recip = 0xFFFFFFFFu / uq;              // floor((2^32-1)/q): one division per block, then multiply-high + fix-up per coefficient
   int eob = last;
   if (eob == 0) eob = l0 ? 1 : 0;
   for (int i = LANE; i < nc; i += 64) {
@@ -114,7 +115,8 @@ __device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *co
       if (i == 0) v = coef[0] < 0 ? -l0 : l0;
       else {
         const uint32_t a = (uint32_t)iabs_(coef[p]) << lsh;
-        const uint32_t lv0 = a / uq;
+        uint32_t lv0 = __umulhi(a, recip);            // a/q - 1 < lv0 <= a/q for a < 2^31
+        if (a - lv0 * uq >= uq) lv0++;
         const uint32_t off = lv0 > 0 ? off1 : off0;
         const int lv = (int)lv0 + ((a + off) >= (lv0 + 1) * uq);
         v = coef[p] < 0 ? -lv : lv;

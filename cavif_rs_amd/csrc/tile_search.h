@@ -55,8 +55,8 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
 
 template <int MAXN> struct Ctx {
-  const FrameDev *f; TileB t; LDS WaveScratch<MAXN> *s; LDS SharedScratch<MAXN> *sh; uint8_t *snap;
-  const uint16_t *cost; const LDS uint16_t *ls;
+  const LDS FrameDev *f; TileB t; LDS WaveScratch<MAXN> *s; LDS SharedScratch<MAXN> *sh; uint8_t *snap;
+  const uint16_t *cost; const LDS uint16_t *ls; CoefCost cc;
 };
 
 __device__ __forceinline__ const int *intra_mode_ctx_tab() { static __device__ const int t[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }; return t; }
@@ -68,7 +68,7 @@ __device__ inline void fill_map_dev(uint8_t *m, int ms, int r, int c, int n4, in
   for (int i = LANE; i < n4 * n4; i += 64) m[(r + i / n4) * ms + c + (i % n4)] = (uint8_t)v;
 }
 // whole workgroup
-template <int NW> __device__ inline void set_decoded_wg(const FrameDev *f, int r, int c, int n4, int v) {
+template <int NW> __device__ inline void set_decoded_wg(const LDS FrameDev *f, int r, int c, int n4, int v) {
   for (int i = threadIdx.x; i < n4 * n4; i += 64 * NW) f->m_decoded[(r + i / n4) * f->mi_stride + c + (i % n4)] = (uint8_t)v;
   WG_SYNC();
 }
@@ -100,9 +100,9 @@ __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t
   return wave_sum_i64((long long)total);
 }
 __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b, int nn) {
-  long long s = 0;
-  for (int i = LANE; i < nn; i += 64) { const int d = (int)a[i] - (int)b[i]; s += (long long)d * d; }
-  return wave_sum_i64(s);
+  int s = 0;                                     // per lane <= 64 samples * 1023^2 < 2^27
+  for (int i = LANE; i < nn; i += 64) { const int d = (int)a[i] - (int)b[i]; s += __mul24(d, d); }
+  return wave_sum_i64((long long)s);
 }
 
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
@@ -110,7 +110,7 @@ template <int MAXN, int BS>
 __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
-  const FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
+  const LDS FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
   const LDS uint16_t *src = k.sh->srcb[plane];
   for (int idx = LANE; idx < n * n; idx += 64) {
     const int i = idx / n, j = idx % n;
@@ -120,7 +120,7 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   WAVE_SYNC();
   fwd_txfm2d_dev<n>(S->tbuf, S->cbuf, txtype);
   const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane]);
-  tr->rate = coef_rate_dev(k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
+  tr->rate = coef_rate_dev(k.cc, k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
   if (eob > 0) {
     dequantize_dev(qc_out, S->cbuf, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
     inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
@@ -132,7 +132,7 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
 
 // one wave writes a plane's result back to the frame buffers
 template <int BS>
-__device__ inline void commit_plane(const FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
+__device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
   constexpr int n = 4 << BS, CS = n < 32 ? n : 32, n4 = 1 << BS;
   uint16_t *gr = f->rec[plane] + (size_t)(r * 4) * f->stride + c * 4;
   int32_t *gc = f->coef[plane] + (size_t)(r * 4) * f->stride + c * 4;
@@ -146,7 +146,7 @@ __device__ inline void commit_plane(const FrameDev *f, int plane, int r, int c, 
 template <int MAXN, int BS, int NW>
 __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
-  const FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
+  const LDS FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
   const int W = NW > 1 ? WAVE_ID : 0;
   const int ms = f->mi_stride, mi = r * ms + c, x = c * 4, y = r * 4;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
@@ -300,11 +300,11 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
           lsum = wave_sum_i32(lsum);
           const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
           predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
-          long long e0 = 0;
-          for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += (long long)d * d; }
-          long long best_sse = wave_sum_i64(e0); int best_a = 0;
+          int e0 = 0;
+          for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
+          long long best_sse = wave_sum_i64((long long)e0); int best_a = 0;
           for (int a0 = 0; a0 < 32; a0 += 8) {
-            long long e[8];
+            int e[8];                                       // CfL blocks are <= 32x32: 16 samples per lane
 #pragma unroll
             for (int a = 0; a < 8; a++) e[a] = 0;
             for (int idx = LANE; idx < nn; idx += 64) {
@@ -312,14 +312,14 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
 #pragma unroll
               for (int a = 0; a < 8; a++) {
                 const int aa = a0 + a, al = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1);
-                const int v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+                const int v = __mul24(al, l), sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
                 const int d = sv - iclamp_(dcv + sc, 0, mx);
-                e[a] += (long long)d * d;
+                e[a] += __mul24(d, d);
               }
             }
 #pragma unroll
             for (int a = 0; a < 8; a++) {
-              const long long ea = wave_sum_i64(e[a]);
+              const long long ea = wave_sum_i64((long long)e[a]);
               const int aa = a0 + a;
               if (ea < best_sse) { best_sse = ea; best_a = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1); }
             }
@@ -423,7 +423,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
 }
 
 // ---- area snapshot (NONE-vs-SPLIT comparison), kept in the tile's HBM scratch; whole workgroup ----
-template <int BS, int NW> __device__ inline void area_copy_dev(const FrameDev *f, uint8_t *snap, int r, int c, int save) {
+template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDev *f, uint8_t *snap, int r, int c, int save) {
   constexpr int n = 4 << BS, n4 = 1 << BS, T = 64 * NW;
   uint16_t *srec = (uint16_t *)snap;                         // [3][n*n]
   int32_t *scoef = (int32_t *)(snap + 3 * n * n * 2);        // [3][n*n]
@@ -459,7 +459,7 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const FrameDev *f
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 16 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
-__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
+__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
@@ -468,7 +468,7 @@ __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const FrameD
 
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   static __device__ void run(Ctx<MAXN> &k, int r, int c) {
-    const FrameDev *f = k.f;
+    const LDS FrameDev *f = k.f;
     if (r >= f->mi_rows || c >= f->mi_cols) return;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
@@ -502,7 +502,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
   static __device__ void run(Ctx<MAXN> &k, int r, int c) {
-    const FrameDev *f = k.f;
+    const LDS FrameDev *f = k.f;
     if (r >= f->mi_rows || c >= f->mi_cols) return;
     set_decoded_wg<NW>(f, r, c, 1, 0);
     try_block<MAXN, 0, NW>(k, r, c);
@@ -510,7 +510,8 @@ template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
 };
 
 template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
-  return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2;
+  return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2 +
+         ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + ((sizeof(FrameDev) + 15) & ~(size_t)15);
 }
 
 template <int MAXBS, int NW>
@@ -520,14 +521,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   const int job = blockIdx.x;
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
-  const FrameDev *f = frames + tj.frame;
+  const FrameDev *gf = frames + tj.frame;
   Ctx<MAXN> k;
   constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
-  k.f = f; k.sh = (LDS SharedScratch<MAXN> *)smem;
+  constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
+  k.sh = (LDS SharedScratch<MAXN> *)smem;
   k.s = (LDS WaveScratch<MAXN> *)(smem + SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * WS_BYTES);
   LDS uint16_t *lsc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES);
+  LDS uint16_t *lcc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES);
+  LDS FrameDev *lf = (LDS FrameDev *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES + CC_BYTES);
+  // the frame descriptor, the scan tables and the coefficient slices of the rate table are staged in LDS once per tile
+  for (int i = threadIdx.x; i < (int)(sizeof(FrameDev) / 4); i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
-  k.cost = f->cost; k.ls = lsc;
+  load_coef_cost(&k.cc, lcc, gf->cost, MAXBS, threadIdx.x, 64 * NW);
+  k.f = lf; k.cost = gf->cost; k.ls = lsc;
+  WG_SYNC();
+  const LDS FrameDev *f = lf;
   k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);

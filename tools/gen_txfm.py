@@ -192,6 +192,7 @@ def selfcheck():
 
 # ---------------------------------------------------------------- C emission
 def emit_fn(name, ops, N, qual):
+    M = 'TX_MUL24' if N <= 16 else 'TX_MUL32'
     L = [f'{qual} void {name}(int32_t *x) {{']
     L.append('  int32_t t0, t1;')
     for op in ops:
@@ -204,30 +205,32 @@ def emit_fn(name, ops, N, qual):
             L.append('  ' + ' '.join(f'x[{i}] = -x[{i}];' for i in op[1]))
         elif op[0] == 'rot':
             _, p, q, (a, b, c, d) = op
-            L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = TX_R12({a} * t0 + ({b}) * t1); x[{q}] = TX_R12(({c}) * t0 + ({d}) * t1);')
+            L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = TX_R12({M}({a}, t0) + {M}({b}, t1)); x[{q}] = TX_R12({M}({c}, t0) + {M}({d}, t1));')
         elif op[0] == 'had':
             _, p, q, a, b, c, d = op
             def term(s, v): return ('-' if s < 0 else '+') + v
             L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = {term(a, "t0")} {term(b, "t1")}; x[{q}] = {term(c, "t0")} {term(d, "t1")};')
         elif op[0] == 'adst4':
             L.append('  { int32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];')
-            L.append('    int32_t s0 = 1321 * x0, s1 = 2482 * x0, s2 = 3344 * x1, s3 = 3803 * x2, s4 = 1321 * x2, s5 = 2482 * x3, s6 = 3803 * x3;')
-            L.append('    int32_t b7 = x0 - x2 + x3; s0 += s3; s1 -= s4; s3 = s2; s2 = 3344 * b7; s0 += s5; s1 -= s6;')
+            L.append('    int32_t s0 = TX_MUL24(1321, x0), s1 = TX_MUL24(2482, x0), s2 = TX_MUL24(3344, x1), s3 = TX_MUL24(3803, x2), s4 = TX_MUL24(1321, x2), s5 = TX_MUL24(2482, x3), s6 = TX_MUL24(3803, x3);')
+            L.append('    int32_t b7 = x0 - x2 + x3; s0 += s3; s1 -= s4; s3 = s2; s2 = TX_MUL24(3344, b7); s0 += s5; s1 -= s6;')
             L.append('    x[0] = TX_R12(s0 + s3); x[1] = TX_R12(s1 + s3); x[2] = TX_R12(s2); x[3] = TX_R12(s0 + s1 - s3); }')
         elif op[0] == 'fadst4':
             L.append('  { int32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];')
-            L.append('    x[0] = TX_R12(1321 * x0 + 2482 * x1 + 3344 * x2 + 3803 * x3);')
-            L.append('    x[1] = TX_R12(3344 * (x0 + x1 - x3));')
-            L.append('    x[2] = TX_R12(3803 * x0 - 1321 * x1 - 3344 * x2 + 2482 * x3);')
-            L.append('    x[3] = TX_R12(2482 * x0 - 3803 * x1 + 3344 * x2 - 1321 * x3); }')
+            L.append('    x[0] = TX_R12(TX_MUL24(1321, x0) + TX_MUL24(2482, x1) + TX_MUL24(3344, x2) + TX_MUL24(3803, x3));')
+            L.append('    x[1] = TX_R12(TX_MUL24(3344, x0 + x1 - x3));')
+            L.append('    x[2] = TX_R12(TX_MUL24(3803, x0) - TX_MUL24(1321, x1) - TX_MUL24(3344, x2) + TX_MUL24(2482, x3));')
+            L.append('    x[3] = TX_R12(TX_MUL24(2482, x0) - TX_MUL24(3803, x1) + TX_MUL24(3344, x2) - TX_MUL24(1321, x3)); }')
     L.append('}')
     return '\n'.join(L)
 
-def emit(path, qual, guard):
+def emit(path, qual, guard, mul_defs):
     out = [f'/* GENERATED by tools/gen_txfm.py -- do not edit.  AV1 1-D transforms (inverse: spec 7.13.2, normative;',
            '   forward: transposed network, encoder-side choice). In-place on int32 x[N]. */',
            f'#ifndef {guard}', f'#define {guard}', '#include <stdint.h>',
-           '#define TX_R12(v) (((v) + 2048) >> 12)']
+           '#define TX_R12(v) (((v) + 2048) >> 12)',
+           '/* N <= 16: operands stay far below 2^23 (|sample| <= 2^20 after the stage shifts, |constant| <= 4096), so the\n   product may use the 24-bit multiplier; the low 32 bits are identical to a full multiply. */',
+           mul_defs]
     for N in (4, 8, 16, 32, 64):
         ops = idct_ops(N)
         out.append(emit_fn(f'av1_idct{N}', ops, N, qual))
@@ -244,6 +247,6 @@ def emit(path, qual, guard):
 if __name__ == '__main__':
     selfcheck()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    emit(os.path.join(root, 'oracle', 'txfm_gen.h'), 'static inline', 'ORACLE_TXFM_GEN_H')
-    emit(os.path.join(root, 'cavif_rs_amd', 'csrc', 'txfm_gen.hip.h'), 'static __device__ __forceinline__', 'MI_TXFM_GEN_HIP_H')
+    emit(os.path.join(root, 'oracle', 'txfm_gen.h'), 'static inline', 'ORACLE_TXFM_GEN_H', '#define TX_MUL24(a, b) ((a) * (b))\n#define TX_MUL32(a, b) ((a) * (b))')
+    emit(os.path.join(root, 'cavif_rs_amd', 'csrc', 'txfm_gen.hip.h'), 'static __device__ __forceinline__', 'MI_TXFM_GEN_HIP_H', '#define TX_MUL24(a, b) __mul24((a), (b))\n#define TX_MUL32(a, b) ((a) * (b))')
     print('wrote oracle/txfm_gen.h, cavif_rs_amd/csrc/txfm_gen.hip.h')
