@@ -278,3 +278,69 @@ __global__ __launch_bounds__(256) void frontend_kernel(const uint8_t *pix, int w
   if (pa) pa[o] = fp.depth == 8 ? (uint16_t)A : (uint16_t)((A << 2) | (A >> 6));
   if (A != 255 && x < w && y < h && alpha_flag) *alpha_flag = 1;
 }
+
+// ---------------------------------------------------------------- dirty-alpha cleaner (ravif/src/dirtyalpha.rs:17-124)
+// Three 3x3 stencil passes over RGBA8 in HBM, window clamped to the image (loop9 convention):
+//   scan  : (256-a)-weighted mean colour of semi-transparent pixels that touch a fully transparent one  (:24-33)
+//   bleed : bleed_opaque_color (:45-76)      blur : blur_transparent_pixels (:79-100)
+// acc = { weights, sum_r, sum_g, sum_b } (u64).  weights == 0 means blurred_dirty_alpha returns None: both
+// rewrite passes then degenerate to copies, so no host round trip is needed to decide.
+__device__ __forceinline__ const uint8_t *rgba_at(const uint8_t *img, int w, int h, int x, int y) {
+  x = x < 0 ? 0 : (x >= w ? w - 1 : x); y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+  return img + ((size_t)y * w + x) * 4;
+}
+__device__ __forceinline__ void premultiplied_minmax_dev(int px, int alpha, int *lo, int *hi) {   // :115-124, `as u8` wraps
+  const int rounded = (px * alpha) / 255 * 255;
+  const int low = ((rounded + 16) / alpha) & 255, high = ((rounded + 239) / alpha) & 255;
+  *lo = imin_(low, px); *hi = imax_(high, px);
+}
+__global__ __launch_bounds__(256) void alpha_scan_kernel(const uint8_t *img, int w, int h, unsigned long long *acc) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  unsigned long long wt = 0, sr = 0, sg = 0, sb = 0;
+  if (x < w && y < h) {
+    const uint8_t *m = rgba_at(img, w, h, x, y);
+    if (m[3] != 255 && m[3] != 0) {
+      int any0 = 0;
+      for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) any0 |= rgba_at(img, w, h, x + dx, y + dy)[3] == 0;
+      if (any0) { wt = 256u - m[3]; sr = (unsigned long long)m[0] * wt; sg = (unsigned long long)m[1] * wt; sb = (unsigned long long)m[2] * wt; }
+    }
+  }
+  // per-lane values are < 2^16: reduce in 32 bits per wave, then one 64-bit atomic per wave and component
+  const int rw = wave_sum_i32((int)wt), rr = wave_sum_i32((int)sr), rg = wave_sum_i32((int)sg), rb = wave_sum_i32((int)sb);
+  if (LANE == 0 && rw) { atomicAdd(acc + 0, (unsigned long long)rw); atomicAdd(acc + 1, (unsigned long long)rr); atomicAdd(acc + 2, (unsigned long long)rg); atomicAdd(acc + 3, (unsigned long long)rb); }
+}
+__global__ __launch_bounds__(256) void alpha_rewrite_kernel(const uint8_t *src, uint8_t *dst, int w, int h, const unsigned long long *acc, int pass) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const uint8_t *m = rgba_at(src, w, h, x, y);
+  uint8_t *o = dst + ((size_t)y * w + x) * 4;
+  const unsigned long long weights = acc[0];
+  int r = m[0], g = m[1], b = m[2], a = m[3];
+  if (weights != 0 && a != 255) {
+    int avg[3]; bool use_bg = false;
+    if (pass == 0) {                               // bleed_opaque_color
+      unsigned int wsum = 0, s[3] = { 0, 0, 0 };
+      for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+        const uint8_t *c = rgba_at(src, w, h, x + dx, y + dy);
+        if (c[3] == 0) continue;
+        const unsigned int wt = 256u - c[3]; wsum += wt; s[0] += c[0] * wt; s[1] += c[1] * wt; s[2] += c[2] * wt;
+      }
+      if (wsum == 0) { use_bg = true; r = (int)(acc[1] / weights) & 255; g = (int)(acc[2] / weights) & 255; b = (int)(acc[3] / weights) & 255; a = 0; }
+      else { avg[0] = (int)(s[0] / wsum) & 255; avg[1] = (int)(s[1] / wsum) & 255; avg[2] = (int)(s[2] / wsum) & 255; }
+    } else {                                       // blur_transparent_pixels
+      int s[3] = { 0, 0, 0 };
+      for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) { const uint8_t *c = rgba_at(src, w, h, x + dx, y + dy); s[0] += c[0]; s[1] += c[1]; s[2] += c[2]; }
+      avg[0] = s[0] / 9; avg[1] = s[1] / 9; avg[2] = s[2] / 9;
+    }
+    if (!use_bg) {
+      if (a == 0) { r = avg[0]; g = avg[1]; b = avg[2]; }
+      else {
+        int lo, hi;
+        premultiplied_minmax_dev(m[0], a, &lo, &hi); r = imin_(imax_(avg[0], lo), hi);
+        premultiplied_minmax_dev(m[1], a, &lo, &hi); g = imin_(imax_(avg[1], lo), hi);
+        premultiplied_minmax_dev(m[2], a, &lo, &hi); b = imin_(imax_(avg[2], lo), hi);
+      }
+    }
+  }
+  o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; o[3] = (uint8_t)a;
+}

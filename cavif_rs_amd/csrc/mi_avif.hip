@@ -158,6 +158,7 @@ struct mi_batch {
   hipStream_t stream = nullptr;
   uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // n * w*h*channels
   int *d_alpha_flags = nullptr; std::vector<int> alpha_flags;
+  uint8_t *d_clean = nullptr, *d_clean_tmp = nullptr; unsigned long long *d_alpha_acc = nullptr;   // dirty-alpha cleaner (RGBA, UnassociatedClean)
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
   uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
@@ -266,6 +267,9 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   b->pixel_bytes = (size_t)n_images * w * h * channels;
   bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess &&
             hipMalloc(&b->d_alpha_flags, sizeof(int) * n_images) == hipSuccess;
+  if (ok && channels == 4 && e->alpha_mode == 1)
+    ok = hipMalloc(&b->d_clean, b->pixel_bytes) == hipSuccess && hipMalloc(&b->d_clean_tmp, (size_t)w * h * 4) == hipSuccess &&
+         hipMalloc(&b->d_alpha_acc, sizeof(unsigned long long) * 4 * n_images) == hipSuccess;
   for (int i = 0; i < 8 && ok; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   if (ok) ok = batch_alloc(b) == MI_OK;
   if (!ok) { mi_batch_destroy(b); return nullptr; }
@@ -318,11 +322,24 @@ int mi_batch_encode_async(mi_batch *b) {
   HIP_OK(hipMemsetAsync(b->d_alpha_flags, 0, sizeof(int) * b->n, s));
   const FrontConsts fc = front_consts(b->depth);
   FrontParams fp{ fc.sy_r, fc.sy_g, fc.sy_b, fc.scale, fc.kcb, fc.kcr, fc.shift, b->depth, b->enc.color_model, b->channels };
+  const uint8_t *front_src = b->d_pixels;
+  if (b->d_clean) {                                            // convert_alpha_8bit: UnassociatedClean (av1encoder.rs:277-281)
+    HIP_OK(hipMemsetAsync(b->d_alpha_acc, 0, sizeof(unsigned long long) * 4 * b->n, s));
+    const dim3 g((b->w + 255) / 256, b->h), blk(256);
+    for (int i = 0; i < b->n; i++) {
+      const uint8_t *in = b->d_pixels + (size_t)i * b->w * b->h * 4; uint8_t *outp = b->d_clean + (size_t)i * b->w * b->h * 4;
+      hipLaunchKernelGGL(alpha_scan_kernel, g, blk, 0, s, in, (int)b->w, (int)b->h, b->d_alpha_acc + 4 * i);
+      hipLaunchKernelGGL(alpha_rewrite_kernel, g, blk, 0, s, in, b->d_clean_tmp, (int)b->w, (int)b->h, b->d_alpha_acc + 4 * i, 0);
+      hipLaunchKernelGGL(alpha_rewrite_kernel, g, blk, 0, s, (const uint8_t *)b->d_clean_tmp, outp, (int)b->w, (int)b->h, b->d_alpha_acc + 4 * i, 1);
+    }
+    HIP_OK(hipGetLastError());
+    front_src = b->d_clean;
+  }
   for (int i = 0; i < b->n; i++) {
     FramePlan &p = b->frames[i];
     uint16_t *alpha_stage = b->channels == 4 ? p.dev.fin[0] : nullptr;      // fin[0] is free until CDEF runs
     hipLaunchKernelGGL(frontend_kernel, dim3((p.pw + 255) / 256, p.ph), dim3(256), 0, s,
-                       b->d_pixels + (size_t)i * b->w * b->h * b->channels, (int)b->w, (int)b->h, (int)b->w, fp,
+                       front_src + (size_t)i * b->w * b->h * b->channels, (int)b->w, (int)b->h, (int)b->w, fp,
                        p.dev.src[0], p.dev.src[1], p.dev.src[2], alpha_stage, p.pw, p.ph, b->d_alpha_flags + i);
   }
   HIP_OK(hipGetLastError());
@@ -466,6 +483,9 @@ void mi_batch_destroy(mi_batch *b) {
   batch_free_device(b);
   if (b->d_pixels) hipFree(b->d_pixels);
   if (b->d_alpha_flags) hipFree(b->d_alpha_flags);
+  if (b->d_clean) hipFree(b->d_clean);
+  if (b->d_clean_tmp) hipFree(b->d_clean_tmp);
+  if (b->d_alpha_acc) hipFree(b->d_alpha_acc);
   for (int i = 0; i < 8; i++) if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;

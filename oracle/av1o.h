@@ -80,6 +80,9 @@ size_t av1o_avif_container(const uint8_t *color, size_t color_len, const uint8_t
                            int w, int h, int depth, int mono_color, int cp, int tc, int mc, int full_range,
                            int premultiplied, uint8_t **out);
 void av1o_free(void *p);
+/* ravif/src/dirtyalpha.rs */
+void av1o_premultiplied_minmax(uint8_t px, uint8_t alpha, uint8_t *lo, uint8_t *hi);
+int  av1o_blurred_dirty_alpha(const uint8_t *rgba, int w, int h, int stride_px, uint8_t *out /* w*h*4 */);
 
 #ifdef __cplusplus
 }

@@ -156,6 +156,11 @@ static int encode_planes(const RavifOracleEncoder *e, int w, int h, uint16_t *pl
 
 static int encode_common(const RavifOracleEncoder *e, const uint8_t *px, int bpp, int w, int h, int stride_px, RavifOracleImage *out) {
   if (!e || !px || w < 1 || h < 1) return 4;
+  uint8_t *cleaned = NULL;
+  if (bpp == 4 && e->alpha_mode == 1) {                       /* convert_alpha_8bit: UnassociatedClean -> blurred_dirty_alpha (:277-281) */
+    cleaned = (uint8_t *)malloc((size_t)w * h * 4);
+    if (av1o_blurred_dirty_alpha(px, w, h, stride_px, cleaned)) { px = cleaned; stride_px = w; } else { free(cleaned); cleaned = NULL; }
+  }
   const int depth = e->depth == 8 ? 8 : 10;                   /* BitDepth::Auto == Ten (:266,:339) */
   const size_t n = (size_t)w * h;
   uint16_t *pl[3]; for (int i = 0; i < 3; i++) pl[i] = (uint16_t *)malloc(n * 2);
@@ -175,6 +180,7 @@ static int encode_common(const RavifOracleEncoder *e, const uint8_t *px, int bpp
   int st = encode_planes(e, w, h, pl, al, depth, e->color_model == 1 ? 0 : 6, out);
   for (int i = 0; i < 3; i++) free(pl[i]);
   free(al);
+  free(cleaned);
   return st;
 }
 int ravif_oracle_encode_rgba(const RavifOracleEncoder *e, const uint8_t *rgba, int w, int h, int stride_px, RavifOracleImage *out) { return encode_common(e, rgba, 4, w, h, stride_px, out); }

@@ -27,3 +27,10 @@ def rgba_opaque(w=129, h=101):
     """ravif/src/lib.rs:73-79 encode8_opaque input: (255, 100+x, y, 255) with u8 wrap."""
     y, x = np.mgrid[0:h, 0:w]
     return np.stack([np.full_like(x, 255), (100 + x) % 256, y % 256, np.full_like(x, 255)], -1).astype(np.uint8)
+
+
+def rgba_noisy(w=256, h=200):
+    """ravif/src/lib.rs:123-125 encode8_cleans_alpha input."""
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.clip(((x + y) & 0x7F).astype(int) - 100, 0, 255)          # (u8 & 0x7F).saturating_sub(100)
+    return np.stack([(((x // 5 + y) & 0xF) << 4) & 255, (7 * x + y // 2) & 255, (x * y) & 3, a], -1).astype(np.uint8)

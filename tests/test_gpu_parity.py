@@ -51,6 +51,24 @@ def test_ravif_entry_points(oracle, avifdec):
     assert d['alpha'] is not None and d['depth'] == 8
 
 
+def test_clean_alpha_matches_oracle(oracle):
+    """UnassociatedClean (blurred_dirty_alpha on the GPU) == oracle; reference windows of lib.rs:121-147 hold."""
+    import cavif_rs_amd as m
+    from tests.helpers.images import rgba_noisy
+    img = rgba_noisy()
+    e = m.Encoder().with_quality(66).with_alpha_quality(88).with_speed(6).with_num_threads(1)
+    clean = e.with_alpha_color_mode('clean').encode_rgba(img)
+    dirty = e.with_alpha_color_mode('dirty').encode_rgba(img)
+    rc, ccol, calpha = oracle.ravif_encode(img, quality=66, alpha_quality=88, speed=6, alpha_mode=1, threads=1)
+    rd, dcol, dalpha = oracle.ravif_encode(img, quality=66, alpha_quality=88, speed=6, alpha_mode=0, threads=1)
+    assert clean.avif_file == rc and dirty.avif_file == rd
+    assert clean.alpha_byte_size == dirty.alpha_byte_size and 200 < clean.alpha_byte_size < 1000
+    assert 2000 < clean.color_byte_size < 6000 and clean.color_byte_size < dirty.color_byte_size / 2
+    # an image whose alpha is strictly {0, 255} is not touched by the cleaner (SURVEY appendix B-15)
+    hard = img.copy(); hard[:, :, 3] = np.where(hard[:, :, 3] > 10, 255, 0)
+    assert e.with_alpha_color_mode('clean').encode_rgba(hard).avif_file == e.with_alpha_color_mode('dirty').encode_rgba(hard).avif_file
+
+
 def test_rgb_identity_model(oracle):
     import cavif_rs_amd as m
     from PIL import Image

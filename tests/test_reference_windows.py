@@ -37,3 +37,27 @@ def test_stdio_ftyp(oracle):
     from PIL import Image
     im = Image.open(io.BytesIO(data)); im.load()
     assert im.size == (128, 85)
+
+
+def test_preminmax(oracle):
+    """ravif/src/dirtyalpha.rs:126-135 verbatim known answers."""
+    import ctypes as C
+    L = oracle.lib()
+    L.av1o_premultiplied_minmax.argtypes = [C.c_uint8, C.c_uint8, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    for (px, a), want in {(100, 255): (100, 100), (100, 10): (78, 100), (100, 2): (8, 119), (100, 1): (16, 239), (255, 1): (15, 255)}.items():
+        lo, hi = C.c_uint8(), C.c_uint8()
+        L.av1o_premultiplied_minmax(px, a, C.byref(lo), C.byref(hi))
+        assert (lo.value, hi.value) == want
+    assert 100 * 10 // 255 == 78 * 10 // 255
+
+
+def test_encode8_cleans_alpha(oracle):
+    """lib.rs:121-147: Clean vs Dirty on a noisy RGBA image, q66 / alpha q88, speed 6, 1 thread."""
+    from tests.helpers.images import rgba_noisy
+    img = rgba_noisy()
+    _, dcol, dalpha = oracle.ravif_encode(img, quality=66, alpha_quality=88, speed=6, alpha_mode=0, threads=1)
+    _, ccol, calpha = oracle.ravif_encode(img, quality=66, alpha_quality=88, speed=6, alpha_mode=1, threads=1)
+    assert calpha == dalpha
+    assert 200 < calpha < 1000
+    assert 2000 < ccol < 6000
+    assert ccol < dcol / 2
