@@ -133,3 +133,35 @@ def test_full_size_1080p_equals_oracle(oracle):
     got = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10).encode_rgb(img)
     ref, _, _ = oracle.ravif_encode(img, quality=80, speed=4, depth=10)
     assert got.avif_file == ref
+
+
+def test_config3_shape_rgba_with_alpha(oracle, avifdec):
+    """BASELINE config 3 shape at reduced size: RGBA with radial alpha ramp, speed 4 q80 (alpha q90 as the CLI derives), clean alpha."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(512, 384, index=7, alpha=True)
+    e = m.Encoder().with_quality(80).with_alpha_quality(90).with_speed(4)
+    got = e.encode_rgba(img)
+    ref, col, al = oracle.ravif_encode(img, quality=80, alpha_quality=90, speed=4, depth=0, alpha_mode=1)
+    assert got.avif_file == ref and got.alpha_byte_size == al and al > 0
+    d = avifdec.decode(got.avif_file)
+    assert d['alpha'] is not None and d['depth'] == 10 and (d['width'], d['height']) == (512, 384)
+
+
+def test_async_pipeline_two_batches(oracle):
+    """encode_async / wait on two resident batches driven alternately (bench.py's loop) gives the same bytes as the blocking call."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    e = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10)
+    imgs = [synth_image(256, 192, index=20 + i) for i in range(3)]
+    slots = [m.BatchEncoder(e, len(imgs), 256, 192, 3) for _ in range(2)]
+    for b in slots:
+        for i, im in enumerate(imgs):
+            b.upload(i, im)
+    ref = [oracle.ravif_encode(im, quality=80, speed=4, depth=10)[0] for im in imgs]
+    slots[0].encode_async(); slots[1].encode_async()
+    slots[0].wait(); slots[0].encode_async(); slots[1].wait(); slots[0].wait()
+    for b in slots:
+        for i in range(len(imgs)):
+            assert b.get(i).avif_file == ref[i]
+        b.close()
