@@ -100,60 +100,67 @@ __device__ __forceinline__ int constrain_dev(int diff, int thr, int damping) {
   const int v = iclamp_(thr - (mag >> adj), 0, mag);
   return diff < 0 ? -v : v;
 }
-// one pixel of the CDEF filter (spec 7.15.3); in = deblocked plane
-__device__ __forceinline__ int cdef_pixel(const FrameDev *f, const uint16_t *in, int py, int px_, int pri, int sec, int damping, int dir) {
-  const int cs = f->bd - 8, st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
-  const int x = in[(size_t)py * st + px_];
-  int sum = 0, mx = x, mn = x;
-  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+// The 12 tap samples of one pixel for direction `dir` (spec 7.15.3 / cdef_get_at): order k=0,1 x sign -,+ x
+// { primary(dir), secondary(dir-2), secondary(dir+2) }.  Samples outside the frame are flagged invalid.
+__device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t *in, int py, int px_, int dir, int *tap, unsigned *valid) {
+  const int st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
+  unsigned v = 0; int n = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
 #pragma unroll
     for (int sg = -1; sg <= 1; sg += 2) {
-      int yy = py + sg * cdef_dir_off(dir, k, 0), xx = px_ + sg * cdef_dir_off(dir, k, 1);
-      if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) {
-        const int p = in[(size_t)yy * st + xx];
-        sum += (k == 0 ? pt0 : pt1) * constrain_dev(p - x, pri, damping);
-        mx = imax_(mx, p); mn = imin_(mn, p);
-      }
 #pragma unroll
-      for (int doff = -2; doff <= 2; doff += 4) {
-        const int d2 = (dir + doff) & 7;
-        yy = py + sg * cdef_dir_off(d2, k, 0); xx = px_ + sg * cdef_dir_off(d2, k, 1);
-        if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) {
-          const int s = in[(size_t)yy * st + xx];
-          sum += (k == 0 ? 2 : 1) * constrain_dev(s - x, sec, damping);
-          mx = imax_(mx, s); mn = imin_(mn, s);
-        }
+      for (int q = 0; q < 3; q++) {
+        const int d2 = q == 0 ? dir : ((dir + (q == 1 ? -2 : 2)) & 7);
+        const int yy = py + sg * cdef_dir_off(d2, k, 0), xx = px_ + sg * cdef_dir_off(d2, k, 1);
+        int val = 0;
+        if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) { val = in[(size_t)yy * st + xx]; v |= 1u << n; }
+        tap[n++] = val;
       }
+    }
+  }
+  *valid = v;
+}
+// filter value of one pixel from its preloaded taps
+__device__ __forceinline__ int cdef_apply_taps(int x, const int *tap, unsigned valid, int pri, int sec, int damping, int cs) {
+  int sum = 0, mx = x, mn = x;
+  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+#pragma unroll
+  for (int n = 0; n < 12; n++) {
+    if (valid & (1u << n)) {
+      const int k = n / 6, q = n % 3, t = tap[n];
+      const int wgt = q == 0 ? (k == 0 ? pt0 : pt1) : (k == 0 ? 2 : 1);
+      sum += wgt * constrain_dev(t - x, q == 0 ? pri : sec, damping);
+      mx = imax_(mx, t); mn = imin_(mn, t);
     }
   }
   return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx);
 }
-// direction search for one 8x8 luma block, executed by lanes 0..7 (one direction each); returns dir and var to all lanes
-__device__ inline int cdef_direction_dev(const uint16_t *img, int stride, int bd, int *var_out) {
+// direction search for one 8x8 luma block by its 64 lanes (one pixel each): the 8 x 15 partial sums are
+// accumulated with LDS atomics, lanes 0..7 turn them into the 8 costs (spec 7.15.2)
+#define LDS_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ inline int cdef_direction_dev(const uint16_t *img, int stride, int bd, LDS int *part /* [8][16] */, int *var_out) {
   const int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
-  const int d = LANE & 7;
+  const int lane = LANE, i = lane >> 3, j = lane & 7;
+  for (int q = lane; q < 128; q += 64) part[q] = 0;
+  WAVE_SYNC();
+  const int x = (img[(size_t)i * stride + j] >> (bd - 8)) - 128;
+  LDS_ADD(&part[0 * 16 + i + j], x); LDS_ADD(&part[1 * 16 + i + j / 2], x); LDS_ADD(&part[2 * 16 + i], x); LDS_ADD(&part[3 * 16 + 3 + i - j / 2], x);
+  LDS_ADD(&part[4 * 16 + 7 + i - j], x); LDS_ADD(&part[5 * 16 + 3 - i / 2 + j], x); LDS_ADD(&part[6 * 16 + j], x); LDS_ADD(&part[7 * 16 + i / 2 + j], x);
+  WAVE_SYNC();
+  const int d = lane & 7;
   int partial[15];
 #pragma unroll
-  for (int i = 0; i < 15; i++) partial[i] = 0;
-  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) {
-    const int x = (img[(size_t)i * stride + j] >> (bd - 8)) - 128;
-    int idx;
-    switch (d) { case 0: idx = i + j; break; case 1: idx = i + j / 2; break; case 2: idx = i; break; case 3: idx = 3 + i - j / 2; break;
-                 case 4: idx = 7 + i - j; break; case 5: idx = 3 - i / 2 + j; break; case 6: idx = j; break; default: idx = i / 2 + j; break; }
-#pragma unroll
-    for (int q = 0; q < 15; q++) if (q == idx) partial[q] += x;
-  }
+  for (int q = 0; q < 15; q++) partial[q] = part[d * 16 + q];
   int cost = 0;
-  if (d == 2 || d == 6) { for (int i = 0; i < 8; i++) cost += partial[i] * partial[i]; cost *= div_table[8]; }
+  if (d == 2 || d == 6) { for (int q = 0; q < 8; q++) cost += partial[q] * partial[q]; cost *= div_table[8]; }
   else if (d == 0 || d == 4) {
-    for (int i = 0; i < 7; i++) cost += (partial[i] * partial[i] + partial[14 - i] * partial[14 - i]) * div_table[i + 1];
+    for (int q = 0; q < 7; q++) cost += (partial[q] * partial[q] + partial[14 - q] * partial[14 - q]) * div_table[q + 1];
     cost += partial[7] * partial[7] * div_table[8];
   } else {
-    for (int j = 0; j < 5; j++) cost += partial[3 + j] * partial[3 + j];
+    for (int q = 0; q < 5; q++) cost += partial[3 + q] * partial[3 + q];
     cost *= div_table[8];
-    for (int j = 0; j < 3; j++) cost += (partial[j] * partial[j] + partial[10 - j] * partial[10 - j]) * div_table[2 * j + 2];
+    for (int q = 0; q < 3; q++) cost += (partial[q] * partial[q] + partial[10 - q] * partial[10 - q]) * div_table[2 * q + 2];
   }
   int best = 0, dir = 0, costs[8];
 #pragma unroll
@@ -166,24 +173,29 @@ __device__ inline int cdef_direction_dev(const uint16_t *img, int stride, int bd
   *var_out = (best - opp) >> 10;
   return dir;
 }
-__device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int idx, int var, int ydir, int *pri, int *sec, int *damping, int *dir) {
+__device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int idx, int var, int *pri, int *sec, int *damping) {
   const int cs = f->bd - 8;
   const int st = plane == 0 ? f->cdef_y[idx] : f->cdef_uv[idx];
   int p = (st >> 2) << cs, s = st & 3; if (s == 3) s = 4; s <<= cs;
-  *dir = p == 0 ? 0 : ydir; *damping = f->cdef_damping + cs - (plane > 0);
+  *damping = f->cdef_damping + cs - (plane > 0);
   if (plane == 0) { const int vs = (var >> 6) ? imin_(31 - __clz(var >> 6), 12) : 0; p = var ? (p * (4 + vs) + 8) >> 4 : 0; }
   *pri = p; *sec = s;
 }
 
 // grid.x = sb index, grid.y = frame; 256 threads = 4 waves, wave w handles 8x8 blocks w, w+4, ...
+// Every strength index >= 1 of the fixed list has a non-zero primary strength, so the filter direction of a block is
+// its luma direction for all candidates and the 12 tap samples per pixel and plane are loaded once.
 __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int write_final) {
   const FrameDev *f = frames + blockIdx.y;
   const int sbi = blockIdx.x;
   if (sbi >= f->sb_rows * f->sb_cols) return;
   __shared__ unsigned long long costs[8];
   __shared__ int any_blocks, best_idx;
+  __shared__ int part_s[4][128];
+  __shared__ int dirvar[64][2];
   const int wave = threadIdx.x >> 6, lane = LANE;
-  const int sr = sbi / f->sb_cols, sc = sbi % f->sb_cols, ms = f->mi_stride;
+  LDS int *part = (LDS int *)part_s[wave];
+  const int sr = sbi / f->sb_cols, sc = sbi % f->sb_cols, ms = f->mi_stride, cs = f->bd - 8;
   if (threadIdx.x < 8) costs[threadIdx.x] = 0;
   if (threadIdx.x == 0) { any_blocks = 0; best_idx = 0; }
   __syncthreads();
@@ -194,19 +206,22 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
       if (r >= f->mi_rows || c >= f->mi_cols) continue;
       const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
       if (sk) continue;
-      int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, &var);
+      int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, part, &var);
+      if (lane == 0) { dirvar[b][0] = ydir; dirvar[b][1] = var; }
       long long cst[8];
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) cst[idx] = 0;
       for (int p = 0; p < f->np; p++) {
         const int y = r * 4 + py_l, x = c * 4 + px_l;
         const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
+        int tap[12]; unsigned valid;
+        cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid);
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
-          int pri, sec, damping, dir; cdef_strengths(f, p, idx, var, ydir, &pri, &sec, &damping, &dir);
-          const int v = (pri == 0 && sec == 0) ? un : cdef_pixel(f, f->rec[p], y, x, pri, sec, damping, dir);
+          int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
+          const int v = (pri == 0 && sec == 0) ? un : cdef_apply_taps(un, tap, valid, pri, sec, damping, cs);
           const int d = v - sv;
-          const long long sse = wave_sum_i64((long long)d * d);
+          const long long sse = wave_sum_i64((long long)__mul24(d, d));
           cst[idx] += (sse * f->wq[p]) >> 5;
         }
       }
@@ -231,15 +246,14 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
     const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
     if (r >= f->mi_rows || c >= f->mi_cols) continue;
     const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
-    int var = 0, ydir = 0;
-    const int filt = best >= 0 && !sk;
-    if (filt) ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, &var);
+    const int filt = best > 0 && !sk;                    // index 0 of the list is (0, 0): nothing to filter
+    const int ydir = filt ? dirvar[b][0] : 0, var = filt ? dirvar[b][1] : 0;
     for (int p = 0; p < f->np; p++) {
       const int y = r * 4 + py_l, x = c * 4 + px_l;
       int v = f->rec[p][(size_t)y * f->stride + x];
       if (filt) {
-        int pri, sec, damping, dir; cdef_strengths(f, p, best, var, ydir, &pri, &sec, &damping, &dir);
-        if (pri || sec) v = cdef_pixel(f, f->rec[p], y, x, pri, sec, damping, dir);
+        int pri, sec, damping; cdef_strengths(f, p, best, var, &pri, &sec, &damping);
+        if (pri || sec) { int tap[12]; unsigned valid; cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid); v = cdef_apply_taps(v, tap, valid, pri, sec, damping, cs); }
       }
       f->fin[p][(size_t)y * f->stride + x] = (uint16_t)v;
     }
