@@ -143,8 +143,11 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
   if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
 }
 
+// `budget`: the caller only needs to know whether the block's cost stays below it (split trials: cost of the
+// undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
+// reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
 template <int MAXN, int BS, int NW>
-__device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
+__device__ long long try_block(Ctx<MAXN> &k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
   const LDS FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -258,6 +261,7 @@ __device__ long long try_block(Ctx<MAXN> &k, int r, int c) {
   WG_SYNC();
   PH(2);
   if (f->dbg == 5) return 0;
+  if (best_j >= budget) return best_j;                      // wave-uniform: every wave reads the same LDS values
   const int best_mode = SH->lm_mode, best_delta = SH->lm_delta;
   long long total_j = best_j; int any_coef = SH->lm_eob > 0;
 
@@ -486,7 +490,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
         for (int q = 0; q < 4 && j_split < j_none && f->dbg != 7; q++) {
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-          j_split += try_block<MAXN, BS - 1, NW>(k, rr, cc);
+          j_split += try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split);
           if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
         }
         if (j_split < j_none && f->dbg != 7 && f->dbg != 8 && !(f->dbg == 10 && BS == 1)) do_split = 1;
