@@ -278,8 +278,11 @@ class BoxWriter {
 inline std::vector<uint8_t> avif_container(const uint8_t *color, size_t color_len, const uint8_t *alpha, size_t alpha_len,
                                            uint32_t w, uint32_t h, int depth, int matrix, bool premultiplied,
                                            const uint8_t *exif, size_t exif_len) {
-  (void)exif; (void)exif_len;   // Exif item: future work (ravif with_exif :213)
+  // Exif (ravif with_exif :208-218 -> avif-serialize set_exif :470-472): an 'Exif' item after the image items, linked to the
+  // colour item by a 'cdsc' reference; its payload is the HEIF ExifDataBlock = u32 exif_tiff_header_offset (0) + the bytes given.
   const bool has_alpha = alpha && alpha_len;
+  const bool has_exif = exif && exif_len;
+  const int n_img = 1 + (int)has_alpha, n_items = n_img + (int)has_exif, exif_id = n_img + 1;
   BoxWriter b;
   auto av1c = [&](int profile, bool mono) {
     const size_t a = b.begin("av1C");
@@ -290,17 +293,21 @@ inline std::vector<uint8_t> avif_container(const uint8_t *color, size_t color_le
   const size_t meta = b.begin_full("meta");
   a = b.begin_full("hdlr"); b.u32(0); b.str4("pict"); b.u32(0); b.u32(0); b.u32(0); b.u8(0); b.end(a);
   a = b.begin_full("pitm"); b.u16(1); b.end(a);
-  a = b.begin_full("iloc"); b.u8(0x44); b.u8(0); b.u16(has_alpha ? 2 : 1);
-  size_t off_pos[2] = { 0, 0 };
-  for (int i = 0; i < 1 + (int)has_alpha; i++) { b.u16(i + 1); b.u16(0); b.u16(1); off_pos[i] = b.out.size(); b.u32(0); b.u32((uint32_t)(i ? alpha_len : color_len)); }
+  a = b.begin_full("iloc"); b.u8(0x44); b.u8(0); b.u16(n_items);
+  size_t off_pos[3] = { 0, 0, 0 };
+  for (int i = 0; i < n_img; i++) { b.u16(i + 1); b.u16(0); b.u16(1); off_pos[i] = b.out.size(); b.u32(0); b.u32((uint32_t)(i ? alpha_len : color_len)); }
+  if (has_exif) { b.u16(exif_id); b.u16(0); b.u16(1); off_pos[2] = b.out.size(); b.u32(0); b.u32((uint32_t)(exif_len + 4)); }
   b.end(a);
-  a = b.begin_full("iinf"); b.u16(has_alpha ? 2 : 1);
-  for (int i = 0; i < 1 + (int)has_alpha; i++) { const size_t e = b.begin_full("infe", 2); b.u16(i + 1); b.u16(0); b.str4("av01"); b.u8(0); b.end(e); }
+  a = b.begin_full("iinf"); b.u16(n_items);
+  for (int i = 0; i < n_img; i++) { const size_t e = b.begin_full("infe", 2); b.u16(i + 1); b.u16(0); b.str4("av01"); b.u8(0); b.end(e); }
+  if (has_exif) { const size_t e = b.begin_full("infe", 2); b.u16(exif_id); b.u16(0); b.str4("Exif"); b.u8(0); b.end(e); }
   b.end(a);
-  if (has_alpha) {
+  if (has_alpha || has_exif) {
     a = b.begin_full("iref");
-    size_t e = b.begin("auxl"); b.u16(2); b.u16(1); b.u16(1); b.end(e);
-    if (premultiplied) { e = b.begin("prem"); b.u16(1); b.u16(1); b.u16(2); b.end(e); }
+    size_t e;
+    if (has_alpha) { e = b.begin("auxl"); b.u16(2); b.u16(1); b.u16(1); b.end(e); }
+    if (has_alpha && premultiplied) { e = b.begin("prem"); b.u16(1); b.u16(1); b.u16(2); b.end(e); }
+    if (has_exif) { e = b.begin("cdsc"); b.u16(exif_id); b.u16(1); b.u16(1); b.end(e); }
     b.end(a);
   }
   a = b.begin("iprp");
@@ -315,7 +322,7 @@ inline std::vector<uint8_t> avif_container(const uint8_t *color, size_t color_le
     e = b.begin_full("pixi"); b.u8(1); b.u8(depth); b.end(e);
   }
   b.end(ipco);
-  e = b.begin_full("ipma"); b.u32(has_alpha ? 2 : 1);
+  e = b.begin_full("ipma"); b.u32(n_img);
   b.u16(1); b.u8(4); b.u8(1); b.u8(2); b.u8(0x80 | 3); b.u8(4);
   if (has_alpha) { b.u16(2); b.u8(4); b.u8(1); b.u8(7); b.u8(0x80 | 5); b.u8(6); }
   b.end(e);
@@ -324,6 +331,7 @@ inline std::vector<uint8_t> avif_container(const uint8_t *color, size_t color_le
   a = b.begin("mdat");
   b.patch32(off_pos[0], (uint32_t)b.out.size()); b.out.insert(b.out.end(), color, color + color_len);
   if (has_alpha) { b.patch32(off_pos[1], (uint32_t)b.out.size()); b.out.insert(b.out.end(), alpha, alpha + alpha_len); }
+  if (has_exif) { b.patch32(off_pos[2], (uint32_t)b.out.size()); b.u32(0); b.out.insert(b.out.end(), exif, exif + exif_len); }
   b.end(a);
   return std::move(b.out);
 }

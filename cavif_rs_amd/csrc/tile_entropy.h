@@ -10,20 +10,20 @@
 
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
-  unsigned long long low; uint32_t rng; int cnt; int overflow;
+  uint32_t low; uint32_t rng; int cnt; int overflow;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
 };
 
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
   e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->overflow = 0;
 }
 __device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) { if (e->offs < e->cap) { if (LANE == 0) e->pre[e->offs] = v; } else e->overflow = 1; e->offs++; }
-__device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, unsigned long long low, uint32_t rng) {
+__device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, uint32_t rng) {
   int c = e->cnt;
   const int d = 16 - (32 - __clz(rng));
   int s = c + d;
   if (s >= 0) {
     c += 16;
-    unsigned long long m = (1ULL << c) - 1;
+    uint32_t m = (1u << c) - 1;
     if (s >= 8) { re_put16(e, (uint16_t)(low >> c)); low &= m; c -= 8; m >>= 8; }
     re_put16(e, (uint16_t)(low >> c));
     s = c + d - 24;
@@ -32,7 +32,7 @@ __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, unsigned long l
   e->low = low << d; e->rng = rng << d; e->cnt = s;
 }
 __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
-  unsigned long long l = e->low; uint32_t r = e->rng;
+  uint32_t l = e->low; uint32_t r = e->rng;
   const int N = nsyms - 1;
   if (fl < 32768) {
     const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4 * (uint32_t)(N - (s - 1));

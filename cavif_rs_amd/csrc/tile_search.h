@@ -16,6 +16,9 @@
 #include "dev_txfm.h"
 #include "dev_rate.h"
 
+#ifndef MI_K1_INLINE
+#define MI_K1_INLINE
+#endif
 #ifndef MI_K1_WG_PER_CU
 #define MI_K1_WG_PER_CU 4
 #endif
@@ -147,7 +150,7 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
 // undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
 // reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
 template <int MAXN, int BS, int NW>
-__device__ long long try_block(Ctx<MAXN> &k, int r, int c, long long budget = J_INF) {
+__device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
   const LDS FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -470,27 +473,38 @@ __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS Fr
   return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
+// `known_j` >= 0: the parent's split trial has just evaluated this block undivided, every earlier sibling kept
+// PARTITION_NONE, and the frame buffers still hold that result -- try_block() would reproduce it bit for bit, so
+// its cost is taken from the trial (oracle/av1o_search.c rd_partition does the same).  Returns 1 when split.
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
-  static __device__ void run(Ctx<MAXN> &k, int r, int c) {
+  static __device__ MI_K1_INLINE int run(Ctx<MAXN> &k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f;
-    if (r >= f->mi_rows || c >= f->mi_cols) return;
+    if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
     const int must_split = px > f->part_max || !has_rows || !has_cols;
     const int can_split = px > f->part_min || must_split;
-    set_decoded_wg<NW>(f, r, c, n4, 0);
-    if (!can_split || (f->dbg == 9 && BS == 1)) { if constexpr (BS <= MAXBS) try_block<MAXN, BS, NW>(k, r, c); return; }
+    if (known_j < 0 || must_split) set_decoded_wg<NW>(f, r, c, n4, 0);
+    if (!can_split || (f->dbg == 9 && BS == 1)) {
+      if constexpr (BS <= MAXBS) { if (known_j < 0) try_block<MAXN, BS, NW>(k, r, c); else set_decoded_wg<NW>(f, r, c, n4, 1); }
+      return 0;
+    }
     int do_split = must_split;
+    long long sub_j[4] = { -1, -1, -1, -1 };
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        const long long j_none = try_block<MAXN, BS, NW>(k, r, c) + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
+        const long long j_blk = known_j >= 0 ? known_j : try_block<MAXN, BS, NW>(k, r, c);
+        const long long j_none = j_blk + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
         area_copy_dev<BS, NW>(f, k.snap, r, c, 1);
         set_decoded_wg<NW>(f, r, c, n4, 0);
         long long j_split = ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
-        for (int q = 0; q < 4 && j_split < j_none && f->dbg != 7; q++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (!(j_split < j_none) || f->dbg == 7) break;
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-          j_split += try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split);
+          sub_j[q] = try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split);
+          j_split += sub_j[q];
           if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
         }
         if (j_split < j_none && f->dbg != 7 && f->dbg != 8 && !(f->dbg == 10 && BS == 1)) do_split = 1;
@@ -499,17 +513,23 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
     }
     if (do_split) {
       set_decoded_wg<NW>(f, r, c, n4, 0);
-      RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r, c); RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r, c + half);
-      RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + half, c); RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + half, c + half);
+      int chain = !must_split && f->dbg != 11;      // the four trial results are in place until a sibling decides to split
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half, chain ? sub_j[q] : -1)) chain = 0;
+      return 1;
     }
+    return 0;
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
-  static __device__ void run(Ctx<MAXN> &k, int r, int c) {
+  static __device__ MI_K1_INLINE int run(Ctx<MAXN> &k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f;
-    if (r >= f->mi_rows || c >= f->mi_cols) return;
+    if (r >= f->mi_rows || c >= f->mi_cols) return 0;
+    if (known_j >= 0) { set_decoded_wg<NW>(f, r, c, 1, 1); return 0; }
     set_decoded_wg<NW>(f, r, c, 1, 0);
     try_block<MAXN, 0, NW>(k, r, c);
+    return 0;
   }
 };
 
@@ -552,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   const unsigned long long clk0 = wall_clock64();
   for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
     for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)
-      RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c);
+      RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
   if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 #if MI_PROFILE
   WG_SYNC();

@@ -173,6 +173,7 @@ class Encoder:
         self.quality, self.alpha_quality, self.speed = 80.0, 80.0, 5
         self.color_model, self.depth, self.alpha_mode, self.threads = 0, 0, 1, None
         self.device, self.tiles_override = 0, 0
+        self.exif = None
 
     def _copy(self, **kw):
         e = Encoder()
@@ -208,6 +209,9 @@ class Encoder:
         modes = {'dirty': 0, 'clean': 1, 'premultiplied': 2}
         return self._copy(alpha_mode=modes[mode])
 
+    def with_exif(self, exif_data):                     # :208 embeds the bytes as an Exif item (no TIFF-offset prefix expected)
+        return self._copy(exif=bytes(exif_data))
+
     def with_device(self, device):
         return self._copy(device=int(device))
 
@@ -216,6 +220,9 @@ class Encoder:
         e.quality, e.alpha_quality, e.speed, e.color_model, e.depth, e.alpha_mode = self.quality, self.alpha_quality, self.speed, self.color_model, self.depth, self.alpha_mode
         e.threads = self.threads or 0
         e.device, e.tiles_override = self.device, self.tiles_override
+        if self.exif:
+            self._exif_buf = C.create_string_buffer(self.exif, len(self.exif))   # must outlive every call made with `e`
+            e.exif, e.exif_len = C.cast(self._exif_buf, C.c_void_p), len(self.exif)
         return e
 
     def _encode(self, px, channels):
@@ -267,6 +274,7 @@ class BatchEncoder:
 
     def __init__(self, encoder, n_images, width, height, channels=3):
         self._L = load_library()
+        self._encoder = encoder                      # keeps the Exif buffer referenced by the batch alive
         e = encoder._c()
         self._h = self._L.mi_batch_create(C.byref(e), n_images, width, height, channels)
         if not self._h:

@@ -282,27 +282,37 @@ static uint32_t partition_rate(Search *s, int r, int c, int bs, int part) {
   return f->cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
-/* encode_partition_topdown */
-static void rd_partition(Search *s, int r, int c, int bs) {
+/* encode_partition_topdown.
+ * `known_j` >= 0: the parent's split trial has just evaluated this block undivided, nothing it depends on has
+ * changed since (every earlier sibling kept PARTITION_NONE), and the frame buffers still hold that result --
+ * re-running try_block() would reproduce it bit for bit, so its cost is taken from the trial instead.  (rav1e
+ * caches the trial's mode decisions for the children the same way.)  Returns 1 when the block was split. */
+static int rd_partition(Search *s, int r, int c, int bs, int64_t known_j) {
   Av1oFrame *f = s->f;
-  if (r >= f->mi_rows || c >= f->mi_cols) return;
+  if (r >= f->mi_rows || c >= f->mi_cols) return 0;
   const int half = (1 << bs) >> 1, px = 4 << bs;
   const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
   const int must_split = bs > BS_4 && (px > f->cfg.part_max || !has_rows || !has_cols);
   const int can_split = bs > BS_4 && (px > f->cfg.part_min || must_split);
-  set_decoded(f, r, c, bs, 0);
-  if (!can_split) { try_block(s, r, c, bs); return; }
+  if (known_j < 0 || must_split) set_decoded(f, r, c, bs, 0);
+  if (!can_split) {
+    if (known_j < 0) try_block(s, r, c, bs); else set_decoded(f, r, c, bs, 1);
+    return 0;
+  }
   int do_split = must_split;
+  int64_t sub_j[4] = { -1, -1, -1, -1 };
   if (!must_split) {
     static AreaSnap snap[5];
-    int64_t j_none = try_block(s, r, c, bs) + (((int64_t)partition_rate(s, r, c, bs, PARTITION_NONE) * f->rdmult[0] + 256) >> 9);
+    const int64_t j_blk = known_j >= 0 ? known_j : try_block(s, r, c, bs);
+    int64_t j_none = j_blk + (((int64_t)partition_rate(s, r, c, bs, PARTITION_NONE) * f->rdmult[0] + 256) >> 9);
     area_copy(f, &snap[bs], r, c, bs, 1);
     set_decoded(f, r, c, bs, 0);
     int64_t j_split = ((int64_t)partition_rate(s, r, c, bs, PARTITION_SPLIT) * f->rdmult[0] + 256) >> 9;
     for (int k = 0; k < 4 && j_split < j_none; k++) {
       int rr = r + (k >> 1) * half, cc = c + (k & 1) * half;
       if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-      j_split += try_block(s, rr, cc, bs - 1);
+      sub_j[k] = try_block(s, rr, cc, bs - 1);
+      j_split += sub_j[k];
       if (bs - 1 >= BS_8) j_split += ((int64_t)partition_rate(s, rr, cc, bs - 1, PARTITION_NONE) * f->rdmult[0] + 256) >> 9;
     }
     if (j_split < j_none) do_split = 1;
@@ -310,10 +320,14 @@ static void rd_partition(Search *s, int r, int c, int bs) {
   }
   if (do_split) {
     set_decoded(f, r, c, bs, 0);
-    /* m_bsize of the area must not look like an undivided block to later context derivations */
-    rd_partition(s, r, c, bs - 1); rd_partition(s, r, c + half, bs - 1);
-    rd_partition(s, r + half, c, bs - 1); rd_partition(s, r + half, c + half, bs - 1);
+    int chain = !must_split;      /* the four trial results are in place until a sibling decides to split */
+    for (int k = 0; k < 4; k++) {
+      const int rr = r + (k >> 1) * half, cc = c + (k & 1) * half;
+      if (rd_partition(s, rr, cc, bs - 1, chain ? sub_j[k] : -1)) chain = 0;
+    }
+    return 1;
   }
+  return 0;
 }
 
 void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
@@ -326,5 +340,5 @@ void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
   }
   for (int r = s.t.mi_row_start; r < s.t.mi_row_end; r += SB_MI)
     for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI)
-      rd_partition(&s, r, c, BS_64);
+      rd_partition(&s, r, c, BS_64, -1);
 }

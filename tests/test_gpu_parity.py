@@ -165,3 +165,19 @@ def test_async_pipeline_two_batches(oracle):
         for i in range(len(imgs)):
             assert b.get(i).avif_file == ref[i]
         b.close()
+
+
+def test_with_exif_embeds_item_and_leaves_payload_unchanged(oracle):
+    """Encoder::with_exif (ravif/src/av1encoder.rs:208-218): same AV1 payload, plus an Exif item an independent reader returns."""
+    import cavif_rs_amd as m
+    PIL = pytest.importorskip('PIL.Image')
+    img = rgba_gradient(96, 64)[..., :3]
+    exif = b'II\x2a\x00\x08\x00\x00\x00\x01\x00\x31\x01\x02\x00\x04\x00\x00\x00xyz\x00\x00\x00\x00\x00'
+    e = m.Encoder().with_quality(70).with_speed(6)
+    plain, tagged = e.encode_rgb(img), e.with_exif(exif).encode_rgb(img)
+    assert plain.color_byte_size == tagged.color_byte_size and len(tagged.avif_file) > len(plain.avif_file)
+    ref, _, _ = oracle.ravif_encode(img, quality=70, speed=6)
+    assert plain.avif_file == ref
+    im = PIL.open(io.BytesIO(tagged.avif_file))
+    assert exif in bytes(im.info.get('exif') or b'')
+    assert np.array_equal(np.asarray(im.convert('RGB')), np.asarray(PIL.open(io.BytesIO(plain.avif_file)).convert('RGB')))
