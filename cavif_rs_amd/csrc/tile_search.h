@@ -76,29 +76,31 @@ template <int NW> __device__ inline void set_decoded_wg(const LDS FrameDev *f, i
   WG_SYNC();
 }
 
-// 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n
+// 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n.
+// One lane per (column, group of 4 rows): the vertical butterflies run in registers, the horizontal ones across the
+// four lanes of a quad with DPP quad_perm -- every lane of the wave works for n >= 16 (the sum of |H D H^T| does not
+// depend on the order of the passes, so the value equals the oracle's row-then-column form exactly).
+template <int CTRL> __device__ __forceinline__ int satd_quad_step(int v, int odd_mask) {
+  const int p = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+  return (LANE & odd_mask) ? p - v : v + p;
+}
 __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t *pred, int n) {
-  const int nb = n >> 2, tot = nb * nb;
+  const int units = n * (n >> 2);                 // multiple of 4: quads are either fully active or fully idle
   int total = 0;
-  for (int b = LANE; b < tot; b += 64) {
-    const int by = (b / nb) * 4, bx = (b % nb) * 4;
-    int d[16], t[16];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) d[i * 4 + j] = (int)src[(by + i) * n + bx + j] - (int)pred[(by + i) * n + bx + j];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int a = d[i * 4] + d[i * 4 + 1], b2 = d[i * 4] - d[i * 4 + 1], c2 = d[i * 4 + 2] + d[i * 4 + 3], e = d[i * 4 + 2] - d[i * 4 + 3];
-      t[i * 4] = a + c2; t[i * 4 + 1] = b2 + e; t[i * 4 + 2] = a - c2; t[i * 4 + 3] = b2 - e;
-    }
+  for (int u = LANE; u < units; u += 64) {
+    const int x = u % n, o = (u / n) * 4 * n + x;
+    const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + n] - (int)pred[o + n];
+    const int d2 = (int)src[o + 2 * n] - (int)pred[o + 2 * n], d3 = (int)src[o + 3 * n] - (int)pred[o + 3 * n];
+    const int a = d0 + d1, b = d0 - d1, c = d2 + d3, e = d2 - d3;
+    int t[4] = { a + c, b + e, a - c, b - e };
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int a = t[j] + t[4 + j], b2 = t[j] - t[4 + j], c2 = t[8 + j] + t[12 + j], e = t[8 + j] - t[12 + j];
-      s += iabs_(a + c2) + iabs_(b2 + e) + iabs_(a - c2) + iabs_(b2 - e);
+    for (int i = 0; i < 4; i++) {
+      int v = satd_quad_step<0xB1>(t[i], 1);      // quad_perm [1,0,3,2]
+      v = satd_quad_step<0x4E>(v, 2);             // quad_perm [2,3,0,1]
+      s += iabs_(v);
     }
-    total += s;                                   // <= 64x64 block: 4 sub-blocks per lane * 16 * 4 * 1023 * 4 fits int
+    total += s;                                   // <= 16 units per lane (64x64) * 4 * 16 * 1023 fits int
   }
   return wave_sum_i64((long long)total);
 }
