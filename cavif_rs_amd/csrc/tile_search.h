@@ -48,7 +48,9 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t luma_rec[N * N];
   long long satd[13], dsd[7][6];
   long long wbest_j[4], cj[16][2], pbest_j[2];
-  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16];
+  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16], ldelta[3];
+  uint16_t lpred[N <= 16 ? 3 : 1][N <= 16 ? N * N : 4];        // final luma predictions of the surviving modes (blocks <= 16x16)
+  long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
 #if MI_PROFILE
   unsigned long long prof[4][16];
@@ -195,13 +197,16 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   PH(3);
   WG_SYNC();
   PH(2);
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < 13; i++) SH->order[i] = i;
-    for (int i = 1; i < 13; i++) { const int v = SH->order[i]; int j = i; while (j > 0 && SH->satd[SH->order[j - 1]] > SH->satd[v]) { SH->order[j] = SH->order[j - 1]; j--; } SH->order[j] = v; }
+  // stable sort by SATD as a rank computation (mode m = lane): every wave writes the same 13 values, so no
+  // workgroup barrier is needed before they are read back
+  if (LANE < 13) {
+    const long long mine = SH->satd[LANE];
+    int rank = 0;
+    for (int j = 0; j < 13; j++) { const long long o = SH->satd[j]; rank += (o < mine) || (o == mine && j < LANE); }
+    SH->order[rank] = LANE;
   }
+  WAVE_SYNC();
   PH(4);
-  WG_SYNC();
-  PH(2);
   const int ncand = f->complex_modes ? 7 : 3;
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
   const int dl[6] = { -1, 1, -2, 2, -3, 3 };
@@ -223,16 +228,37 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
+  const bool pred_cached = MAXN <= 16 && ncand <= 3 && NW > 1;
+  if (pred_cached) {
+    for (int ci = W; ci < ncand; ci += NW) {
+      const int m = SH->order[ci];
+      int delta = 0;
+      if (m >= V_PRED && m <= D67_PRED && refine) {
+        long long bsd = SH->satd[m];
+        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
+      }
+      predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, SH->lpred[ci]);
+      if (LANE == 0) SH->ldelta[ci] = delta;
+    }
+    PH(12);
+    WG_SYNC();
+    PH(2);
+  }
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
     const int directional = m >= V_PRED && m <= D67_PRED;
     int delta = 0;
-    if (directional && refine) {
-      long long bsd = SH->satd[m];
-      for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
+    const LDS uint16_t *lpred = S->pred;
+    if (pred_cached) { delta = SH->ldelta[ci]; lpred = SH->lpred[ci]; }
+    else {
+      if (directional && refine) {
+        long long bsd = SH->satd[m];
+        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
+      }
+      predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
     }
-    predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
     uint32_t mode_rate = ycost[m];
     if (directional && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
     int ns2, set2;
@@ -241,7 +267,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
     TxRes tr;
-    long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
+    long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; cur ^= 1; }
   }
@@ -301,18 +327,26 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       {
         const int p = (W & 1) + 1;
-        if (valid && um == UV_CFL_PRED) {
-          // rdo_cfl_alpha: the alpha in -16..16 minimising this plane's prediction SSE
+        // rdo_cfl_alpha: the alpha in -16..16 minimising this plane's prediction SSE.  The 1 + 32 trial values are
+        // scanned in two halves: by the wave that owns the CfL candidate (pair 1) and by its idle peer of pair 0;
+        // each reports (sse, position in the scan order), the earliest position wins ties exactly like one scan.
+        const int cfl_main = valid && um == UV_CFL_PRED;
+        const int cfl_help = cfl_allowed && active && pair == 0 && rd == nother - 1;
+        if (cfl_main || cfl_help) {
+          const int half = cfl_help ? 1 : 0;
           const LDS uint16_t *luma = SH->luma_rec;
           int lsum = 0;
           for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
           lsum = wave_sum_i32(lsum);
           const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
           predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
-          int e0 = 0;
-          for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
-          long long best_sse = wave_sum_i64((long long)e0); int best_a = 0;
-          for (int a0 = 0; a0 < 32; a0 += 8) {
+          long long best_sse = J_INF; int best_idx = 1 << 20;
+          if (half == 0) {
+            int e0 = 0;
+            for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
+            best_sse = wave_sum_i64((long long)e0); best_idx = -1;
+          }
+          for (int a0 = half * 16; a0 < half * 16 + 16; a0 += 8) {
             int e[8];                                       // CfL blocks are <= 32x32: 16 samples per lane
 #pragma unroll
             for (int a = 0; a < 8; a++) e[a] = 0;
@@ -329,11 +363,10 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
 #pragma unroll
             for (int a = 0; a < 8; a++) {
               const long long ea = wave_sum_i64((long long)e[a]);
-              const int aa = a0 + a;
-              if (ea < best_sse) { best_sse = ea; best_a = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1); }
+              if (ea < best_sse) { best_sse = ea; best_idx = a0 + a; }
             }
           }
-          if (LANE == 0) SH->calpha[pair][p - 1] = best_a;
+          if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
         }
       }
       PH(8);
@@ -343,7 +376,12 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       uint32_t mode_rate = uvcost[um];
       if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
       if (valid && um == UV_CFL_PRED) {
-        alpha_u = SH->calpha[pair][0]; alpha_v = SH->calpha[pair][1];
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+          const int idx = SH->ca_sse[pp][1] < SH->ca_sse[pp][0] ? SH->ca_idx[pp][1] : SH->ca_idx[pp][0];
+          const int al = idx < 0 ? 0 : ((idx & 1) ? -((idx >> 1) + 1) : ((idx >> 1) + 1));
+          if (pp == 0) alpha_u = al; else alpha_v = al;
+        }
         if (alpha_u == 0 && alpha_v == 0) ok = 0;
         else {
           const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
