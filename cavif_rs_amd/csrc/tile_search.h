@@ -189,10 +189,25 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
-  for (int m = W; m < 13; m += NW) {
-    predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
-    const long long sd = satd_dev(SH->srcb[0], S->pred, n);
-    if (LANE == 0) SH->satd[m] = sd;
+  // dealt by cost rather than round-robin: the six diagonal modes (edge filter + interpolation) weigh about three
+  // cheap ones, so each wave gets 2 + 1, 2 + 1, 1 + 3 and 1 + 2 of them
+  if constexpr (NW == 4) {
+    const int deal = W == 0 ? 0x0F043 : W == 1 ? 0x0F165 : W == 2 ? 0x2C97 : 0x0FBA8;     // four mode nibbles per wave, 0xF = none
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int m = (deal >> (4 * i)) & 15;
+      if (m < 13) {
+        predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+        const long long sd = satd_dev(SH->srcb[0], S->pred, n);
+        if (LANE == 0) SH->satd[m] = sd;
+      }
+    }
+  } else {
+    for (int m = W; m < 13; m += NW) {
+      predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+      const long long sd = satd_dev(SH->srcb[0], S->pred, n);
+      if (LANE == 0) SH->satd[m] = sd;
+    }
   }
   PH(3);
   WG_SYNC();
@@ -346,25 +361,26 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
             best_sse = wave_sum_i64((long long)e0); best_idx = -1;
           }
-          for (int a0 = half * 16; a0 < half * 16 + 16; a0 += 8) {
-            int e[8];                                       // CfL blocks are <= 32x32: 16 samples per lane
+          // scan position aa = 2k is alpha +(k+1), aa = 2k+1 is -(k+1); the scaled luma term of -a is minus that of +a,
+          // so each magnitude is scaled and rounded once.  A CfL block has <= 1024 samples: its SSE stays below 2^31.
+          int e[16];
 #pragma unroll
-            for (int a = 0; a < 8; a++) e[a] = 0;
-            for (int idx = LANE; idx < nn; idx += 64) {
-              const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
+          for (int a = 0; a < 16; a++) e[a] = 0;
+          for (int idx = LANE; idx < nn; idx += 64) {
+            const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
+            const int la = iabs_(l), neg = l < 0;
 #pragma unroll
-              for (int a = 0; a < 8; a++) {
-                const int aa = a0 + a, al = (aa & 1) ? -((aa >> 1) + 1) : ((aa >> 1) + 1);
-                const int v = __mul24(al, l), sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-                const int d = sv - iclamp_(dcv + sc, 0, mx);
-                e[a] += __mul24(d, d);
-              }
+            for (int kq = 0; kq < 8; kq++) {
+              const int mag = half * 8 + kq + 1;
+              const int r = round2_(__mul24(mag, la), 6), sc = neg ? -r : r;       // alpha = +mag
+              const int dp = sv - iclamp_(dcv + sc, 0, mx), dm = sv - iclamp_(dcv - sc, 0, mx);
+              e[2 * kq] += __mul24(dp, dp); e[2 * kq + 1] += __mul24(dm, dm);
             }
+          }
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-              const long long ea = wave_sum_i64((long long)e[a]);
-              if (ea < best_sse) { best_sse = ea; best_idx = a0 + a; }
-            }
+          for (int a = 0; a < 16; a++) {
+            const long long ea = (long long)wave_sum_i32(e[a]);
+            if (ea < best_sse) { best_sse = ea; best_idx = half * 16 + a; }
           }
           if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
         }

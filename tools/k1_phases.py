@@ -9,7 +9,7 @@ b = m.BatchEncoder(e, B, 1920, 1080, 3)
 for i in range(B): b.upload(i, synth_image(1920, 1080, index=i))
 b.encode(); b.encode()
 p = b.phase_profile().astype(np.float64)          # [tiles][wave][phase] cycles
-names = ['txb_ctx', 'stage_src_edges', 'WAIT_barrier', 'satd13', 'sort', 'delta_satd', 'luma_rd', 'luma_commit', 'cfl_alpha', 'chroma_eval', 'chroma_commit', 'final']
+names = ['txb_ctx', 'stage_src_edges', 'WAIT_barrier', 'satd13', 'sort', 'delta_satd', 'luma_rd', 'luma_commit', 'cfl_alpha', 'chroma_eval', 'chroma_commit', 'final', 'luma_final_pred']
 tot = p.sum(axis=2)                                 # per tile per wave
 print('stage_ms', b.stage_ms())
 print('mean cycles per wave per tile: %.3g' % tot.mean())
