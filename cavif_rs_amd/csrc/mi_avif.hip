@@ -400,7 +400,7 @@ int mi_batch_encode_async(mi_batch *b) {
   HIP_OK(hipGetLastError());
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
-  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), 0, s, b->d_frames, b->d_jobs, njobs, b->d_precarry, b->pre_cap);
+  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), sizeof(EntropyLds), s, b->d_frames, b->d_jobs, njobs, b->d_precarry, b->pre_cap);
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -543,7 +543,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   DBG_STAGE("deblock");
   hipLaunchKernelGGL(cdef_kernel, dim3(p.sb_cols * p.sb_rows, 1), dim3(256), 0, s, d_frame, 1);
   DBG_STAGE("cdef");
-  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), 0, s, d_frame, d_jobs, njobs, d_pre, cap);
+  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), sizeof(EntropyLds), s, d_frame, d_jobs, njobs, d_pre, cap);
   DBG_STAGE("entropy");
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);

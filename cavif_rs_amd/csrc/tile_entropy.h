@@ -264,6 +264,9 @@ __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) 
   }
 }
 
+// <= 128 registers per lane, so that an entropy wave fits the slot one finished search workgroup frees on a SIMD and
+// batch A's entropy coding can run next to batch B's search instead of waiting for its tail
+// (dynamic LDS: with a compile-time LDS size that caps the occupancy the compiler pads the VGPR allocation to 176)
 struct EntropyLds {
   uint16_t cdf[CDF_TOTAL];
   int32_t qc[32 * 32];
@@ -275,7 +278,8 @@ struct EntropyLds {
 };
 
 __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames, const TileJob *jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
-  __shared__ EntropyLds L;
+  extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds), passed at launch
+  EntropyLds &L = *(EntropyLds *)k4_smem;
   const int job = blockIdx.x;
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
