@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--depth', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-identity-check', action='store_true')
-    ap.add_argument('--pipeline', type=int, default=2, help='resident batches driven alternately (2 = double buffering: one batch entropy-codes while the next searches)')
+    ap.add_argument('--pipeline', type=int, default=3, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 3 measured best on MI355X)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
