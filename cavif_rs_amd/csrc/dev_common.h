@@ -31,6 +31,7 @@ struct FrameDev {
   int8_t *cdef_idx;
   // quantizer / lambda
   int base_q_idx, qctx, dc_q[3], ac_q[3];
+  uint32_t dc_recip[3], ac_recip[3];          // floor((2^32 - 1) / q): quantisation divides by multiply-high + one fix-up
   long long rdmult, wq[3];
   // tools
   int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, enable_cdef;

@@ -154,7 +154,7 @@ template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(const CoefC
   }
   bits = wave_sum_i32(bits);
   cul = wave_sum_i32(imin_(cul, 1 << 20));
-  dcc = wave_max_i32(dcc);
+  dcc = __builtin_amdgcn_readfirstlane(dcc);             // only scan position 0 (lane 0, first iteration) sets it
   *cul_out = imin_(cul, 63); *dc_cat = dcc;
   return head + (uint32_t)bits;
 }

@@ -93,7 +93,8 @@ template <int N> __device__ inline void inv_txfm2d_add_dev(const LDS int32_t *dq
 }
 
 // returns eob (wave-uniform); qc [CS*CS].  All magnitudes fit 32 bits (|coef| < 2^22, q < 2^13).
-__device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *coef, LDS int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq) {
+__device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *coef, LDS int32_t *qc, int n /*coded size*/, int txs, int txtype, int dcq, int acq,
+                                   uint32_t dc_recip, uint32_t recip /* floor((2^32-1)/q) for the dc and ac step */) {
   const int nc = n * n, cls = tx_class_of(txtype);
   const int lsh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
   const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
@@ -104,8 +105,10 @@ __device__ inline int quantize_dev(const LDS uint16_t *ls, const LDS int32_t *co
   }
   last = wave_max_i32(last);
   const uint32_t a0 = (uint32_t)iabs_(coef[0]) << lsh;
-  const int l0 = (int)((a0 + dc_off) / (uint32_t)dcq);
-  const uint32_t recip = 0xFFFFFFFFu / uq;              // floor((2^32-1)/q): one division per block, then multiply-high + fix-up per coefficient
+  const uint32_t x0 = a0 + dc_off;                      // x/q by multiply-high with floor((2^32-1)/q) and one fix-up: x/q - 1 < hi <= x/q for x < 2^31
+  uint32_t l0u = __umulhi(x0, dc_recip);
+  if (x0 - l0u * (uint32_t)dcq >= (uint32_t)dcq) l0u++;
+  const int l0 = (int)l0u;
   int eob = last;
   if (eob == 0) eob = l0 ? 1 : 0;
   for (int i = LANE; i < nc; i += 64) {

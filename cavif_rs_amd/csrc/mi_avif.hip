@@ -113,7 +113,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.mi_cols = p.mi_cols; d.mi_rows = p.mi_rows; d.sb_cols = p.sb_cols; d.sb_rows = p.sb_rows;
   d.pw = p.pw; d.ph = p.ph; d.stride = p.pw; d.mi_stride = p.mi_stride; d.mi_h = p.mi_h;
   d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
-  for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; }
+  for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
   d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef;
   d.tile_cols = p.tiles.cols; d.tile_rows = p.tiles.rows; d.tile_cols_log2 = p.tiles.cols_log2; d.tile_rows_log2 = p.tiles.rows_log2;

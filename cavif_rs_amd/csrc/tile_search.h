@@ -104,11 +104,12 @@ __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t
     }
     total += s;                                   // <= 16 units per lane (64x64) * 4 * 16 * 1023 fits int
   }
-  return wave_sum_i64((long long)total);
+  return (long long)wave_sum_i32(total);         // whole-block SATD <= 64*64 * 16 * 1023 < 2^31
 }
 __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b, int nn) {
   int s = 0;                                     // per lane <= 64 samples * 1023^2 < 2^27
   for (int i = LANE; i < nn; i += 64) { const int d = (int)a[i] - (int)b[i]; s += __mul24(d, d); }
+  if (nn <= 1024) return (long long)wave_sum_i32(s);   // <= 1024 * 1023^2 < 2^31: one 32-bit reduction
   return wave_sum_i64((long long)s);
 }
 
@@ -126,7 +127,7 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   }
   WAVE_SYNC();
   fwd_txfm2d_dev<n>(S->tbuf, S->cbuf, txtype);
-  const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane]);
+  const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane]);
   tr->rate = coef_rate_dev(k.cc, k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
   if (eob > 0) {
     dequantize_dev(qc_out, S->cbuf, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
