@@ -158,3 +158,125 @@ template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(const CoefC
   *cul_out = imin_(cul, 63); *dc_cat = dcc;
   return head + (uint32_t)bits;
 }
+
+// Padded level maps, one region per coded size so that the zero padding written once at kernel start stays zero
+// (the interior is fully rewritten by every evaluation of that size).
+#define LEV_OFF(cs) ((cs) == 4 ? 0 : (cs) == 8 ? 64 : (cs) == 16 ? 64 + 144 : 64 + 144 + 400)
+#define LEV_BYTES(maxcs) ((maxcs) == 4 ? 64 : (maxcs) == 8 ? 64 + 144 : (maxcs) == 16 ? 64 + 144 + 400 : 64 + 144 + 400 + 1296)
+
+// Quantise + level map + dequantise + rate of one transform block in one sweep: each lane keeps the scan positions,
+// magnitudes and levels of its coefficients in registers between the steps (quantize_dev + build_level_map +
+// dequantize_dev + coef_rate_dev did four sweeps with LDS round trips in between; results are identical).
+//   cbuf: in = forward coefficients [CS*CS], out = dequantised coefficients (only meaningful when eob > 0)
+//   qc:   out = quantised levels, raster [CS*CS];  levbase: this wave's level-map regions (LEV_OFF)
+// Returns eob (wave-uniform); *rate_out in 1/512 bit.
+template <int CS, typename CostPtr>
+__device__ inline int quant_rate_dev(const CoefCost &cc, CostPtr cost, const LDS uint16_t *ls, LDS int32_t *cbuf, LDS int32_t *qc, LDS uint8_t *levbase,
+                                     int plane, int txs, int txtype, int dcq, int acq, uint32_t dc_recip, uint32_t ac_recip, int bd,
+                                     int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint32_t *rate_out, int *cul_out, int *dc_cat) {
+  constexpr int n = CS, nc = CS * CS, IT = nc < 64 ? 1 : nc / 64, bwl = CS == 4 ? 2 : CS == 8 ? 3 : CS == 16 ? 4 : 5, st = CS + 4;
+  LDS uint8_t *lev = levbase + LEV_OFF(CS);
+  const int cls = tx_class_of(txtype), pt = plane > 0, txs_ctx = txs;
+  const int lsh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
+  const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
+  const uint32_t thr = (uint32_t)acq - off_eob, uq = (uint32_t)acq;
+  int pos[IT]; uint32_t mag[IT]; int neg[IT];
+  int last = 0;
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int i = LANE + 64 * k;
+    const bool valid = nc >= 64 || i < nc;
+    pos[k] = valid ? scan_pos(ls, n, cls, i) : 0;
+    const int c = valid ? cbuf[pos[k]] : 0;
+    mag[k] = (uint32_t)iabs_(c) << lsh; neg[k] = c < 0;
+    if (valid && i >= 1 && mag[k] >= thr) last = i + 1;
+  }
+  last = wave_max_i32(last);
+  // dc level by every lane (uniform LDS read), as quantize_dev
+  const uint32_t x0 = ((uint32_t)iabs_(cbuf[0]) << lsh) + dc_off;
+  uint32_t l0u = __umulhi(x0, dc_recip);
+  if (x0 - l0u * (uint32_t)dcq >= (uint32_t)dcq) l0u++;
+  const int l0 = (int)l0u;
+  int eob = last;
+  if (eob == 0) eob = l0 ? 1 : 0;
+  const int sh = lsh, dmx = (1 << (7 + bd)) - 1, dmn = -(1 << (7 + bd));
+  int lvl[IT];
+  WAVE_SYNC();                                   // every lane has read its coefficients before cbuf is overwritten
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int i = LANE + 64 * k;
+    const bool valid = nc >= 64 || i < nc;
+    int lv = 0;
+    if (valid && i < eob) {
+      if (i == 0) lv = l0;
+      else {
+        const uint32_t a = mag[k];
+        uint32_t lv0 = __umulhi(a, ac_recip);          // a/q - 1 < lv0 <= a/q for a < 2^31
+        if (a - lv0 * uq >= uq) lv0++;
+        const uint32_t off = lv0 > 0 ? off1 : off0;
+        lv = (int)lv0 + ((a + off) >= (lv0 + 1) * uq);
+      }
+    }
+    lvl[k] = lv;
+    if (valid) {
+      const int pp = pos[k];
+      qc[pp] = neg[k] ? -lv : lv;
+      lev[(pp >> bwl) * st + (pp & (n - 1))] = (uint8_t)imin_(lv, 127);
+      uint32_t m = (uint32_t)lv * (uint32_t)(pp == 0 ? dcq : acq);          // dequantize_dev
+      m &= 0xFFFFFF; m >>= sh;
+      const int v = neg[k] ? -(int)m : (int)m;
+      cbuf[pp] = v < dmn ? dmn : (v > dmx ? dmx : v);
+    }
+  }
+  WAVE_SYNC();
+  *cul_out = 0; *dc_cat = 0;
+  uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  if (eob == 0) { *rate_out = head; return 0; }
+  if (tx_off >= 0) head += cost[tx_off + tx_sym];
+  const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
+  {
+    const int strs[4] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_1024_STRIDE };
+    const int sq = eob_multi >> 1;
+    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * strs[sq] + eob_pt - 1];
+  }
+  if (eob_pt >= 3) {
+    const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+    head += cc.eobx[((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
+    head += 512u * (uint32_t)(nb - 1);
+  }
+  constexpr int area = nc;
+  int bits = 0, cul = 0, dcc = 0;
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int c = LANE + 64 * k;
+    if (c < eob) {
+      const int pp = pos[k], row = pp >> bwl, col = pp & (n - 1), level = lvl[k];
+      const LDS uint8_t *L = lev + row * st + col;
+      if (c == eob - 1) {
+        const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
+        bits += cc.beob[((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+      } else {
+        const int ctx = base_ctx(L, st, cls, row, col);
+        bits += cc.base[((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+      }
+      if (level > 2) {
+        const int ctx = br_ctx(L, st, cls, row, col, c);
+        const int off = ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+        int rem = level - 3;
+        for (int idx = 0; idx < 4; idx++) { const int s2 = imin_(rem, 3); bits += cc.br[off + s2]; rem -= s2; if (s2 < 3) break; }
+      }
+      if (level) {
+        if (c == 0) { bits += cc.dcs[(pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + neg[k]]; dcc = neg[k] ? 1 : 2; }
+        else bits += 512;
+        if (level > 14) { const int len = 32 - __clz(level - 14); bits += 512 * (2 * len - 1); }
+      }
+      cul += level;
+    }
+  }
+  bits = wave_sum_i32(bits);
+  cul = wave_sum_i32(imin_(cul, 1 << 20));
+  dcc = __builtin_amdgcn_readfirstlane(dcc);
+  *cul_out = imin_(cul, 63); *dc_cat = dcc;
+  *rate_out = head + (uint32_t)bits;
+  return eob;
+}

@@ -226,7 +226,7 @@ static int batch_alloc(mi_batch *b) {
   b->pre_cap = max_cap;
   HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * max_cap * 2));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
-  HIP_OK(hipMalloc(&b->d_prof, max_tiles * 64 * 8));
+  HIP_OK(hipMalloc(&b->d_prof, max_tiles * 128 * 8));
   b->packed_cap = std::min<size_t>(packed, (size_t)1 << 31);
   HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
@@ -299,7 +299,7 @@ int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
 int mi_batch_phase_profile(mi_batch *b, unsigned long long *out) {
   if (!b || !out || !b->d_prof) return MI_INVALID_ARGUMENT;
   hipSetDevice(b->device);
-  HIP_OK(hipMemcpy(out, b->d_prof, b->jobs.size() * 64 * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out, b->d_prof, b->jobs.size() * 128 * 8, hipMemcpyDeviceToHost));
   return MI_OK;
 }
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }

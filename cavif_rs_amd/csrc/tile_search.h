@@ -40,7 +40,7 @@ template <int N> struct WaveScratch {            // private to one wavefront
   uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
   uint16_t pred[N * N], dcp[N * N], rec[2][N * N];
   int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];      // cbuf doubles as the dequantised block
-  uint8_t lev[(CS + 4) * (CS + 4) + 4];
+  uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
 };
 template <int N> struct SharedScratch {          // shared by the waves of the tile
   uint16_t ra[3][EDGE_LEN(N)], rl[3][EDGE_LEN(N)];
@@ -53,7 +53,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
 #if MI_PROFILE
-  unsigned long long prof[4][16];
+  unsigned long long prof[4][32];
 #endif
 };
 
@@ -120,21 +120,27 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
   const LDS FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
   const LDS uint16_t *src = k.sh->srcb[plane];
+#if MI_PROFILE
+  LDS SharedScratch<MAXN> *SH = k.sh; const int W = WAVE_ID;
+#endif
+  PH_BEGIN();
   for (int idx = LANE; idx < n * n; idx += 64) {
     const int i = idx / n, j = idx % n;
     S->tbuf[i * P + j] = (int)src[idx] - (int)pred[idx];
     rec_out[idx] = pred[idx];
   }
   WAVE_SYNC();
+  PH(16);
   fwd_txfm2d_dev<n>(S->tbuf, S->cbuf, txtype);
-  const int eob = quantize_dev(k.ls, S->cbuf, qc_out, CS, BS, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane]);
-  tr->rate = coef_rate_dev(k.cc, k.cost, k.ls, qc_out, eob, plane, BS, txtype, sctx, dctx, tx_off, tx_sym, S->lev, &tr->cul, &tr->dcc);
-  if (eob > 0) {
-    dequantize_dev(qc_out, S->cbuf, CS, BS, f->dc_q[plane], f->ac_q[plane], f->bd);
-    inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
-  }
+  PH(17);
+  const int eob = quant_rate_dev<CS>(k.cc, k.cost, k.ls, S->cbuf, qc_out, S->lev, plane, BS, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane],
+                                     f->bd, sctx, dctx, tx_off, tx_sym, &tr->rate, &tr->cul, &tr->dcc);
+  PH(19);
+  if (eob > 0) inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
   tr->eob = eob;
+  PH(20);
   tr->sse = sse_dev(src, rec_out, n * n);
+  PH(21);
   return ((tr->sse * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
 }
 
@@ -614,6 +620,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   // the frame descriptor, the scan tables and the coefficient slices of the rate table are staged in LDS once per tile
   for (int i = threadIdx.x; i < (int)(sizeof(FrameDev) / 4); i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
+  for (int i = LANE; i < (int)sizeof(k.s->lev); i += 64) k.s->lev[i] = 0;        // level-map padding stays zero for the whole tile
   load_coef_cost(&k.cc, lcc, gf->cost, MAXBS, threadIdx.x, 64 * NW);
   k.f = lf; k.cost = gf->cost; k.ls = lsc;
   WG_SYNC();
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
 #if MI_PROFILE
-  if (threadIdx.x < 64) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
+  if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
 #endif
   WG_SYNC();
   if (f->dbg == 1) return;
@@ -633,6 +640,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 #if MI_PROFILE
   WG_SYNC();
-  if (f->prof_out && threadIdx.x < 64) f->prof_out[(size_t)job * 64 + threadIdx.x] = ((LDS unsigned long long *)k.sh->prof)[threadIdx.x];
+  if (f->prof_out && threadIdx.x < 128) f->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh->prof)[threadIdx.x];
 #endif
 }

@@ -337,7 +337,7 @@ class BatchEncoder:
         return a
 
     def phase_profile(self):
-        a = np.zeros((self.num_tiles(), 4, 16), dtype=np.uint64)
+        a = np.zeros((self.num_tiles(), 4, 32), dtype=np.uint64)
         st = self._L.mi_batch_phase_profile(self._h, a.ctypes.data)
         if st:
             raise AvifError(st)
