@@ -70,7 +70,7 @@ template <int N> __device__ inline void inv_txfm2d_add_dev(const LDS int32_t *dq
     int32_t x[N];
     if (i < CS) {
 #pragma unroll
-      for (int j = 0; j < N; j++) x[j] = j < CS ? iclamp_(dq[i * CS + j], rmin, rmax) : 0;
+      for (int j = 0; j < N; j++) x[j] = j < CS ? dq[i * CS + j] : 0;      // already clamped to [rmin, rmax] by the dequantiser (same bounds)
       tx1d<N>(x, rk, false);
 #pragma unroll
       for (int j = 0; j < N; j++) tbuf[i * P + j] = iclamp_(round2_(x[j], ROWSH), cmin, cmax);

@@ -179,7 +179,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   PH_BEGIN();
 
   // ---- stage the source block and the raw edges of every plane (plane p by wave p % NW) ----
-  for (int p = 0; p < f->np; p++) if (p % NW == W) {
+  for (int p = 0; p < f->np; p++) if ((p + 1) % NW == W) {      // waves 1..3: wave 0 carries the longest candidate chains below
     int sc_, dc_;                                            // all-zero / dc-sign contexts depend on the neighbours only
     txb_ctx_dev(f, t, p, r, c, BS, BS, &sc_, &dc_);
     if (LANE == 0) { SH->sctx[p] = sc_; SH->dctx[p] = dc_; }
@@ -253,7 +253,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
   const bool pred_cached = MAXN <= 16 && ncand <= 3 && NW > 1;
   if (pred_cached) {
-    for (int ci = W; ci < ncand; ci += NW) {
+    for (int ci = NW - 1 - W; ci < ncand; ci += NW) {          // waves 3, 2, 1
       const int m = SH->order[ci];
       int delta = 0;
       if (m >= V_PRED && m <= D67_PRED && refine) {
@@ -329,7 +329,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
     constexpr int NPAIR = 2;
-    const int pair = (W >> 1) & 1, active = W < 4;
+    const int pair = ((W >> 1) & 1) ^ 1, active = W < 4;      // pair 0 (two plain candidates) = waves 2, 3: they have the lighter luma share
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
     // pair 0: candidates 0 and the odd ones; pair 1: the even ones from 2 on and CfL (always last) -- the winner rule
     // below only looks at (cost, candidate index), so the dealing order does not change the decision.
