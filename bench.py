@@ -22,6 +22,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_PX = {10: 10.0, 8: 7.0}   # 4 B RGBA8 in + 3*s source samples read once
 
 
+def hbm_traffic_bytes(kernel, cfg):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_counters.json), when they were
+    taken on this very workload; None otherwise.  (2 * FETCH_SIZE + WRITE_SIZE) KB -- the gfx950 FETCH_SIZE correction
+    of MI355X_MICROARCH.md; counters come from separate rocprofv3 --pmc passes, see tools/final_profile.sh.)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'hbm_counters.json')) as fh:
+            d = json.load(fh)
+        if any(d['config'].get(k_) != v_ for k_, v_ in cfg.items()):
+            return None
+        c = d['kernels'][kernel]
+        return (2.0 * c['FETCH_SIZE_KB'] + c['WRITE_SIZE_KB']) * 1024.0
+    except Exception:
+        return None
+
+
 def _oracle_worker(job):
     idx, w, h, speed, quality, depth = job
     sys.path.insert(0, ROOT)
@@ -151,7 +166,10 @@ def main():
                        "images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth,
                        "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU driven alternately" % (world, depth_q)},
             "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8),
+                         "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
+                                                                             "quality": args.quality, "bit_depth": args.depth}),
+                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json; ~200x the algorithmic bytes: register-spill scratch (callee-saved VGPR save/restore of the block search) served by L2 / Infinity Cache, not source re-reads",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(k1 * 1e3, 3)},
             "stage_ms_per_step": {k_: round(v_ / args.steps, 3) for k_, v_ in stage_acc.items()},
         }

@@ -14,3 +14,9 @@ for name, s, t in (('K1', 0, 1), ('K4', 2, 3)):
     span = (c[:, t].max() - c[:, s].min()) / 100e6 * 1e3
     print(name, 'tiles', len(d), 'mean %.1f ms  median %.1f  p90 %.1f  max %.1f  min %.1f  kernel span %.1f ms  mean/max %.2f' % (d.mean(), np.median(d), np.percentile(d, 90), d.max(), d.min(), span, d.mean() / d.max()))
 print(b.stage_ms())
+# K4 time against the size of what a tile codes
+sizes = np.array([len(b.get(i).avif_file) for i in range(B)], dtype=np.float64)
+d4 = (c[:, 3] - c[:, 2]) / 100e6 * 1e3
+per_img = d4.reshape(B, -1)
+print('K4 per image: max-tile ms vs file bytes:', [(round(float(per_img[i].max()), 1), int(sizes[i])) for i in range(min(B, 6))])
+print('K4 total tile-ms %.1f for %.0f payload bytes -> %.2f us per byte (~%.0f ns per coded bit)' % (d4.sum(), sizes.sum(), 1e3 * d4.sum() / sizes.sum(), 1e6 * d4.sum() / sizes.sum() / 8))
