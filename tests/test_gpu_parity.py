@@ -181,3 +181,64 @@ def test_with_exif_embeds_item_and_leaves_payload_unchanged(oracle):
     im = PIL.open(io.BytesIO(tagged.avif_file))
     assert exif in bytes(im.info.get('exif') or b'')
     assert np.array_equal(np.asarray(im.convert('RGB')), np.asarray(PIL.open(io.BytesIO(plain.avif_file)).convert('RGB')))
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        w, h = int(rng.integers(8, 220)), int(rng.integers(8, 180))
+        out.append((w, h, int(rng.choice([8, 10])), int(rng.integers(1, 11)), int(rng.integers(5, 251)), bool(rng.integers(0, 4) == 0), int(rng.choice([0, 0, 2, 4]))))
+    return out
+
+
+@pytest.mark.parametrize('w,h,bd,speed,q,mono,tiles', _random_cases(24, 20260924))
+def test_random_configuration_sweep(oracle, w, h, bd, speed, q, mono, tiles):
+    """Seeded sweep over ragged sizes, both depths, every speed preset, the whole quantizer range, colour / monochrome, tile counts."""
+    import cavif_rs_amd as m
+    pl = planes(h, w, seed=1000 + w * 7 + h, bd=bd, mono=mono)
+    r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, speed, tiles=tiles), pl)
+    obu, rec = m.encode_planes(pl, bd, q, speed, mono, tiles=tiles)
+    assert obu == r['obu'], 'bitstream differs (%d vs %d bytes)' % (len(obu), len(r['obu']))
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
+def test_config3_full_size_4096_rgba_properties(avifdec):
+    """BASELINE config 3 at its full size (4096x4096 RGBA, speed 4, q80): both planes' streams decode (dav1d) to exactly the
+    encoder's reconstruction, the call is deterministic, and the alpha plane went through the second encode."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(4096, 4096, index=3, alpha=True)
+    e = m.Encoder().with_quality(80).with_alpha_quality(90).with_speed(4)
+    b = m.BatchEncoder(e, 1, 4096, 4096, channels=4)
+    b.upload(0, img)
+    b.encode()
+    out = b.get(0)
+    assert out.alpha_byte_size > 0 and out.color_byte_size > 0
+    d = avifdec.decode(out.avif_file)
+    assert (d['width'], d['height'], d['depth']) == (4096, 4096, 10) and d['alpha'] is not None
+    for a, r in zip(d['planes'], b.recon(0)):
+        assert np.array_equal(a, r)
+    assert np.array_equal(d['alpha'], b.recon(0, alpha=True)[0])
+    b.encode()
+    assert b.get(0).avif_file == out.avif_file
+    b.close()
+
+
+def test_config5_8k_speed1_properties(avifdec):
+    """BASELINE config 5 at its full size (7680x4320, speed 1, 10-bit): conformance + reconstruction identity + tile plan."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(7680, 4320, index=5)
+    e = m.Encoder().with_quality(80).with_speed(1).with_bit_depth(10)
+    b = m.BatchEncoder(e, 1, 7680, 4320, channels=3)
+    b.upload(0, img)
+    b.encode()
+    out = b.get(0)
+    assert b.num_tiles() == 8            # 2048-px minimum tile size at speed 1 (ravif/src/av1encoder.rs:598-604): 7680*4320 / 2048^2 = 7.9 -> 8
+    d = avifdec.decode(out.avif_file)
+    assert (d['width'], d['height'], d['depth']) == (7680, 4320, 10)
+    for a, r in zip(d['planes'], b.recon(0)):
+        assert np.array_equal(a, r)
+    b.close()
