@@ -1,0 +1,149 @@
+// cavif_mi -- the cavif command line (src/main.rs) on top of libmi_avif.so: same flags, path rules and report line;
+// the rayon fan-out over files (src/main.rs:223) becomes mi_ravif_encode_batch (one host thread per MI355X).
+//   cavif_mi [-Q n] [-s n] [-j n] [-f] [-o path] [-q] [--dirty-alpha] [--color ycbcr|rgb] [--depth 8|10|auto] IMAGES...
+// Differences, deliberate: PNG input only (the reference also reads JPEG through load_image), `--devices a,b,..`
+// selects HIP devices (default: all), and there is no CPU fallback -- without a GPU every file fails loudly.
+#include <sys/stat.h>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mi_avif.h"
+
+namespace {
+
+struct Input { bool is_stdio = false; std::string path; };
+bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+bool is_dir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+void mkdirs(const std::string &p) {
+  for (size_t i = 1; i <= p.size(); i++) if (i == p.size() || p[i] == '/') { const std::string s = p.substr(0, i); mkdir(s.c_str(), 0777); }
+}
+std::string file_name(const std::string &p) { const size_t s = p.find_last_of('/'); return s == std::string::npos ? p : p.substr(s + 1); }
+// Path::extension(): text after the last '.' of the file name, none for names that start with their only dot
+bool extension(const std::string &p, std::string *ext) {
+  const std::string f = file_name(p); const size_t d = f.find_last_of('.');
+  if (d == std::string::npos || d == 0) return false;
+  *ext = f.substr(d + 1); return true;
+}
+std::string with_extension_avif(const std::string &p) {
+  std::string e; if (!extension(p, &e)) return p + ".avif";
+  return p.substr(0, p.size() - e.size()) + "avif";
+}
+bool read_all(FILE *f, std::vector<uint8_t> &out) {
+  uint8_t buf[1 << 16]; size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.insert(out.end(), buf, buf + n);
+  return !ferror(f);
+}
+int usage(const char *msg) {
+  fprintf(stderr, "error: %s\nusage: cavif_mi [-Q quality 1-100] [-s speed 1-10] [-j threads] [-f|--overwrite] [-o path] [-q] [--dirty-alpha]\n"
+                  "                [--color ycbcr|rgb] [--depth 8|10|auto] [--devices 0,1,..] IMAGES...   (\"-\" = stdin/stdout)\n", msg);
+  return 1;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0;
+  bool overwrite = false, quiet = false, dirty_alpha = false, have_output = false, output_stdio = false;
+  std::string output; std::vector<std::string> images; std::vector<int> devices;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto value = [&](const char *name) -> const char * { if (i + 1 >= argc) { usage((std::string("missing value for ") + name).c_str()); exit(1); } return argv[++i]; };
+    if (a == "-Q" || a == "--quality") {
+      char *end; quality = strtof(value("--quality"), &end);
+      if (*end || !(quality >= 1.f && quality <= 100.f)) return usage("quality must be a number between 1 and 100");      // parse_quality, src/main.rs:24-33
+    } else if (a == "-s" || a == "--speed") {
+      char *end; const long v = strtol(value("--speed"), &end, 10);
+      if (*end || v < 1 || v > 10) return usage("speed must be a number between 1 and 10");                                // parse_speed, :35-43
+      speed = (int)v;
+    } else if (a == "-j" || a == "--threads") { threads = atoi(value("--threads")); if (threads < 0 || threads > 255) return usage("bad thread count"); }
+    else if (a == "-f" || a == "--overwrite" || a == "--force") overwrite = true;
+    else if (a == "-o" || a == "--output") { output = value("--output"); have_output = true; output_stdio = output == "-"; }
+    else if (a == "-q" || a == "--quiet") quiet = true;
+    else if (a == "--dirty-alpha") dirty_alpha = true;
+    else if (a == "--color") { const std::string v = value("--color"); if (v == "ycbcr") color_model = 0; else if (v == "rgb") color_model = 1; else return usage("bad color type"); }
+    else if (a == "--depth") { const std::string v = value("--depth"); depth = v == "8" ? 8 : v == "10" ? 10 : 0; if (v != "8" && v != "10" && v != "auto") return usage("bad depth"); }
+    else if (a == "--devices") { const char *v = value("--devices"); for (const char *p = v; *p;) { devices.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') p++; } }
+    else if (a.size() > 1 && a[0] == '-' ) return usage(("unknown option " + a).c_str());
+    else images.push_back(a);
+  }
+  if (images.empty()) return usage("Please specify image paths to convert");
+  // file filter, src/main.rs:137-160
+  std::vector<Input> files;
+  for (const std::string &p : images) {
+    if (p == "-") { Input in; in.is_stdio = true; files.push_back(in); continue; }
+    if (quiet) { char *end; const long v = strtol(p.c_str(), &end, 10); if (!*end && v >= 0 && v <= 255 && !exists(p)) fprintf(stderr, "warning: -q is not for quality, so '%s' is misinterpreted as a file. Use -Q %s\n", p.c_str(), p.c_str()); }
+    std::string ext;
+    if (extension(p, &ext) && ext == "avif") {
+      if (!quiet) {
+        if (exists(p)) fprintf(stderr, "warning: ignoring %s, because it's already an AVIF\n", p.c_str());
+        else { fprintf(stderr, "warning: Did you mean to use -o %s?\n", p.c_str()); Input in; in.path = p; files.push_back(in); }
+      }
+      continue;
+    }
+    Input in; in.path = p; files.push_back(in);
+  }
+  if (files.empty()) { fprintf(stderr, "error: No PNG/JPEG files specified\n"); return 1; }
+  bool use_dir = false;
+  if (have_output && !output_stdio) { if (files.size() > 1) mkdirs(output); use_dir = files.size() > 1 || is_dir(output); }
+
+  mi_ravif_encoder enc; mi_ravif_encoder_default(&enc);
+  enc.quality = quality;
+  enc.alpha_quality = std::fmin((quality + 100.f) / 2.f, quality + quality / 4.f + 2.f);                                   // :115
+  enc.speed = (uint8_t)speed; enc.depth = (uint8_t)depth; enc.color_model = (uint8_t)color_model;
+  enc.alpha_mode = dirty_alpha ? 0 : 1; enc.threads = threads > 0 ? threads : 0;
+
+  // load + decide output paths (process(), :169-200); failures are collected per file and reported at the end
+  struct Job { std::string in_name, out_path; bool out_stdio = false; uint8_t *rgba = nullptr; uint32_t w = 0, h = 0; std::string error; };
+  std::vector<Job> jobs(files.size());
+  for (size_t i = 0; i < files.size(); i++) {
+    Job &j = jobs[i]; const Input &in = files[i];
+    j.in_name = in.is_stdio ? "stdin" : in.path;
+    std::vector<uint8_t> data;
+    if (in.is_stdio) { if (!read_all(stdin, data)) j.error = "Unable to read stdin"; }
+    else { FILE *f = fopen(in.path.c_str(), "rb"); if (!f || !read_all(f, data)) j.error = "Unable to read input image " + in.path + ": " + strerror(errno); if (f) fclose(f); }
+    if (j.error.empty()) {
+      const int st = mi_png_decode_rgba(data.data(), data.size(), &j.rgba, &j.w, &j.h);
+      if (st) j.error = st == MI_UNSUPPORTED ? "unsupported image format (this build reads PNG)" : "corrupt PNG data";
+    }
+    if (!have_output) { if (in.is_stdio) j.out_stdio = true; else j.out_path = with_extension_avif(in.path); }
+    else if (output_stdio) j.out_stdio = true;
+    else if (in.is_stdio) j.out_path = output;
+    else j.out_path = use_dir ? output + "/" + with_extension_avif(file_name(in.path)) : output;
+    if (j.error.empty() && !j.out_stdio && !overwrite && exists(j.out_path)) j.error = j.out_path + " already exists; skipping";
+  }
+  // encode everything that is still alive, across the selected devices
+  std::vector<mi_image_desc> desc; std::vector<size_t> who;
+  for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].error.empty()) { mi_image_desc d; d.pixels = jobs[i].rgba; d.width = jobs[i].w; d.height = jobs[i].h; d.stride_px = jobs[i].w; d.channels = 4; desc.push_back(d); who.push_back(i); }
+  std::vector<mi_encoded_image> enc_out(desc.size()); std::vector<int> status(desc.size(), MI_OK);
+  if (!desc.empty()) {
+    const int rc = mi_ravif_encode_batch(&enc, desc.size(), desc.data(), enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
+    if (rc == MI_NO_DEVICE) for (int &s : status) s = MI_NO_DEVICE;
+  }
+  for (size_t k = 0; k < who.size(); k++) {
+    Job &j = jobs[who[k]]; const mi_encoded_image &im = enc_out[k];
+    if (status[k] != MI_OK) {
+      static const char *names[] = { "ok", "TooFewPixels", "Unsupported", "EncodingError", "invalid argument", "no HIP device (this encoder has no CPU fallback)" };
+      j.error = names[status[k] >= 0 && status[k] <= 5 ? status[k] : 3];
+      continue;
+    }
+    if (j.out_stdio) { if (fwrite(im.avif_file, 1, im.avif_len, stdout) != im.avif_len) j.error = "Unable to write output image: stdout"; }
+    else {
+      if (!quiet) printf("%s: %zuKB (%zuB color, %zuB alpha, %zuB HEIF)\n", j.out_path.c_str(), (im.avif_len + 999) / 1000, im.color_byte_size, im.alpha_byte_size,
+                         im.avif_len - im.color_byte_size - im.alpha_byte_size);                                                                   // :213
+      FILE *f = fopen(j.out_path.c_str(), "wb");
+      if (!f || fwrite(im.avif_file, 1, im.avif_len, f) != im.avif_len) j.error = "Unable to write output image: " + std::string(strerror(errno));
+      if (f) fclose(f);
+    }
+    mi_free(im.avif_file);
+  }
+  int failures = 0;
+  for (Job &j : jobs) {
+    if (j.rgba) mi_free(j.rgba);
+    if (!j.error.empty()) { failures++; if (!quiet) fprintf(stderr, "error: %s: error: %s\n", j.in_name.c_str(), j.error.c_str()); }
+  }
+  return failures ? 1 : 0;
+}

@@ -7,7 +7,10 @@
 #include <cstdlib>
 #include <mutex>
 #include <memory>
+#include <thread>
+#include <atomic>
 #include "host_av1.h"
+#include "png_reader.h"
 #include "tile_search.h"
 #include "tile_entropy.h"
 #include "loopfilter.h"
@@ -502,6 +505,58 @@ static int encode_one(const mi_ravif_encoder *e, const uint8_t *px, int channels
   return st;
 }
 int mi_ravif_encode_rgba(const mi_ravif_encoder *e, const uint8_t *rgba, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgba, 4, w, h, stride_px, out); }
+
+// PNG -> RGBA8 (cavif's load_rgba, src/main.rs:265-283); host code, no GPU involved
+int mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_t *w, uint32_t *h) {
+  if (!data || !rgba || !w || !h) return MI_INVALID_ARGUMENT;
+  std::vector<uint8_t> px;
+  const int st = png_decode_rgba(data, len, px, *w, *h);
+  if (st) return st;
+  *rgba = (uint8_t *)malloc(px.size()); memcpy(*rgba, px.data(), px.size());
+  return MI_OK;
+}
+
+// The reference's files.into_par_iter() (src/main.rs:223) over the GPUs of one node: images are independent, so a host
+// thread per device pulls runs of equally-shaped images from a shared cursor and pushes each run through one resident
+// batch (no collective, no cross-device traffic).  status[i] receives the per-image result; returns the first failure.
+int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev) {
+  if (!e || (n && (!in || !out))) return MI_INVALID_ARGUMENT;
+  const int have = mi_device_count();
+  std::vector<int> devs;
+  if (devices && ndev > 0) devs.assign(devices, devices + ndev); else for (int d = 0; d < have; d++) devs.push_back(d);
+  for (int d : devs) if (d < 0 || d >= have) { fprintf(stderr, "mi_avif: no HIP device %d (no CPU fallback)\n", d); return MI_NO_DEVICE; }
+  if (devs.empty()) { fprintf(stderr, "mi_avif: no HIP device (no CPU fallback)\n"); return MI_NO_DEVICE; }
+  std::vector<int> st(n, MI_OK);
+  for (size_t i = 0; i < n; i++) { out[i].avif_file = nullptr; out[i].avif_len = out[i].color_byte_size = out[i].alpha_byte_size = 0; }
+  std::atomic<size_t> cursor{ 0 };
+  const size_t max_run = 32;
+  auto worker = [&](int dev) {
+    mi_ravif_encoder enc = *e; enc.device = dev;
+    for (;;) {
+      // claim a run [i0, i1) of images with the same shape
+      size_t i0 = cursor.load(), i1;
+      do {
+        if (i0 >= n) return;
+        i1 = i0 + 1;
+        while (i1 < n && i1 - i0 < max_run && in[i1].width == in[i0].width && in[i1].height == in[i0].height && in[i1].channels == in[i0].channels) i1++;
+      } while (!cursor.compare_exchange_weak(i0, i1));
+      const mi_image_desc &d0 = in[i0];
+      int rc = (d0.pixels && d0.width && d0.height && (d0.channels == 3 || d0.channels == 4)) ? MI_OK : MI_INVALID_ARGUMENT;
+      mi_batch *b = rc == MI_OK ? mi_batch_create(&enc, (int)(i1 - i0), d0.width, d0.height, d0.channels) : nullptr;
+      if (rc == MI_OK && !b) rc = MI_ENCODING_ERROR;
+      for (size_t i = i0; i < i1 && rc == MI_OK; i++) rc = in[i].pixels ? mi_batch_upload(b, (int)(i - i0), in[i].pixels, in[i].stride_px ? in[i].stride_px : in[i].width) : MI_INVALID_ARGUMENT;
+      if (rc == MI_OK) rc = mi_batch_encode(b);
+      for (size_t i = i0; i < i1; i++) st[i] = rc == MI_OK ? mi_batch_get(b, (int)(i - i0), &out[i]) : rc;
+      if (b) mi_batch_destroy(b);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int d : devs) th.emplace_back(worker, d);
+  for (auto &t : th) t.join();
+  int first = MI_OK;
+  for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (first == MI_OK && st[i] != MI_OK) first = st[i]; }
+  return first;
+}
 int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgb, 3, w, h, stride_px, out); }
 
 // level 1: caller-supplied planes (encode_to_av1). Planes go straight into the frame's src[] (edge-replicated on the host).

@@ -269,6 +269,32 @@ class Encoder:
         return self._raw(load_library().mi_ravif_encode_raw_planes_10, np.uint16, planes, alpha, width, height, color_pixel_range, matrix_coefficients)
 
 
+class _ImageDesc(C.Structure):
+    _fields_ = [('pixels', C.c_void_p), ('width', C.c_uint32), ('height', C.c_uint32), ('stride_px', C.c_size_t), ('channels', C.c_int)]
+
+
+def encode_many(encoder, images, devices=None):
+    """mi_ravif_encode_batch: the reference's files.into_par_iter() (src/main.rs:223) over the node's GPUs.
+    images: list of HxWx3 / HxWx4 uint8 arrays (shapes may differ).  Returns a list of EncodedImage."""
+    L = load_library()
+    L.mi_ravif_encode_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    arrs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+    desc = (_ImageDesc * len(arrs))()
+    for d, a in zip(desc, arrs):
+        if a.ndim != 3 or a.shape[2] not in (3, 4):
+            raise AvifError(4)
+        d.pixels, d.width, d.height, d.stride_px, d.channels = a.ctypes.data, a.shape[1], a.shape[0], a.shape[1], a.shape[2]
+    out = (_EncodedImage * len(arrs))()
+    status = (C.c_int * len(arrs))()
+    dev = (C.c_int * len(devices))(*devices) if devices else None
+    e = encoder._c()
+    st = L.mi_ravif_encode_batch(C.byref(e), len(arrs), desc, out, status, dev, len(devices) if devices else 0)
+    res = [_take(o) if s == 0 else None for o, s in zip(out, status)]
+    if st:
+        raise AvifError(st)
+    return res
+
+
 class BatchEncoder:
     """Device-resident batch (the reference's files.into_par_iter(), src/main.rs:223): upload once, encode many."""
 

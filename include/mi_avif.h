@@ -76,6 +76,17 @@ int  mi_ravif_encode_rgb (const mi_ravif_encoder *e, const uint8_t *rgb,  uint32
 int  mi_ravif_encode_raw_planes_8 (const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint8_t  *yuv, const uint8_t  *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out);
 int  mi_ravif_encode_raw_planes_10(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const uint16_t *yuv, const uint16_t *alpha, uint8_t range, uint8_t matrix, mi_encoded_image *out);
 
+/* ---- many images, all GPUs of the node: the reference's files.into_par_iter() (src/main.rs:223) ----
+ * One host thread per device pulls runs of equally-shaped images and pushes each run through a resident batch; images are
+ * independent (no collective).  devices == NULL / ndev <= 0: every visible device.  status (nullable) gets one code per image;
+ * the return value is the first failure.  out[i].avif_file is malloc'd (mi_free). */
+typedef struct mi_image_desc { const uint8_t *pixels; uint32_t width, height; size_t stride_px /* 0 = width */; int channels /* 3 RGB8 | 4 RGBA8 */; } mi_image_desc;
+int  mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev);
+
+/* PNG -> RGBA8 as cavif's load_rgba does (src/main.rs:265-283: RGB gets alpha 255, 16-bit samples keep their high byte, gray is
+ * replicated); all colour types, bit depths, tRNS and Adam7.  Host code over zlib.  *rgba is malloc'd (mi_free), w*h*4 bytes. */
+int  mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_t *w, uint32_t *h);
+
 /* ---- batch: the data-parallel path (src/main.rs:223 files.into_par_iter()); images resident in HBM ---- */
 typedef struct mi_batch mi_batch;
 /* n images of w x h, channels 3 (RGB8) or 4 (RGBA8) on HIP device `e->device` */

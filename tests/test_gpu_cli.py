@@ -1,0 +1,89 @@
+"""-m gpu: the cavif command line replica (cavif_rs_amd/cli/cavif_mi.cpp over the C ABI) and mi_ravif_encode_batch
+against the library entry points they wrap: same bytes, the reference's report line, path and stdin/stdout rules
+(src/main.rs:110-252)."""
+import io
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+from tests.helpers.images import rgba_gradient
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, 'cavif_rs_amd', 'cavif_mi')
+Image = pytest.importorskip('PIL.Image')
+
+
+def _cli_encoder(quality=80.0, speed=4, dirty=False, depth=0, color=0):
+    import cavif_rs_amd as m
+    aq = min((quality + 100.0) / 2.0, quality + quality / 4.0 + 2.0)           # src/main.rs:115
+    e = m.Encoder().with_quality(quality).with_alpha_quality(aq).with_speed(speed).with_alpha_color_mode('dirty' if dirty else 'clean')
+    if depth:
+        e = e.with_bit_depth(depth)
+    if color:
+        e = e.with_internal_color_model('rgb')
+    return e
+
+
+def test_encode_many_equals_single_calls_and_oracle(oracle):
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    imgs = [synth_image(160, 96, index=1), synth_image(160, 96, index=2), synth_image(96, 160, index=3), synth_image(128, 64, index=4, alpha=True), synth_image(160, 96, index=5)]
+    e = m.Encoder().with_quality(70).with_speed(6)
+    got = m.encode_many(e, imgs, devices=[0])
+    for im, g in zip(imgs, got):
+        ref, _, _ = oracle.ravif_encode(im, quality=70, alpha_quality=80, speed=6)
+        assert g.avif_file == ref
+    again = m.encode_many(e, imgs)                                              # every visible device
+    assert [g.avif_file for g in again] == [g.avif_file for g in got]
+    with pytest.raises(m.AvifError):
+        m.encode_many(e, imgs, devices=[m.device_count() + 3])
+
+
+def test_cli_matches_library_and_reports_like_the_reference(tmp_path):
+    rgb = (np.add.outer(np.arange(72), np.arange(120))[..., None] * np.array([1, 2, 3])).astype(np.uint8)
+    rgba = rgba_gradient(96, 80)
+    Image.fromarray(rgb, 'RGB').save(tmp_path / 'one.png')
+    Image.fromarray(rgba, 'RGBA').save(tmp_path / 'two.png')
+    r = subprocess.run([CLI, str(tmp_path / 'one.png'), str(tmp_path / 'two.png')], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    e = _cli_encoder()
+    want_one = e.encode_rgba(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]))
+    want_two = e.encode_rgba(rgba)
+    assert (tmp_path / 'one.avif').read_bytes() == want_one.avif_file
+    assert (tmp_path / 'two.avif').read_bytes() == want_two.avif_file
+    lines = sorted(r.stdout.decode().strip().splitlines())
+    m1 = re.fullmatch(r'(.*one\.avif): (\d+)KB \((\d+)B color, (\d+)B alpha, (\d+)B HEIF\)', lines[0])
+    assert m1 and int(m1.group(2)) == -(-len(want_one.avif_file) // 1000) and int(m1.group(3)) == want_one.color_byte_size and int(m1.group(4)) == 0
+    assert int(m1.group(5)) == len(want_one.avif_file) - want_one.color_byte_size
+    m2 = re.fullmatch(r'(.*two\.avif): (\d+)KB \((\d+)B color, (\d+)B alpha, (\d+)B HEIF\)', lines[1])
+    assert m2 and int(m2.group(4)) == want_two.alpha_byte_size > 0
+    # second run: outputs exist -> skipped, exit 1, files untouched; -f overwrites
+    r = subprocess.run([CLI, '-q', str(tmp_path / 'one.png')], capture_output=True)
+    assert r.returncode == 1 and r.stdout == b'' and r.stderr == b''
+    r = subprocess.run([CLI, '-f', '-Q', '50', '-s', '7', '--depth', '8', str(tmp_path / 'one.png')], capture_output=True)
+    assert r.returncode == 0
+    want = _cli_encoder(50.0, 7, depth=8).encode_rgba(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]))
+    assert (tmp_path / 'one.avif').read_bytes() == want.avif_file
+
+
+def test_cli_output_directory_stdio_and_dirty_alpha(tmp_path):
+    rgba = rgba_gradient(64, 48)
+    Image.fromarray(rgba, 'RGBA').save(tmp_path / 'g.png')
+    Image.fromarray(rgba[::-1].copy(), 'RGBA').save(tmp_path / 'h.png')
+    outdir = tmp_path / 'out' / 'nested'
+    r = subprocess.run([CLI, '-o', str(outdir), '--dirty-alpha', '--color', 'rgb', str(tmp_path / 'g.png'), str(tmp_path / 'h.png')], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    e = _cli_encoder(dirty=True, color=1)
+    assert (outdir / 'g.avif').read_bytes() == e.encode_rgba(rgba).avif_file
+    assert (outdir / 'h.avif').read_bytes() == e.encode_rgba(rgba[::-1].copy()).avif_file
+    # stdin -> stdout, nothing else on stdout
+    r = subprocess.run([CLI, '-'], input=(tmp_path / 'g.png').read_bytes(), capture_output=True)
+    assert r.returncode == 0 and r.stdout == _cli_encoder().encode_rgba(rgba).avif_file
+    # single input with -o file
+    r = subprocess.run([CLI, '-o', str(tmp_path / 'named.avif'), str(tmp_path / 'g.png')], capture_output=True)
+    assert r.returncode == 0 and (tmp_path / 'named.avif').read_bytes() == _cli_encoder().encode_rgba(rgba).avif_file
+    im = Image.open(io.BytesIO((tmp_path / 'named.avif').read_bytes()))
+    assert im.size == (64, 48)
+
