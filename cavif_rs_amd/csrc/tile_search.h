@@ -15,6 +15,7 @@
 #include "dev_predict.h"
 #include "dev_txfm.h"
 #include "dev_rate.h"
+#include "dev_group.h"
 
 #ifndef MI_K1_INLINE
 #define MI_K1_INLINE
@@ -38,8 +39,14 @@
 template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32;
   uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
-  uint16_t pred[N * N], dcp[N * N], rec[2][N * N];
-  int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];      // cbuf doubles as the dequantised block
+  uint16_t pred[N * N], dcp[N * N];
+  union {                                          // one candidate at a time (all sizes) or four at a time (4x4 / 8x8, dev_group.h)
+    struct {
+      uint16_t rec[2][N * N];
+      int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];  // cbuf doubles as the dequantised block
+    };
+    GroupBuf8 grp[4];
+  };
   uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
 };
 template <int N> struct SharedScratch {          // shared by the waves of the tile
@@ -268,6 +275,43 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     PH(2);
   }
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
+  // 4x4 / 8x8: all (mode x tx type) trials of the block in ONE round, four per wave (one per 16-lane row, dev_group.h)
+  bool grouped = false; int my_g = 0;
+  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) {
+    grouped = pred_cached && ncand * ntx <= 16;
+    if (grouped) {
+      const int g = GROUP_ID, total = ncand * ntx;
+      int e;
+      if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W : (W < 3 ? W * 5 + 4 : -1);   // a wave's rows 0..2 share the tx type (no divergence in the 1-D networks)
+      else e = W * 4 + g;
+      const bool live = e >= 0 && e < total;
+      const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
+      const int delta = SH->ldelta[ci];
+      uint32_t mode_rate = ycost[m];
+      if (m >= V_PRED && m <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+      int ns2, set2;
+      const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
+      int txtype;
+      if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
+      else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
+      GroupRes gr;
+      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[0], SH->lpred[ci], 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
+                    tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, &gr);
+      long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
+      if (!live) j = J_INF;
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++) {
+        const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+        const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+        if (jg < my_j || (jg == my_j && eg < my_e)) {
+          my_j = jg; my_e = eg; my_g = gg;
+          my_mode = __builtin_amdgcn_readlane(m, gg * 16); my_delta = __builtin_amdgcn_readlane(delta, gg * 16); my_tx = __builtin_amdgcn_readlane(txtype, gg * 16);
+          my_tr.eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); my_tr.cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); my_tr.dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        }
+      }
+    }
+  }
+  if (!grouped)
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
     const int directional = m >= V_PRED && m <= D67_PRED;
@@ -302,12 +346,14 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const long long best_j = SH->wbest_j[win];
   if (W == win) {
     const int b = cur ^ 1;                                  // buffer holding this wave's best
-    commit_plane<BS>(f, 0, r, c, S->rec[b], S->qc[b], my_tr.eob, my_tr.cul, my_tr.dcc);
+    const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
+    if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
+    commit_plane<BS>(f, 0, r, c, best_rec, best_qc, my_tr.eob, my_tr.cul, my_tr.dcc);
     fill_map_dev(f->m_ymode, ms, r, c, n4, my_mode);
     fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
     fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
     fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
-    if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = S->rec[b][i];
+    if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
     if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; }
   }
   PH(7);
