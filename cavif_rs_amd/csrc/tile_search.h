@@ -364,8 +364,140 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const int best_mode = SH->lm_mode, best_delta = SH->lm_delta;
   long long total_j = best_j; int any_coef = SH->lm_eob > 0;
 
+  // ---- chroma, 4x4 / 8x8 blocks with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four
+  // waves (plane x half of the range), then every candidate of a plane in one grouped evaluation (dev_group.h) ----
+  bool cgrouped = false;
+  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) cgrouped = f->np > 1 && !f->complex_modes;
+  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (cgrouped) {
+    const uint16_t *uvcost = k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
+    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, f->reduced_tx_set);
+    const int bdelta = (best_mode >= V_PRED && best_mode <= D67_PRED && BS >= BS_8) ? best_delta : 0;
+    const int mx = (1 << f->bd) - 1;
+    {
+      // rdo_cfl_alpha (see the one-candidate path below for the scan order and the tie rule)
+      const int p = (W >> 1) + 1, half = W & 1;
+      const LDS uint16_t *luma = SH->luma_rec;
+      int lsum = 0;
+      for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
+      lsum = wave_sum_i32(lsum);
+      const int avg = round2_(lsum, 2 * log2w);
+      predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
+      long long best_sse = J_INF; int best_idx = 1 << 20;
+      if (half == 0) {
+        int e0 = 0;
+        for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
+        best_sse = (long long)wave_sum_i32(e0); best_idx = -1;
+      }
+      int e[16];
+#pragma unroll
+      for (int a = 0; a < 16; a++) e[a] = 0;
+      for (int idx = LANE; idx < nn; idx += 64) {
+        const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
+        const int la = iabs_(l), neg = l < 0;
+#pragma unroll
+        for (int kq = 0; kq < 8; kq++) {
+          const int mag = half * 8 + kq + 1;
+          const int rr = round2_(__mul24(mag, la), 6), sc = neg ? -rr : rr;
+          const int dp = sv - iclamp_(dcv + sc, 0, mx), dm = sv - iclamp_(dcv - sc, 0, mx);
+          e[2 * kq] += __mul24(dp, dp); e[2 * kq + 1] += __mul24(dm, dm);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 16; a++) {
+        const long long ea = (long long)wave_sum_i32(e[a]);
+        if (ea < best_sse) { best_sse = ea; best_idx = half * 16 + a; }
+      }
+      if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
+    }
+    PH(8);
+    WG_SYNC();
+    PH(2);
+    int alpha_u = 0, alpha_v = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) {
+      const int idx = SH->ca_sse[pp][1] < SH->ca_sse[pp][0] ? SH->ca_idx[pp][1] : SH->ca_idx[pp][0];
+      const int al = idx < 0 ? 0 : ((idx & 1) ? -((idx >> 1) + 1) : ((idx >> 1) + 1));
+      if (pp == 0) alpha_u = al; else alpha_v = al;
+    }
+    const int cfl_ok = alpha_u != 0 || alpha_v != 0;
+    GroupRes gr = { 0, 0, 0, 0, 0 };
+    if (W < 2) {
+      // wave 0: plane U, wave 1: plane V.  The candidates' predictions go side by side into S->pred (4 x 64 samples), then
+      // row g of the wave evaluates candidate g.
+      const int p = W + 1;
+      const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
+      predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
+      if (nplain == 2) predict_block(f, x, y, log2w, availL, availU, best_mode, bdelta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred + nn);
+      {
+        const int al = p == 1 ? alpha_u : alpha_v;
+        LDS uint16_t *cp = S->pred + (nc - 1) * nn;
+        int lsum = 0;
+        for (int idx = LANE; idx < nn; idx += 64) lsum += SH->luma_rec[idx] << 3;
+        lsum = wave_sum_i32(lsum);
+        const int avg = round2_(lsum, 2 * log2w);
+        for (int idx = LANE; idx < nn; idx += 64) {
+          const int l = ((int)SH->luma_rec[idx] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+          cp[idx] = (uint16_t)iclamp_((int)S->pred[idx] + sc, 0, mx);             // S->pred[0..nn) is the DC prediction
+        }
+      }
+      WAVE_SYNC();
+      const int g = GROUP_ID, cand = imin_(g, nc - 1);
+      const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
+      int txtype = mode_to_txtype(um);
+      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
+      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], S->pred + cand * nn, p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, &gr);
+      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
+    }
+    PH(9);
+    WG_SYNC();
+    PH(2);
+    long long best_uv = J_INF; int bc = 0, b_sign = 0;
+#pragma unroll
+    for (int cnd = 0; cnd < 3; cnd++) {
+      if (cnd < nc) {
+        const int is_cfl = cnd == nc - 1, um = is_cfl ? UV_CFL_PRED : (cnd == 0 ? DC_PRED : best_mode);
+        uint32_t mode_rate = uvcost[um];
+        int jsign = 0;
+        if (!is_cfl && cnd == 1 && um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + bdelta + 3];
+        if (is_cfl && cfl_ok) {
+          const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
+          jsign = su * 3 + sv - 1;
+          mode_rate += k.cost[CDF_CFL_SIGN + jsign];
+          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_u) - 1];
+          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_v) - 1];
+        }
+        if (!is_cfl || cfl_ok) {
+          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+          if (j < best_uv) { best_uv = j; bc = cnd; b_sign = jsign; }
+        }
+      }
+    }
+    if (W < 2) {
+      const int p = W + 1, chose_cfl = bc == nc - 1;
+      const int eob = __builtin_amdgcn_readlane(gr.eob, 0), eob1 = __builtin_amdgcn_readlane(gr.eob, 16), eob2 = __builtin_amdgcn_readlane(gr.eob, 32);
+      const int cul = __builtin_amdgcn_readlane(gr.cul, 0), cul1 = __builtin_amdgcn_readlane(gr.cul, 16), cul2 = __builtin_amdgcn_readlane(gr.cul, 32);
+      const int dcc = __builtin_amdgcn_readlane(gr.dcc, 0), dcc1 = __builtin_amdgcn_readlane(gr.dcc, 16), dcc2 = __builtin_amdgcn_readlane(gr.dcc, 32);
+      const int beob = bc == 0 ? eob : (bc == 1 ? eob1 : eob2), bcul = bc == 0 ? cul : (bc == 1 ? cul1 : cul2), bdcc = bc == 0 ? dcc : (bc == 1 ? dcc1 : dcc2);
+      commit_plane<BS>(f, p, r, c, S->grp[bc].rec, S->grp[bc].qc, beob, bcul, bdcc);
+      if (LANE == 0) SH->ceob[p - 1] = beob;
+      if (p == 1) {
+        const int buv = chose_cfl ? UV_CFL_PRED : (bc == 0 ? DC_PRED : best_mode);
+        fill_map_dev(f->m_uvmode, ms, r, c, n4, buv);
+        fill_map_dev((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)((!chose_cfl && bc == 1) ? bdelta : 0));
+        fill_map_dev(f->m_cfl_sign, ms, r, c, n4, chose_cfl ? b_sign : 0);
+        fill_map_dev(f->m_cfl_au, ms, r, c, n4, (chose_cfl && alpha_u) ? iabs_(alpha_u) - 1 : 0);
+        fill_map_dev(f->m_cfl_av, ms, r, c, n4, (chose_cfl && alpha_v) ? iabs_(alpha_v) - 1 : 0);
+      }
+    }
+    PH(10);
+    WG_SYNC();
+    PH(2);
+    any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
+    total_j += best_uv;
+  }
   // ---- chroma: candidate ci2 by wave pair (ci2 & 1), plane (W & 1) + 1 within the pair ----
-  if constexpr (NW >= 2) if (f->np > 1) {
+  if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
     const int cfl_allowed = BS <= BS_32;
     const uint16_t *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
