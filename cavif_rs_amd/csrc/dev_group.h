@@ -6,6 +6,7 @@
 // candidate, the 1-D networks use lane l < N of the group as column / row l, reductions stay inside the row (DPP
 // row_ror all-reduce).  Everything that is wave-uniform in the single-candidate code is row-uniform here.
 #pragma once
+#include "dev_predict.h"
 #include "dev_txfm.h"
 #include "dev_rate.h"
 
@@ -188,4 +189,118 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
 #pragma unroll
   for (int k = 0; k < IT; k++) { const int idx = gl + 16 * k; const int d = (int)src[idx] - (int)gb->rec[idx]; s += __mul24(d, d); }
   res->sse = row_sum_i32(s);                     // <= 64 * 1023^2 < 2^27
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Directional intra prediction + SATD, four predictions per wavefront (4x4 / 8x8 blocks): each 16-lane row runs one
+// prediction angle.  Same steps as predict_block()'s directional branch in dev_predict.h (spec 7.11.2.4: edge copies,
+// edge filter, edge upsampling, two-tap interpolation); the corner filter of that branch only exists for blocks of
+// 12 samples and more and is therefore absent here.
+struct GroupPredBuf { uint16_t wa[48], wl[48], tmp[32], pred[64]; };      // EDGE_OFF + 2*8 + 16 entries per edge
+
+__device__ __forceinline__ void edge_filter_group(LDS uint16_t *buf, int sz, int strength, LDS uint16_t *tmp, int gl) {
+  // row-uniform arguments; the syncs are executed by every row (strength 0 rows just pass through)
+  if (strength) for (int i = gl; i < sz; i += 16) tmp[i] = buf[i - 1];
+  WAVE_SYNC();
+  if (strength) for (int i = 1 + gl; i < sz; i += 16) {
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int k = iclamp_(i - 2 + j, 0, sz - 1);
+      const int kw = strength == 1 ? (j == 0 || j == 4 ? 0 : (j == 2 ? 8 : 4)) : (strength == 2 ? (j == 0 || j == 4 ? 0 : (j == 2 ? 6 : 5)) : (j == 0 || j == 4 ? 2 : 4));
+      s += kw * tmp[k];
+    }
+    buf[i - 1] = (uint16_t)((s + 8) >> 4);
+  }
+  WAVE_SYNC();
+}
+__device__ __forceinline__ void edge_upsample_group(LDS uint16_t *buf, int num_px, int on, int bd, LDS uint16_t *tmp, int gl) {
+  if (on) for (int i = gl; i < num_px + 3; i += 16) {
+    uint16_t v;
+    if (i == 0) v = buf[-1]; else if (i == num_px + 2) v = buf[num_px - 1]; else v = buf[i - 2];
+    tmp[i] = v;
+  }
+  WAVE_SYNC();
+  const int mx = (1 << bd) - 1;
+  if (on) {
+    if (gl == 0) buf[-2] = tmp[0];
+    for (int i = gl; i < num_px; i += 16) {
+      int s = -(int)tmp[i] + 9 * (int)tmp[i + 1] + 9 * (int)tmp[i + 2] - (int)tmp[i + 3];
+      s = iclamp_(round2_(s, 4), 0, mx);
+      buf[2 * i - 1] = (uint16_t)s;
+      buf[2 * i] = tmp[i + 2];
+    }
+  }
+  WAVE_SYNC();
+}
+
+// pa: prediction angle of this row (mode angle + 3 * delta), row-uniform.  Rows with live == false still walk the code
+// (pa = 90 keeps them cheap).  Output: gp->pred[N*N].
+template <int N>
+__device__ inline void predict_dir_group(const LDS FrameDev *f, int x, int y, int have_left, int have_above, int pa, int ftype,
+                                         const LDS uint16_t *ra, const LDS uint16_t *rl, LDS GroupPredBuf *gp) {
+  constexpr int log2w = N == 4 ? 2 : 3, nn = N * N;
+  const int gl = GROUP_LANE, bd = f->bd;
+  const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
+  LDS uint16_t *wa = gp->wa + EDGE_OFF, *wl = gp->wl + EDGE_OFF;
+  for (int i = gl; i < 2 * N + 1; i += 16) { wa[i - 1] = ra[i - 1]; wl[i - 1] = rl[i - 1]; }
+  WAVE_SYNC();
+  const int diag = pa != 90 && pa != 180;
+  {
+    const int st_a = (diag && have_above) ? edge_strength_dev(N, N, ftype, pa - 90) : 0;
+    const int num_a = imin_(N, max_x - x + 1) + (pa < 90 ? N : 0) + 1;
+    edge_filter_group(wa, num_a, st_a, gp->tmp, gl);
+    const int st_l = (diag && have_left) ? edge_strength_dev(N, N, ftype, pa - 180) : 0;
+    const int num_l = imin_(N, max_y - y + 1) + (pa > 180 ? N : 0) + 1;
+    edge_filter_group(wl, num_l, st_l, gp->tmp, gl);
+  }
+  const int up_a = edge_upsample_sel_dev(N, N, ftype, pa - 90);
+  edge_upsample_group(wa, N + (pa < 90 ? N : 0), up_a, bd, gp->tmp, gl);
+  const int up_l = edge_upsample_sel_dev(N, N, ftype, pa - 180);
+  edge_upsample_group(wl, N + (pa > 180 ? N : 0), up_l, bd, gp->tmp, gl);
+  int dx = 0, dy = 0;
+  if (pa < 90) dx = dr_deriv_dev(pa); else if (pa > 90 && pa < 180) dx = dr_deriv_dev(180 - pa);
+  if (pa > 90 && pa < 180) dy = dr_deriv_dev(pa - 90); else if (pa > 180) dy = dr_deriv_dev(270 - pa);
+  for (int idx = gl; idx < nn; idx += 16) {
+    const int i = idx >> log2w, j = idx & (N - 1);
+    int v;
+    if (pa < 90) {
+      const int max_base = (2 * N - 1) << up_a;
+      const int id = (i + 1) * dx, base = (id >> (6 - up_a)) + (j << up_a), sh = ((id << up_a) >> 1) & 0x1F;
+      v = base < max_base ? round2_(wa[base] * (32 - sh) + wa[base + 1] * sh, 5) : wa[max_base];
+    } else if (pa > 90 && pa < 180) {
+      int id = (j << 6) - (i + 1) * dx, base = id >> (6 - up_a);
+      if (base >= -(1 << up_a)) { const int sh = ((id << up_a) >> 1) & 0x1F; v = round2_(wa[base] * (32 - sh) + wa[base + 1] * sh, 5); }
+      else { id = (i << 6) - (j + 1) * dy; base = id >> (6 - up_l); const int sh = ((id << up_l) >> 1) & 0x1F; v = round2_(wl[base] * (32 - sh) + wl[base + 1] * sh, 5); }
+    } else if (pa > 180) {
+      const int id = (j + 1) * dy, base = (id >> (6 - up_l)) + (i << up_l), sh = ((id << up_l) >> 1) & 0x1F;
+      v = round2_(wl[base] * (32 - sh) + wl[base + 1] * sh, 5);
+    } else if (pa == 90) v = wa[j];
+    else v = wl[i];
+    gp->pred[idx] = (uint16_t)v;
+  }
+  WAVE_SYNC();
+}
+
+// 4x4-Hadamard SATD of one row's prediction (satd_dev with 16 lanes: one lane per column x group of four rows)
+template <int N> __device__ inline int satd_group(const LDS uint16_t *src, const LDS uint16_t *pred) {
+  constexpr int units = N * (N / 4);              // 16 for 8x8, 4 for 4x4: whole quads
+  const int u = GROUP_LANE;
+  int s = 0;
+  if (u < units) {
+    const int xx = u % N, o = (u / N) * 4 * N + xx;
+    const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + N] - (int)pred[o + N];
+    const int d2 = (int)src[o + 2 * N] - (int)pred[o + 2 * N], d3 = (int)src[o + 3 * N] - (int)pred[o + 3 * N];
+    const int a = d0 + d1, b = d0 - d1, c = d2 + d3, e = d2 - d3;
+    int t[4] = { a + c, b + e, a - c, b - e };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int v = __builtin_amdgcn_update_dpp(0, t[i], 0xB1, 0xF, 0xF, false);
+      v = (LANE & 1) ? v - t[i] : t[i] + v;
+      int w2 = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+      v = (LANE & 2) ? w2 - v : v + w2;
+      s += iabs_(v);
+    }
+  }
+  return row_sum_i32(s);
 }

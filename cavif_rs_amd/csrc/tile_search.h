@@ -46,6 +46,7 @@ template <int N> struct WaveScratch {            // private to one wavefront
       int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];  // cbuf doubles as the dequantised block
     };
     GroupBuf8 grp[4];
+    GroupPredBuf gpred[4];                         // four directional predictions at a time (SATD stages of 4x4 / 8x8 blocks)
   };
   uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
 };
@@ -203,9 +204,34 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
+  constexpr bool SMALL_GROUPED = BS <= BS_8 && NW == 4 && MAXN <= 16;
+  const int mode_angle_t[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
+  if constexpr (SMALL_GROUPED) {
+    // 4x4 / 8x8: the eight directional modes run four per wave (one prediction angle per 16-lane row, dev_group.h) on
+    // waves 0 and 1 -- rows sorted so that a wave's rows mostly share the interpolation branch --, the five others
+    // wave-wide on waves 2 and 3
+    if (W < 2) {
+      const int g = GROUP_ID;
+      const int m = W == 0 ? (g == 0 ? V_PRED : g == 1 ? H_PRED : g == 2 ? D45_PRED : D67_PRED) : D135_PRED + g;
+      LDS GroupPredBuf *gp = &S->gpred[g];
+      predict_dir_group<n>(f, x, y, availL, availU, mode_angle_t[m], ftype_y, ra, rl, gp);
+      const int sd = satd_group<n>(SH->srcb[0], gp->pred);
+      if (GROUP_LANE == 0) SH->satd[m] = (long long)sd;
+    } else {
+      const int deal = W == 2 ? 0xFC90 : 0xFFBA;          // DC, SMOOTH, PAETH | SMOOTH_V, SMOOTH_H
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int m = (deal >> (4 * i)) & 15;
+        if (m < 13) {
+          predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+          const long long sd = satd_dev(SH->srcb[0], S->pred, n);
+          if (LANE == 0) SH->satd[m] = sd;
+        }
+      }
+    }
+  } else if constexpr (NW == 4) {
   // dealt by cost rather than round-robin: the six diagonal modes (edge filter + interpolation) weigh about three
   // cheap ones, so each wave gets 2 + 1, 2 + 1, 1 + 3 and 1 + 2 of them
-  if constexpr (NW == 4) {
     const int deal = W == 0 ? 0x0F043 : W == 1 ? 0x0F165 : W == 2 ? 0x2C97 : 0x0FBA8;     // four mode nibbles per wave, 0xF = none
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -240,7 +266,30 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
   const int dl[6] = { -1, 1, -2, 2, -3, 3 };
   const int refine = BS >= BS_8 && f->fine_directional;
-  if (refine) {
+  bool refine_grouped = false;
+  if constexpr (SMALL_GROUPED) refine_grouped = refine && ncand == 3;
+  if constexpr (SMALL_GROUPED) if (refine_grouped) {
+    // 18 (candidate, delta) probes in 16 + 2 rows: waves 0..2 take deltas -1, 1, -2, 2 of candidate W, wave 3 takes the
+    // +-3 probes of candidates 0 and 1, then those of candidate 2
+    const int g = GROUP_ID;
+    for (int pass = 0; pass < (W == 3 ? 2 : 1); pass++) {
+      int ci, q;
+      if (W < 3) { ci = W; q = g; } else if (pass == 0) { ci = g >> 1; q = 4 + (g & 1); } else { ci = 2; q = 4 + (g & 1); }
+      const int m = SH->order[ci];
+      const bool live = m >= V_PRED && m <= D67_PRED && !(W == 3 && pass == 1 && g >= 2);
+      const int m1 = SH->order[W < 3 ? W : (pass == 0 ? 0 : 2)], m2 = SH->order[W == 3 && pass == 0 ? 1 : (W < 3 ? W : 2)];
+      if ((m1 >= V_PRED && m1 <= D67_PRED) || (m2 >= V_PRED && m2 <= D67_PRED)) {          // wave-uniform: anything to do in this pass?
+        LDS GroupPredBuf *gp = &S->gpred[g];
+        predict_dir_group<n>(f, x, y, availL, availU, live ? mode_angle_t[m] + 3 * dl[q] : 90, ftype_y, ra, rl, gp);
+        const int sd = satd_group<n>(SH->srcb[0], gp->pred);
+        if (live && GROUP_LANE == 0) SH->dsd[ci][q] = (long long)sd;
+      }
+    }
+    PH(5);
+    WG_SYNC();
+    PH(2);
+  }
+  if (refine && !refine_grouped) {
     for (int u = W; u < ncand * 6; u += NW) {
       const int ci = u / 6, q = u - ci * 6, m = SH->order[ci];
       if (m >= V_PRED && m <= D67_PRED) {
