@@ -144,6 +144,13 @@ template <int MAXBS, int NW> static hipError_t launch_search_t(const FrameDev *d
   return hipGetLastError();
 }
 // jobs must all belong to frames of the same block-size class
+// K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
+static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(64), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+  else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(64), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+  return hipGetLastError();
+}
 static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   if (maxbs <= 2) return launch_search_t<2, 4>(d_frames, d_jobs, njobs, s);
@@ -403,7 +410,8 @@ int mi_batch_encode_async(mi_batch *b) {
   HIP_OK(hipGetLastError());
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
-  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), sizeof(EntropyLds), s, b->d_frames, b->d_jobs, njobs, b->d_precarry, b->pre_cap);
+  for (int cls = 2; cls <= 4; cls++)
+    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * b->pre_cap, b->pre_cap, s));
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -598,7 +606,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   DBG_STAGE("deblock");
   hipLaunchKernelGGL(cdef_kernel, dim3(p.sb_cols * p.sb_rows, 1), dim3(256), 0, s, d_frame, 1);
   DBG_STAGE("cdef");
-  hipLaunchKernelGGL(tile_entropy_kernel, dim3(njobs), dim3(64), sizeof(EntropyLds), s, d_frame, d_jobs, njobs, d_pre, cap);
+  HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   DBG_STAGE("entropy");
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);

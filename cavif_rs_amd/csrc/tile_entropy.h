@@ -84,7 +84,7 @@ struct TileWriter {
   const FrameDev *f; TileB t; RangeEncDev ec; LDS uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
   LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient records of the current transform block
-  LDS uint8_t *cdef_done;                                           // LDS [<= 64 SBs of this tile]... indexed by local sb
+  int cdef_pending;                                                 // the 64x64 superblock being walked has not signalled its cdef_idx yet
   int sb_cols_tile;
 };
 
@@ -155,8 +155,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
     re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
     if (!skip && f->enable_cdef) {
-      const int lsb = ((r - t->mi_row_start) >> 4) * w->sb_cols_tile + ((c - t->mi_col_start) >> 4);
-      if (!w->cdef_done[lsb]) { WAVE_SYNC(); if (LANE == 0) w->cdef_done[lsb] = 1; WAVE_SYNC(); re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }
+      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
     const int *imc = intra_mode_ctx_tab();
     const int am = imc[availU ? f->m_ymode[mi - ms] : DC_PRED], lm = imc[availL ? f->m_ymode[mi - 1] : DC_PRED];
@@ -230,8 +229,9 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
 
 // Iterative Z-order walk of one superblock (explicit stack, depth <= 5) so that every block-size instance of
 // write_block_dev is inlined exactly once and the range-coder state stays in registers.
-__device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) {
+template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) {
   const FrameDev *f = w->f;
+  w->cdef_pending = 1;
   int sr[5], sc[5], sk[5];
   int sp = 0; sr[0] = r0; sc[0] = c0; sk[0] = 0;
   while (sp >= 0) {
@@ -247,8 +247,8 @@ __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) 
           case 0: write_block_dev<0>(w, r, c); break;
           case 1: write_block_dev<1>(w, r, c); break;
           case 2: write_block_dev<2>(w, r, c); break;
-          case 3: write_block_dev<3>(w, r, c); break;
-          default: write_block_dev<4>(w, r, c); break;
+          case 3: if constexpr (MAXBS >= 3) write_block_dev<3>(w, r, c); break;
+          default: if constexpr (MAXBS >= 4) write_block_dev<4>(w, r, c); break;
         }
         sp--; continue;
       }
@@ -267,19 +267,22 @@ __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) 
 // <= 128 registers per lane, so that an entropy wave fits the slot one finished search workgroup frees on a SIMD and
 // batch A's entropy coding can run next to batch B's search instead of waiting for its tail
 // (dynamic LDS: with a compile-time LDS size that caps the occupancy the compiler pads the VGPR allocation to 176)
-struct EntropyLds {
+// LDS sized by the largest block the launch can meet (MAXBS 2: 16x16 -> 15.5 KB, so two entropy workgroups fit the LDS one
+// finished search workgroup frees; MAXBS 4: 32x32 coded coefficients -> 28 KB)
+template <int CS> struct EntropyLds {
   uint16_t cdf[CDF_TOTAL];
-  int32_t qc[32 * 32];
-  uint8_t lev[36 * 36 + 4];
-  uint16_t scans[1360];
-  uint16_t rec_off[1024], rec_br[1024];
-  uint32_t rec_lv[1024];
-  uint8_t cdef_done[MI_MAX_TILE_COLS * MI_MAX_TILE_ROWS > 4096 ? 4096 : 4096];
+  int32_t qc[CS * CS];
+  uint8_t lev[(CS + 4) * (CS + 4) + 4];
+  uint16_t scans[SCAN_LDS_ENTRIES(CS)];
+  uint16_t rec_off[CS * CS], rec_br[CS * CS];
+  uint32_t rec_lv[CS * CS];
 };
 
+template <int MAXBS>
 __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames, const TileJob *jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
-  extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds), passed at launch
-  EntropyLds &L = *(EntropyLds *)k4_smem;
+  constexpr int CS = MAXBS <= 2 ? 16 : 32;
+  extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
+  EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
   const int job = blockIdx.x;
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
@@ -288,18 +291,17 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   w.f = f;
   w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_done = (LDS uint8_t *)L.cdef_done; w.ls = (LDS uint16_t *)L.scans;
+  w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
   w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
-  load_scans_to_lds((LDS uint16_t *)L.scans, 32);
+  load_scans_to_lds((LDS uint16_t *)L.scans, CS);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
-  for (int i = LANE; i < 4096; i += 64) L.cdef_done[i] = 0;
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
   const unsigned long long clk0 = wall_clock64();
   WAVE_SYNC();
   for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
     for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
-      write_superblock(&w, r, c);
+      write_superblock<MAXBS>(&w, r, c);
   WAVE_SYNC();
   if (LANE == 0) {
     const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
