@@ -56,8 +56,8 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t luma_rec[N * N];
   long long satd[13], dsd[7][6];
   long long wbest_j[4], cj[16][2], pbest_j[2];
-  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16], ldelta[3];
-  uint16_t lpred[N <= 16 ? 3 : 1][N <= 16 ? N * N : 4];        // final luma predictions of the surviving modes (blocks <= 16x16)
+  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16], ldelta[7];
+  uint16_t lpred[N <= 16 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
 #if MI_PROFILE
@@ -307,7 +307,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
   // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
-  const bool pred_cached = MAXN <= 16 && ncand <= 3 && NW > 1;
+  const bool pred_cached = MAXN <= 16 && NW > 1 && ncand * nn <= 768;
   if (pred_cached) {
     for (int ci = NW - 1 - W; ci < ncand; ci += NW) {          // waves 3, 2, 1
       const int m = SH->order[ci];
@@ -316,7 +316,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         long long bsd = SH->satd[m];
         for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
       }
-      predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, SH->lpred[ci]);
+      predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, SH->lpred + ci * nn);
       if (LANE == 0) SH->ldelta[ci] = delta;
     }
     PH(12);
@@ -324,38 +324,49 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     PH(2);
   }
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
-  // 4x4 / 8x8: all (mode x tx type) trials of the block in ONE round, four per wave (one per 16-lane row, dev_group.h)
-  bool grouped = false; int my_g = 0;
+  // 4x4 / 8x8: the (mode x tx type) trials of the block sixteen at a time, four per wave (one per 16-lane row, dev_group.h):
+  // ONE round for the 3 x 5 trials of speed 4, two for 3 x 7, four for 7 x 7.  Between rounds a wave parks its best
+  // candidate's reconstruction and levels in S->dcp (idle during the luma trials).
+  bool grouped = false, parked = false; int my_g = 0;
   if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) {
-    grouped = pred_cached && ncand * ntx <= 16;
+    grouped = pred_cached;
     if (grouped) {
-      const int g = GROUP_ID, total = ncand * ntx;
-      int e;
-      if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W : (W < 3 ? W * 5 + 4 : -1);   // a wave's rows 0..2 share the tx type (no divergence in the 1-D networks)
-      else e = W * 4 + g;
-      const bool live = e >= 0 && e < total;
-      const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
-      const int delta = SH->ldelta[ci];
-      uint32_t mode_rate = ycost[m];
-      if (m >= V_PRED && m <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
-      int ns2, set2;
-      const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
-      int txtype;
-      if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
-      else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
-      GroupRes gr;
-      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[0], SH->lpred[ci], 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
-                    tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, &gr);
-      long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
-      if (!live) j = J_INF;
+      const int g = GROUP_ID, total = ncand * ntx, rounds = (total + 15) >> 4;
+      LDS uint16_t *park_rec = (LDS uint16_t *)S->dcp; LDS int32_t *park_qc = (LDS int32_t *)(S->dcp + 64);
+      for (int rd = 0; rd < rounds; rd++) {
+        int e;
+        if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W : (W < 3 ? W * 5 + 4 : -1);   // a wave's rows 0..2 share the tx type (no divergence in the 1-D networks)
+        else e = rd * 16 + W * 4 + g;
+        const bool live = e >= 0 && e < total;
+        const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
+        const int delta = SH->ldelta[ci];
+        uint32_t mode_rate = ycost[m];
+        if (m >= V_PRED && m <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+        int ns2, set2;
+        const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
+        int txtype;
+        if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
+        else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
+        GroupRes gr;
+        eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
+                      tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, &gr);
+        long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        if (!live) j = J_INF;
+        bool improved = false;
 #pragma unroll
-      for (int gg = 0; gg < 4; gg++) {
-        const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
-        const int eg = __builtin_amdgcn_readlane(e, gg * 16);
-        if (jg < my_j || (jg == my_j && eg < my_e)) {
-          my_j = jg; my_e = eg; my_g = gg;
-          my_mode = __builtin_amdgcn_readlane(m, gg * 16); my_delta = __builtin_amdgcn_readlane(delta, gg * 16); my_tx = __builtin_amdgcn_readlane(txtype, gg * 16);
-          my_tr.eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); my_tr.cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); my_tr.dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        for (int gg = 0; gg < 4; gg++) {
+          const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+          const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+          if (jg < my_j || (jg == my_j && eg < my_e)) {
+            my_j = jg; my_e = eg; my_g = gg; improved = true;
+            my_mode = __builtin_amdgcn_readlane(m, gg * 16); my_delta = __builtin_amdgcn_readlane(delta, gg * 16); my_tx = __builtin_amdgcn_readlane(txtype, gg * 16);
+            my_tr.eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); my_tr.cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); my_tr.dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+          }
+        }
+        if (rounds > 1 && improved) {                      // wave-uniform
+          for (int i = LANE; i < nn; i += 64) { park_rec[i] = S->grp[my_g].rec[i]; park_qc[i] = S->grp[my_g].qc[i]; }
+          parked = true;
+          WAVE_SYNC();
         }
       }
     }
@@ -366,7 +377,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     const int directional = m >= V_PRED && m <= D67_PRED;
     int delta = 0;
     const LDS uint16_t *lpred = S->pred;
-    if (pred_cached) { delta = SH->ldelta[ci]; lpred = SH->lpred[ci]; }
+    if (pred_cached) { delta = SH->ldelta[ci]; lpred = SH->lpred + ci * nn; }
     else {
       if (directional && refine) {
         long long bsd = SH->satd[m];
@@ -396,7 +407,10 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   if (W == win) {
     const int b = cur ^ 1;                                  // buffer holding this wave's best
     const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
-    if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
+    if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) {
+      if (parked) { best_rec = (const LDS uint16_t *)S->dcp; best_qc = (const LDS int32_t *)(S->dcp + 64); }
+      else { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
+    }
     commit_plane<BS>(f, 0, r, c, best_rec, best_qc, my_tr.eob, my_tr.cul, my_tr.dcc);
     fill_map_dev(f->m_ymode, ms, r, c, n4, my_mode);
     fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
