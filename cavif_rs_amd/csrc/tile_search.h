@@ -484,12 +484,12 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     }
     const int cfl_ok = alpha_u != 0 || alpha_v != 0;
     GroupRes gr = { 0, 0, 0, 0, 0 };
-    if (W < 2) {
-      // wave 0: plane U, wave 1: plane V.  The candidates' predictions go side by side into S->pred (4 x 64 samples), then
+    const int cw = (W & 1) == 0;                              // waves 0 (plane U) and 2 (plane V): their S->dcp already holds the plane's DC prediction
+    if (cw) {
+      // The candidates' predictions go side by side into S->pred (4 x 64 samples; candidate 0 = DC stays in S->dcp), then
       // row g of the wave evaluates candidate g.
-      const int p = W + 1;
+      const int p = (W >> 1) + 1;
       const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
-      predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
       if (nplain == 2) predict_block(f, x, y, log2w, availL, availU, best_mode, bdelta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred + nn);
       {
         const int al = p == 1 ? alpha_u : alpha_v;
@@ -500,7 +500,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         const int avg = round2_(lsum, 2 * log2w);
         for (int idx = LANE; idx < nn; idx += 64) {
           const int l = ((int)SH->luma_rec[idx] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-          cp[idx] = (uint16_t)iclamp_((int)S->pred[idx] + sc, 0, mx);             // S->pred[0..nn) is the DC prediction
+          cp[idx] = (uint16_t)iclamp_((int)S->dcp[idx] + sc, 0, mx);
         }
       }
       WAVE_SYNC();
@@ -508,7 +508,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], S->pred + cand * nn, p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, &gr);
+      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, &gr);
       const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }
@@ -536,8 +536,8 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         }
       }
     }
-    if (W < 2) {
-      const int p = W + 1, chose_cfl = bc == nc - 1;
+    if (cw) {
+      const int p = (W >> 1) + 1, chose_cfl = bc == nc - 1;
       const int eob = __builtin_amdgcn_readlane(gr.eob, 0), eob1 = __builtin_amdgcn_readlane(gr.eob, 16), eob2 = __builtin_amdgcn_readlane(gr.eob, 32);
       const int cul = __builtin_amdgcn_readlane(gr.cul, 0), cul1 = __builtin_amdgcn_readlane(gr.cul, 16), cul2 = __builtin_amdgcn_readlane(gr.cul, 32);
       const int dcc = __builtin_amdgcn_readlane(gr.dcc, 0), dcc1 = __builtin_amdgcn_readlane(gr.dcc, 16), dcc2 = __builtin_amdgcn_readlane(gr.dcc, 32);
