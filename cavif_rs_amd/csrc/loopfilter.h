@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
           int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
           const int v = (pri == 0 && sec == 0) ? un : cdef_apply_taps(un, tap, valid, pri, sec, damping, cs);
           const int d = v - sv;
-          const long long sse = wave_sum_i64((long long)__mul24(d, d));
+          const long long sse = (long long)wave_sum_i32(__mul24(d, d));          // 64 samples * 1023^2 < 2^26
           cst[idx] += (sse * f->wq[p]) >> 5;
         }
       }
