@@ -274,3 +274,15 @@ def test_entry_points_are_reentrant(oracle):
     for t in th: t.start()
     for t in th: t.join()
     assert out == ref
+
+
+@pytest.mark.parametrize('quality,depth,speed,idx', [(50, 8, 4, 11), (95, 10, 4, 12), (65, 10, 3, 13), (35, 8, 2, 14), (88, 10, 6, 15)])
+def test_quarter_hd_across_qualities_equals_oracle(oracle, quality, depth, speed, idx):
+    """960x540 synthetic photographs across the quality range (low quality switches LRF/CDEF flags and 64x64 partitions on,
+    high quality caps blocks at 16x16 and doubles the tile size), both depths, speeds around the bench preset."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(960, 540, index=idx)
+    got = m.Encoder().with_quality(quality).with_speed(speed).with_bit_depth(depth).encode_rgb(img)
+    ref, _, _ = oracle.ravif_encode(img, quality=quality, speed=speed, depth=depth)
+    assert got.avif_file == ref
