@@ -34,7 +34,7 @@ struct FrameDev {
   uint32_t dc_recip[3], ac_recip[3];          // floor((2^32 - 1) / q): quantisation divides by multiply-high + one fix-up
   long long rdmult, wq[3];
   // tools
-  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, enable_cdef;
+  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, enable_cdef, fast_deblock;
   // tiles (SB units)
   int tile_cols, tile_rows, tile_cols_log2, tile_rows_log2;
   int tile_col_start[MI_MAX_TILE_COLS + 1], tile_row_start[MI_MAX_TILE_ROWS + 1];
@@ -43,6 +43,8 @@ struct FrameDev {
   const uint16_t *cdf0;      // [CDF_TOTAL]
   // loop filter / cdef
   int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
+  long long *lf_tally;       // deblock level search: [3 planes][2 passes][65] SSE-delta difference arrays (zeroed per encode)
+  int *lf_out;               // the frame's 4 chosen levels, read back by the host for the frame header
   // per-tile scratch + outputs
   uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
   uint8_t *tile_out;         // per tile: tile_out_cap bytes

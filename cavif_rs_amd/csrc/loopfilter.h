@@ -59,6 +59,102 @@ __device__ inline void filter_edge_sample_dev(uint16_t *px, int step, int filter
 #undef PX_Q
 }
 
+// Edge geometry shared by the level search and the filter: thread id -> (r, c, line i); returns the filter size or 0.
+__device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pass, long long tid, int *r_, int *c_, int *i_) {
+  int r, c, i;
+  if (pass == 0) {       // consecutive threads walk mi columns of one pixel row
+    const int line = (int)(tid / f->mi_cols); c = (int)(tid % f->mi_cols); r = line >> 2; i = line & 3;
+  } else {               // consecutive threads walk pixel columns of one mi row
+    const int col_px = (int)(tid % (f->mi_cols * 4)); r = (int)(tid / (f->mi_cols * 4)); c = col_px >> 2; i = col_px & 3;
+  }
+  *r_ = r; *c_ = c; *i_ = i;
+  if (r >= f->mi_rows || c >= f->mi_cols) return 0;
+  const int x = c * 4, y = r * 4;
+  if (x >= f->w || y >= f->h) return 0;
+  if (pass == 0 && c == 0) return 0;
+  if (pass == 1 && r == 0) return 0;
+  const int ms = f->mi_stride;
+  const int cur = imin_(64, 4 << f->m_bsize[r * ms + c]);
+  if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;
+  const int prev = pass == 0 ? imin_(64, 4 << f->m_bsize[r * ms + c - 1]) : imin_(64, 4 << f->m_bsize[(r - 1) * ms + c]);
+  const int base = imin_(cur, prev);
+  return plane == 0 ? imin_(16, base) : imin_(8, base);
+}
+
+// K2a: deblock level search (rav1e deblock_filter_optimize with fast_deblock == false; oracle/av1o_filters.c
+// deblock_tally_line).  One thread per edge line, judged on the unfiltered reconstruction: with sharpness 0 the filter of a
+// line is off below the smallest level Lmin that passes the masks and can only change where L >> 4 changes, so a line adds at
+// most four (level range, SSE delta) pairs to the (plane, pass) difference array -- LDS first, then one global atomic per
+// non-zero entry and workgroup.  grid = (line chunks, plane * 2 + pass, frame).
+__global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *frames, int nframes) {
+  const FrameDev *f = frames + blockIdx.z;
+  const int plane = blockIdx.y >> 1, pass = blockIdx.y & 1;
+  if (plane >= f->np || f->fast_deblock) return;
+  __shared__ long long ldiff[65];
+  if (threadIdx.x < 65) ldiff[threadIdx.x] = 0;
+  __syncthreads();
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int r, c, i;
+  const int fsz = deblock_edge(f, plane, pass, tid, &r, &c, &i);
+  if (fsz) {
+    const int s8 = f->bd - 8, half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8), one = 1 << s8;
+    const int step = pass == 0 ? 1 : f->stride;
+    const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
+    const uint16_t *rec = f->rec[plane] + o, *src = f->src[plane] + o;
+    int R[16], S[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int q = k - 8; const bool in = q >= -half && q < half; R[k] = in ? (int)rec[(long long)q * step] : 0; S[k] = in ? (int)src[(long long)q * step] : 0; }
+    const int flen = fsz == 4 ? 4 : (plane != 0 ? 6 : (fsz == 8 ? 8 : 16));
+    int dmax = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
+    if (flen >= 6) dmax = imax_(dmax, imax_(iabs_(R[5] - R[6]), iabs_(R[10] - R[9])));
+    if (flen >= 8) dmax = imax_(dmax, imax_(iabs_(R[4] - R[5]), iabs_(R[11] - R[10])));
+    const int b = iabs_(R[7] - R[8]) * 2 + iabs_(R[6] - R[9]) / 2;
+    const int B = (b + one - 1) >> s8;
+    const int lmin = imax_(1, imax_((dmax + one - 1) >> s8, B > 4 ? (B - 2) / 3 : 0));
+    if (lmin <= 63) {
+      int sse0 = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const int d = R[k] - S[k]; sse0 += d * d; }
+      for (int a = lmin; a < 64; a = (a | 15) + 1) {
+        const int bnd = imin_(64, (a | 15) + 1);
+        uint16_t t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = (uint16_t)R[k];
+        filter_edge_sample_dev(t + 8, 1, fsz, plane, a, 0, f->bd);
+        int sse = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const int d = (int)t[k] - S[k]; sse += d * d; }
+        const long long dl = (long long)(sse - sse0);
+        if (dl) { atomicAdd((unsigned long long *)&ldiff[a], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[bnd], (unsigned long long)(-dl)); }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 65 && ldiff[threadIdx.x]) atomicAdd((unsigned long long *)&f->lf_tally[(plane * 2 + pass) * 65 + threadIdx.x], (unsigned long long)ldiff[threadIdx.x]);
+}
+// one thread per frame: prefix sums -> level per (luma vertical, luma horizontal, U, V); lowest level wins ties
+__global__ void deblock_pick_kernel(FrameDev *frames, int nframes) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nframes) return;
+  FrameDev *f = frames + k;
+  if (!f->fast_deblock) {
+    int lv[4] = { 0, 0, 0, 0 };
+    for (int pass = 0; pass < 2; pass++) {
+      long long acc = 0, best = 0; int bl = 0;
+      for (int l = 0; l < 64; l++) { acc += f->lf_tally[pass * 65 + l]; if (acc < best) { best = acc; bl = l; } }
+      lv[pass] = bl;
+    }
+    for (int plane = 1; plane < f->np; plane++) {
+      long long a0 = 0, a1 = 0, best = 0; int bl = 0;
+      for (int l = 0; l < 64; l++) { a0 += f->lf_tally[(plane * 2) * 65 + l]; a1 += f->lf_tally[(plane * 2 + 1) * 65 + l]; if (a0 + a1 < best) { best = a0 + a1; bl = l; } }
+      lv[plane + 1] = bl;
+    }
+    if (!lv[0] && !lv[1]) lv[2] = lv[3] = 0;
+    for (int i = 0; i < 4; i++) f->lf_level[i] = lv[i];
+  }
+  for (int i = 0; i < 4; i++) f->lf_out[i] = f->lf_level[i];
+}
+
 // pass 0: vertical edges (filter along x), pass 1: horizontal edges.  One thread per (plane, line, mi col).
 __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *frames, int nframes, int pass) {
   const FrameDev *f = frames + blockIdx.z;
@@ -68,22 +164,9 @@ __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *frames, in
   if (!L) return;
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int r, c, i;
-  if (pass == 0) {       // consecutive threads walk mi columns of one pixel row
-    const int line = (int)(tid / f->mi_cols); c = (int)(tid % f->mi_cols); r = line >> 2; i = line & 3;
-  } else {               // consecutive threads walk pixel columns of one mi row
-    const int col_px = (int)(tid % (f->mi_cols * 4)); r = (int)(tid / (f->mi_cols * 4)); c = col_px >> 2; i = col_px & 3;
-  }
-  if (r >= f->mi_rows || c >= f->mi_cols) return;
+  const int fsz = deblock_edge(f, plane, pass, tid, &r, &c, &i);
+  if (!fsz) return;
   const int x = c * 4, y = r * 4;
-  if (x >= f->w || y >= f->h) return;
-  if (pass == 0 && c == 0) return;
-  if (pass == 1 && r == 0) return;
-  const int ms = f->mi_stride;
-  const int cur = imin_(64, 4 << f->m_bsize[r * ms + c]);
-  if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return;
-  const int prev = pass == 0 ? imin_(64, 4 << f->m_bsize[r * ms + c - 1]) : imin_(64, 4 << f->m_bsize[(r - 1) * ms + c]);
-  const int base = imin_(cur, prev);
-  const int fsz = plane == 0 ? imin_(16, base) : imin_(8, base);
   uint16_t *px = pass == 0 ? f->rec[plane] + (size_t)(y + i) * f->stride + x : f->rec[plane] + (size_t)y * f->stride + x + i;
   filter_edge_sample_dev(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);
 }

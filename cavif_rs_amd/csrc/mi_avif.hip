@@ -61,6 +61,10 @@ struct FramePlan {
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct FramePlan;
+static size_t zeroed_bytes(const FramePlan &p);
+
+static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + 6 * 65 * sizeof(long long); }
 
 static void plan_geometry(FramePlan &p) {
   const mi_av1_config &c = p.cfg;
@@ -90,7 +94,10 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     d.m_lvl[i] = take(nmi); d.m_dc[i] = take(nmi); d.m_eob[i] = (uint16_t *)take(nmi * 2);
   }
   d.m_bsize = take(nmi); d.m_skip = take(nmi); d.m_ymode = take(nmi); d.m_uvmode = take(nmi); d.m_txtype = take(nmi);
-  d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi); d.m_decoded = take(nmi);
+  d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi);
+  // state the kernels expect zeroed before every encode, in one block (one memset): decoded flags + deblock tallies
+  d.m_decoded = take(zeroed_bytes(p)); d.lf_tally = (long long *)(d.m_decoded + align_up(nmi, 256));
+  d.lf_out = (int *)take(64);
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
   d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
@@ -118,13 +125,14 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
   for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
-  d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef;
+  d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef; d.fast_deblock = c.fast_deblock;
   d.tile_cols = p.tiles.cols; d.tile_rows = p.tiles.rows; d.tile_cols_log2 = p.tiles.cols_log2; d.tile_rows_log2 = p.tiles.rows_log2;
   for (int i = 0; i <= p.tiles.cols; i++) d.tile_col_start[i] = p.tiles.col_start[i];
   for (int i = 0; i <= p.tiles.rows; i++) d.tile_row_start[i] = p.tiles.row_start[i];
   d.cost = tab.cost[p.q.qctx]; d.cdf0 = tab.cdf0[p.q.qctx];
   d.dbg = getenv("MI_DEBUG_LEVEL") ? atoi(getenv("MI_DEBUG_LEVEL")) : 0;
-  const int lvl = deblock_level_from_q(p.q.ac_q[0], c.bit_depth);
+  // fast_deblock: the q formula; otherwise K2a searches the levels on the device and the host reads them back for the header
+  const int lvl = c.fast_deblock ? deblock_level_from_q(p.q.ac_q[0], c.bit_depth) : 0;
   d.lf_level[0] = d.lf_level[1] = d.lf_level[2] = d.lf_level[3] = lvl; d.lf_sharp = 0;
   static const int strengths[8] = { 0, 1 * 4 + 0, 2 * 4 + 1, 3 * 4 + 1, 5 * 4 + 2, 7 * 4 + 3, 10 * 4 + 3, 13 * 4 + 3 };   // rav1e's fixed list
   d.cdef_damping = 3; d.cdef_bits = 3;
@@ -158,6 +166,18 @@ static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJ
   return launch_search_t<4, 1>(d_frames, d_jobs, njobs, s);     // 64x64 blocks: alpha (4:0:0) frames only
 }
 
+// The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
+// points: K2a deblock level search -> level pick -> K2 deblock (vertical, horizontal edges) -> K3 CDEF.
+static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, hipStream_t s, hipEvent_t ev_cdef) {
+  hipLaunchKernelGGL(deblock_tally_kernel, dim3((max_mi_cells + 255) / 256, 6, nframes), dim3(256), 0, s, d_frames, nframes);
+  hipLaunchKernelGGL(deblock_pick_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
+  for (int pass = 0; pass < 2; pass++)
+    hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, d_frames, nframes, pass);
+  if (ev_cdef) { hipError_t e = hipEventRecord(ev_cdef, s); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, d_frames, 1);
+  return hipGetLastError();
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -173,7 +193,7 @@ struct mi_batch {
   uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
   uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0; unsigned long long *d_prof = nullptr;
-  uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr;
+  uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
   std::vector<TileJob> jobs; std::vector<FrameDev> hframes;
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
   hipEvent_t ev[8]{}; double stage_ms[8]{};
@@ -209,6 +229,7 @@ static void batch_free_device(mi_batch *b) {
   if (b->d_packed) hipFree(b->d_packed); b->d_packed = nullptr;
   if (b->h_packed) hipHostFree(b->h_packed); b->h_packed = nullptr;
   if (b->h_lens) hipHostFree(b->h_lens); b->h_lens = nullptr;
+  if (b->h_lf) hipHostFree(b->h_lf); b->h_lf = nullptr;
 }
 
 // allocate arena for the worst case: every image has an alpha frame when channels == 4
@@ -241,6 +262,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_lens, max_tiles * 4));
+  HIP_OK(hipHostMalloc(&b->h_lf, worst.size() * 4 * sizeof(int)));
   return MI_OK;
 }
 
@@ -390,7 +412,7 @@ int mi_batch_encode_async(mi_batch *b) {
     FramePlan &p = b->frames[k];
     max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
     // clear the state the kernels rely on being zero
-    HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
+    HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   }
   b->hframes.clear(); for (auto &p : b->frames) b->hframes.push_back(p.dev);     // must outlive the async copy
   HIP_OK(hipMemcpyAsync(b->d_frames, b->hframes.data(), sizeof(FrameDev) * b->hframes.size(), hipMemcpyHostToDevice, s));
@@ -399,15 +421,9 @@ int mi_batch_encode_async(mi_batch *b) {
   // ---- K1 tile search
   HIP_OK(hipEventRecord(b->ev[1], s));
   for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
-  // ---- K2 deblock
+  // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
-  for (int pass = 0; pass < 2; pass++)
-    hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, b->d_frames, nframes, pass);
-  HIP_OK(hipGetLastError());
-  // ---- K3 CDEF
-  HIP_OK(hipEventRecord(b->ev[3], s));
-  hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, b->d_frames, 1);
-  HIP_OK(hipGetLastError());
+  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, s, b->ev[3]));
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
@@ -415,7 +431,8 @@ int mi_batch_encode_async(mi_batch *b) {
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
-  for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s)); }
+  for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(b->h_lf + 4 * k, p.dev.lf_out, 4 * sizeof(int), hipMemcpyDeviceToHost, s)); }
   b->in_flight = true;
   return MI_OK;
 }
@@ -445,6 +462,7 @@ int mi_batch_wait(mi_batch *b) {
     FramePlan &p = b->frames[k];
     std::vector<std::pair<const uint8_t *, size_t>> tl;
     for (int t = 0; t < p.ntiles; t++) { const int j = p.dev.tile_base + t; tl.push_back({ b->h_packed + offsets[j], (size_t)b->h_lens[j] }); }
+    for (int i = 0; i < 4; i++) p.hdr.lf_level[i] = b->h_lf[4 * k + i];
     p.obu = assemble_obus(p.hdr, tl);
   }
   for (int i = 0; i < b->n; i++) {
@@ -590,7 +608,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
     }
     HIP_OK(hipMemcpy(p.dev.src[i], host.data(), npx * 2, hipMemcpyHostToDevice));
   }
-  HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, (size_t)p.mi_stride * p.mi_h, s));
+  HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
   FrameDev *d_frame; TileJob *d_jobs; uint16_t *d_pre;
@@ -602,15 +620,14 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
 #define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)
   DBG_STAGE("tile_search");
-  for (int pass = 0; pass < 2; pass++) hipLaunchKernelGGL(deblock_kernel, dim3((p.mi_cols * p.mi_rows * 4 + 255) / 256, 3, 1), dim3(256), 0, s, d_frame, 1, pass);
-  DBG_STAGE("deblock");
-  hipLaunchKernelGGL(cdef_kernel, dim3(p.sb_cols * p.sb_rows, 1), dim3(256), 0, s, d_frame, 1);
-  DBG_STAGE("cdef");
+  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, s, nullptr));
+  DBG_STAGE("loop filters");
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   DBG_STAGE("entropy");
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);
   HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(p.hdr.lf_level, p.dev.lf_out, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   std::vector<std::vector<uint8_t>> td(njobs); std::vector<std::pair<const uint8_t *, size_t>> tl;
   for (int j = 0; j < njobs; j++) {

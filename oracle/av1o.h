@@ -58,6 +58,7 @@ typedef struct Av1oResult {
   int base_q_idx;
   int tile_cols, tile_rows;
   int64_t total_sse[3];
+  int lf_level[4];                         /* deblock levels: luma vertical / horizontal edges, U, V */
 } Av1oResult;
 
 int  av1o_tweaks_from_preset(int speed, int quantizer, Av1oConfig *c);   /* av1encoder.rs:554-606 */

@@ -3,6 +3,7 @@
  * rav1e equivalents (absent): src/deblock.rs (deblock_filter_optimize, fast path = libaom's q-based formula),
  * src/cdef.rs + rdo.rs::rdo_loop_decision (per-64x64 strength index search, fixed 8-entry strength list). */
 #include "av1o_int.h"
+#include <stdio.h>
 
 /* ------------------------------------------------------------------ deblock */
 static int tx_px(const Av1oFrame *f, int r, int c) { return 4 << f->m_bsize[r * f->mi_stride + c]; }  /* TX_MODE_LARGEST, capped below */
@@ -62,32 +63,131 @@ static void filter_edge_sample(uint16_t *px, int step /* distance between p/q sa
   #undef Q
 }
 
+/* Geometry of one candidate edge position: returns the filter size (0 = no edge here). */
+static int edge_fsz(const Av1oFrame *f, int plane, int pass, int r, int c) {
+  const int x = c * 4, y = r * 4;
+  if (x >= f->w || y >= f->h) return 0;
+  if (pass == 0 && c == 0) return 0;
+  if (pass == 1 && r == 0) return 0;
+  const int cur = imin(64, tx_px(f, r, c));
+  if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;   /* tx (== block) edge? origins are aligned to their size */
+  const int prev = pass == 0 ? imin(64, tx_px(f, r, c - 1)) : imin(64, tx_px(f, r - 1, c));
+  const int base = imin(cur, prev);
+  return plane == 0 ? imin(16, base) : imin(8, base);
+}
+
+/* ---- level search (rav1e deblock.rs deblock_filter_optimize with fast_deblock == false, [UPSTREAM-RECALL]):
+ * every edge line is judged on the UNFILTERED reconstruction, independently of the other edges.  With sharpness 0 the
+ * filter of one line is a piecewise-constant function of the level L: off below the smallest level that satisfies the
+ * masks (limit = L, blimit = 3L + 4), and within [Lmin, 63] it can only change where thresh = L >> 4 changes (hev).  So one
+ * line contributes at most four (range of levels, SSE delta) pairs, accumulated as a difference array per (plane, pass);
+ * prefix sums give the frame SSE change for every level, the minimum picks the level (lowest level on ties).
+ * Luma: vertical and horizontal edges get their own level; chroma: one level per plane over both passes. */
+static void deblock_tally_line(const Av1oFrame *f, int plane, const uint16_t *rec, const uint16_t *src, int step, int fsz, int64_t *diff /* [65] */) {
+  const int s8 = f->bd - 8, half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8), one = 1 << s8;
+  int R[16];
+  for (int i = -half; i < half; i++) R[i + 8] = rec[i * step];
+  #define RP(i) R[7 - (i)]
+  #define RQ(i) R[8 + (i)]
+  const int flen = fsz == 4 ? 4 : (plane != 0 ? 6 : (fsz == 8 ? 8 : 16));
+  int dmax = imax(iabs(RP(1) - RP(0)), iabs(RQ(1) - RQ(0)));
+  if (flen >= 6) dmax = imax(dmax, imax(iabs(RP(2) - RP(1)), iabs(RQ(2) - RQ(1))));
+  if (flen >= 8) dmax = imax(dmax, imax(iabs(RP(3) - RP(2)), iabs(RQ(3) - RQ(2))));
+  const int b = iabs(RP(0) - RQ(0)) * 2 + iabs(RP(1) - RQ(1)) / 2;
+  #undef RP
+  #undef RQ
+  const int B = (b + one - 1) >> s8;
+  const int lmin = imax(1, imax((dmax + one - 1) >> s8, B > 4 ? (B - 4 + 2) / 3 : 0));
+  if (lmin > 63) return;
+  int64_t sse0 = 0;
+  for (int i = -half; i < half; i++) { const int d = R[i + 8] - (int)src[i * step]; sse0 += d * d; }
+  for (int a = lmin; a < 64; a = (a | 15) + 1) {
+    const int bnd = imin(64, (a | 15) + 1);
+    uint16_t t[16];
+    for (int i = 0; i < 16; i++) t[i] = (uint16_t)((i >= 8 - half && i < 8 + half) ? R[i] : 0);
+    filter_edge_sample(t + 8, 1, fsz, plane, a, 0, f->bd);
+    int64_t sse = 0;
+    for (int i = -half; i < half; i++) { const int d = (int)t[i + 8] - (int)src[i * step]; sse += d * d; }
+    diff[a] += sse - sse0; diff[bnd] -= sse - sse0;
+  }
+}
+void av1o_deblock_search(Av1oFrame *f, int64_t tally[3][2][64]) {
+  static int64_t diff[3][2][65];
+  memset(diff, 0, sizeof(diff));
+  for (int plane = 0; plane < f->np; plane++) for (int pass = 0; pass < 2; pass++)
+    for (int r = 0; r < f->mi_rows; r++) for (int c = 0; c < f->mi_cols; c++) {
+      const int fsz = edge_fsz(f, plane, pass, r, c);
+      if (!fsz) continue;
+      for (int i = 0; i < 4; i++) {
+        const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
+        deblock_tally_line(f, plane, f->rec[plane] + o, f->src[plane] + o, pass == 0 ? 1 : f->stride, fsz, diff[plane][pass]);
+      }
+    }
+  for (int plane = 0; plane < 3; plane++) for (int pass = 0; pass < 2; pass++) {
+    int64_t acc = 0;
+    for (int l = 0; l < 64; l++) { acc += diff[plane][pass][l]; tally[plane][pass][l] = acc; }
+  }
+}
+/* AV1O_SELFCHECK=1: the tallies against a brute-force evaluation (the real filter on every line at every level) */
+static void deblock_selfcheck(const Av1oFrame *f, int64_t tally[3][2][64]) {
+  for (int plane = 0; plane < f->np; plane++) for (int pass = 0; pass < 2; pass++) for (int l = 0; l < 64; l++) {
+    int64_t acc = 0;
+    for (int r = 0; r < f->mi_rows; r++) for (int c = 0; c < f->mi_cols; c++) {
+      const int fsz = edge_fsz(f, plane, pass, r, c);
+      if (!fsz || !l) continue;
+      for (int i = 0; i < 4; i++) {
+        const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
+        const int step = pass == 0 ? 1 : f->stride;
+        uint16_t t[16];
+        for (int k = -8; k < 8; k++) t[k + 8] = (k >= -(fsz / 2 < 2 ? 2 : (fsz == 8 ? 4 : (fsz == 4 ? 2 : 8))) && k < (fsz == 4 ? 2 : (fsz == 8 ? 4 : 8))) ? f->rec[plane][o + k * step] : 0;
+        uint16_t u[16]; memcpy(u, t, sizeof(t));
+        filter_edge_sample(u + 8, 1, fsz, plane, l, 0, f->bd);
+        for (int k = -8; k < 8; k++) if (u[k + 8] != t[k + 8]) {
+          const int s = f->src[plane][o + k * step], d0 = (int)t[k + 8] - s, d1 = (int)u[k + 8] - s;
+          acc += (int64_t)d1 * d1 - (int64_t)d0 * d0;
+        }
+      }
+    }
+    if (acc != tally[plane][pass][l]) { fprintf(stderr, "av1o deblock selfcheck: plane %d pass %d level %d: %lld vs %lld\n", plane, pass, l, (long long)acc, (long long)tally[plane][pass][l]); abort(); }
+  }
+}
+static void deblock_pick_levels(Av1oFrame *f) {
+  int64_t tally[3][2][64];
+  av1o_deblock_search(f, tally);
+  if (getenv("AV1O_SELFCHECK")) deblock_selfcheck(f, tally);
+  for (int pass = 0; pass < 2; pass++) {
+    int best = 0;
+    for (int l = 1; l < 64; l++) if (tally[0][pass][l] < tally[0][pass][best]) best = l;
+    f->lf_level[pass] = best;
+  }
+  for (int plane = 1; plane < 3; plane++) {
+    int best = 0;
+    if (plane < f->np) for (int l = 1; l < 64; l++) if (tally[plane][0][l] + tally[plane][1][l] < tally[plane][0][best] + tally[plane][1][best]) best = l;
+    f->lf_level[plane + 1] = best;
+  }
+  if (!f->lf_level[0] && !f->lf_level[1]) f->lf_level[2] = f->lf_level[3] = 0;   /* spec 5.9.11: chroma levels are not coded then */
+}
+
 void av1o_deblock_frame(Av1oFrame *f) {
-  /* level: libaom/rav1e q-based guess (fast_deblock path; rav1e's SSE search is future work) */
-  const int q = f->ac_q[0];
-  int lvl;
-  if (f->bd == 8) lvl = (q * 17563 - 421574 + (1 << 17)) >> 18;
-  else lvl = ((q * 20723 + 4060632 + (1 << 19)) >> 20) - 4;
-  lvl = iclamp(lvl, 0, 63);
-  f->lf_level[0] = f->lf_level[1] = lvl; f->lf_level[2] = f->lf_level[3] = lvl; f->lf_sharp = 0;
-  if (lvl == 0) return;
-  const int ms = f->mi_stride;
+  f->lf_sharp = 0;
+  if (f->cfg.fast_deblock) {
+    /* libaom/rav1e q-based guess (rav1e deblock_filter_optimize, fast_deblock path, key frame) */
+    const int q = f->ac_q[0];
+    int lvl;
+    if (f->bd == 8) lvl = (q * 17563 - 421574 + (1 << 17)) >> 18;
+    else lvl = ((q * 20723 + 4060632 + (1 << 19)) >> 20) - 4;
+    lvl = iclamp(lvl, 0, 63);
+    f->lf_level[0] = f->lf_level[1] = lvl; f->lf_level[2] = f->lf_level[3] = lvl;
+  } else deblock_pick_levels(f);
+  if (!f->lf_level[0] && !f->lf_level[1]) return;
   for (int plane = 0; plane < f->np; plane++) {
     for (int pass = 0; pass < 2; pass++) {
       const int L = plane == 0 ? f->lf_level[pass] : f->lf_level[plane + 1];
       if (!L) continue;
       for (int r = 0; r < f->mi_rows; r++) for (int c = 0; c < f->mi_cols; c++) {
+        const int fsz = edge_fsz(f, plane, pass, r, c);
+        if (!fsz) continue;
         const int x = c * 4, y = r * 4;
-        if (x >= f->w || y >= f->h) continue;
-        if (pass == 0 && c == 0) continue;
-        if (pass == 1 && r == 0) continue;
-        const int cur = imin(64, tx_px(f, r, c));
-        /* tx (== block) edge? block origins are aligned to their size */
-        if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) continue;
-        const int prev = pass == 0 ? imin(64, tx_px(f, r, c - 1)) : imin(64, tx_px(f, r - 1, c));
-        const int base = imin(cur, prev);
-        const int fsz = plane == 0 ? imin(16, base) : imin(8, base);
-        (void)ms;
         for (int i = 0; i < 4; i++) {
           uint16_t *px = pass == 0 ? f->rec[plane] + (y + i) * f->stride + x : f->rec[plane] + y * f->stride + x + i;
           filter_edge_sample(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);

@@ -181,6 +181,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   }
   out->mi_cols = f->mi_cols; out->mi_rows = f->mi_rows; out->mi_stride = f->mi_stride;
   out->m_bsize = f->m_bsize; out->m_ymode = f->m_ymode; out->m_uvmode = f->m_uvmode; out->m_skip = f->m_skip; out->m_txtype = f->m_txtype;
+  for (int i = 0; i < 4; i++) out->lf_level[i] = f->lf_level[i];
   out->base_q_idx = f->base_q_idx; out->tile_cols = f->tile_cols; out->tile_rows = f->tile_rows;
   for (int p = 0; p < f->np; p++) { free(f->src[p]); free(f->rec[p]); free(f->coef[p]); free(f->m_lvl[p]); free(f->m_dc[p]); free(f->m_eob[p]); }
   free(f->m_cfl_sign); free(f->m_cfl_au); free(f->m_cfl_av); free(f->m_angle_y); free(f->m_angle_uv); free(f->m_decoded); free(f->cdef_idx);
