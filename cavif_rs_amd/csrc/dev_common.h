@@ -22,7 +22,11 @@ struct FrameDev {
   int w, h, bd, np;
   int mi_cols, mi_rows, sb_cols, sb_rows;
   int pw, ph, stride, mi_stride, mi_h;
-  uint16_t *src[3], *rec[3], *fin[3];      // source, in-loop reconstruction, post-CDEF output
+  uint16_t *src[3], *rec[3], *fin[3];      // source, in-loop reconstruction (deblocked in place), post-CDEF output
+  uint16_t *lrp[3];                        // post-loop-restoration output (the final picture when enable_restoration)
+  uint8_t *lr_type, *lr_set; int8_t *lr_xqd;   // per (plane, restoration unit): 0 none / 1 sgrproj, parameter set, xqd[2]
+  uint32_t lr_cost[3];                     // static cost of the switchable restoration_type symbols (1/512 bit)
+  int enable_restoration, sgr_full;
   int32_t *coef[3];
   uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av, *m_decoded;
   int8_t *m_angle_y, *m_angle_uv;

@@ -184,6 +184,7 @@ inline void put_leb128(std::vector<uint8_t> &o, uint64_t v) { do { uint8_t b = v
 struct FrameHeaderInfo {                                       // what the OBU writer needs about one frame
   mi_av1_config cfg; int np; int sb_cols, sb_rows; QuantSel q; Tiling tiles;
   int lf_level[4], lf_sharp; int enable_cdef, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
+  int enable_restoration;
 };
 
 inline std::vector<uint8_t> sequence_header(const FrameHeaderInfo &h) {   // spec 5.5, reduced_still_picture_header
@@ -193,7 +194,7 @@ inline std::vector<uint8_t> sequence_header(const FrameHeaderInfo &h) {   // spe
   const int wb = 32 - __builtin_clz(std::max<uint32_t>(c.width - 1, 1)), hb = 32 - __builtin_clz(std::max<uint32_t>(c.height - 1, 1));
   b.put(wb - 1, 4); b.put(hb - 1, 4); b.put(c.width - 1, wb); b.put(c.height - 1, hb);
   b.put(0, 1); b.put(0, 1); b.put(1, 1);          // use_128x128_superblock, enable_filter_intra, enable_intra_edge_filter
-  b.put(0, 1); b.put(h.enable_cdef, 1); b.put(0, 1);   // enable_superres, enable_cdef, enable_restoration
+  b.put(0, 1); b.put(h.enable_cdef, 1); b.put(h.enable_restoration, 1);   // enable_superres, enable_cdef, enable_restoration
   b.put(c.bit_depth > 8, 1);
   if (mono) b.put(1, 1);
   b.put(c.has_color_desc ? 1 : 0, 1);
@@ -236,6 +237,10 @@ inline std::vector<uint8_t> frame_obu_header(const FrameHeaderInfo &h, int tile_
       b.put(h.cdef_y[i] >> 2, 4); b.put(h.cdef_y[i] & 3, 2);
       if (h.np > 1) { b.put(h.cdef_uv[i] >> 2, 4); b.put(h.cdef_uv[i] & 3, 2); }
     }
+  }
+  if (h.enable_restoration) {                     // lr_params(): RESTORE_SWITCHABLE on every plane, 64x64 units (lr_unit_shift 0)
+    for (int p = 0; p < h.np; p++) b.put(1, 2);
+    b.put(0, 1);
   }
   b.put(0, 1);                                    // tx_mode_select = 0 (TX_MODE_LARGEST)
   b.put(h.cfg.reduced_tx_set, 1);

@@ -14,6 +14,7 @@
 #include "tile_search.h"
 #include "tile_entropy.h"
 #include "loopfilter.h"
+#include "restoration.h"
 
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "mi_avif: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MI_ENCODING_ERROR; } } while (0)
 
@@ -64,6 +65,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct FramePlan;
 static size_t zeroed_bytes(const FramePlan &p);
 
+static int lr_units_host(uint32_t size) { const int n = ((int)size + 32) / 64; return n < 1 ? 1 : n; }
 static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + 6 * 65 * sizeof(long long); }
 
 static void plan_geometry(FramePlan &p) {
@@ -100,6 +102,11 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.lf_out = (int *)take(64);
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
+  {
+    const size_t nlr = (size_t)lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) * p.np;
+    for (int i = 0; i < 3; i++) d.lrp[i] = (i < p.np && p.cfg.lrf) ? (uint16_t *)take(npx * 2) : nullptr;
+    d.lr_type = take(nlr); d.lr_set = take(nlr); d.lr_xqd = (int8_t *)take(nlr * 2);
+  }
   d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
@@ -126,6 +133,8 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
   d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef; d.fast_deblock = c.fast_deblock;
+  d.enable_restoration = c.lrf; d.sgr_full = c.sgr_full;
+  { const uint32_t cdf[3] = { 9413, 22581, 32768 }; uint32_t lo = 0; for (int i = 0; i < 3; i++) { d.lr_cost[i] = neg_log2_q9(cdf[i] - lo); lo = cdf[i]; } }   // libaom default_switchable_restore_cdf
   d.tile_cols = p.tiles.cols; d.tile_rows = p.tiles.rows; d.tile_cols_log2 = p.tiles.cols_log2; d.tile_rows_log2 = p.tiles.rows_log2;
   for (int i = 0; i <= p.tiles.cols; i++) d.tile_col_start[i] = p.tiles.col_start[i];
   for (int i = 0; i <= p.tiles.rows; i++) d.tile_row_start[i] = p.tiles.row_start[i];
@@ -140,7 +149,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   FrameHeaderInfo &h = p.hdr;
   h.cfg = c; h.np = p.np; h.sb_cols = p.sb_cols; h.sb_rows = p.sb_rows; h.q = p.q; h.tiles = p.tiles;
   for (int i = 0; i < 4; i++) h.lf_level[i] = d.lf_level[i];
-  h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3;
+  h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3; h.enable_restoration = c.lrf;
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
@@ -168,13 +177,14 @@ static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJ
 
 // The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
 // points: K2a deblock level search -> level pick -> K2 deblock (vertical, horizontal edges) -> K3 CDEF.
-static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, hipStream_t s, hipEvent_t ev_cdef) {
+static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, int max_lr_units, hipStream_t s, hipEvent_t ev_cdef) {
   hipLaunchKernelGGL(deblock_tally_kernel, dim3((max_mi_cells + 255) / 256, 6, nframes), dim3(256), 0, s, d_frames, nframes);
   hipLaunchKernelGGL(deblock_pick_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
   for (int pass = 0; pass < 2; pass++)
     hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, d_frames, nframes, pass);
   if (ev_cdef) { hipError_t e = hipEventRecord(ev_cdef, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, d_frames, 1);
+  if (max_lr_units > 0) hipLaunchKernelGGL(lr_kernel, dim3(max_lr_units, 3, nframes), dim3(256), 0, s, d_frames);
   return hipGetLastError();
 }
 
@@ -395,7 +405,7 @@ int mi_batch_encode_async(mi_batch *b) {
   }
   // ---- tile job list, frame descriptors
   b->jobs.clear();
-  int max_mi_cells = 0, max_sb = 0, class_begin[6] = { 0, 0, 0, 0, 0, 0 };
+  int max_mi_cells = 0, max_sb = 0, max_lr = 0, class_begin[6] = { 0, 0, 0, 0, 0, 0 };
   // tile jobs grouped by block-size class (one K1 instantiation per class); tile_base indexes the grouped list
   for (int cls = 2; cls <= 4; cls++) {
     class_begin[cls] = (int)b->jobs.size();
@@ -411,6 +421,7 @@ int mi_batch_encode_async(mi_batch *b) {
   for (size_t k = 0; k < b->frames.size(); k++) {
     FramePlan &p = b->frames[k];
     max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
+    if (p.cfg.lrf) max_lr = std::max(max_lr, lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height));
     // clear the state the kernels rely on being zero
     HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   }
@@ -423,7 +434,7 @@ int mi_batch_encode_async(mi_batch *b) {
   for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
-  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, s, b->ev[3]));
+  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, s, b->ev[3]));
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
@@ -501,7 +512,7 @@ int mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]) {
   for (int i = 0; i < 3; i++) planes[i] = nullptr;
   for (int i = 0; i < p->np; i++) {
     planes[i] = (uint16_t *)malloc((size_t)b->w * b->h * 2);
-    HIP_OK(hipMemcpy2D(planes[i], (size_t)b->w * 2, p->dev.fin[i], (size_t)p->pw * 2, (size_t)b->w * 2, b->h, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy2D(planes[i], (size_t)b->w * 2, p->cfg.lrf ? p->dev.lrp[i] : p->dev.fin[i], (size_t)p->pw * 2, (size_t)b->w * 2, b->h, hipMemcpyDeviceToHost));
   }
   return MI_OK;
 }
@@ -620,7 +631,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
 #define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)
   DBG_STAGE("tile_search");
-  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, s, nullptr));
+  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, s, nullptr));
   DBG_STAGE("loop filters");
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   DBG_STAGE("entropy");
@@ -640,7 +651,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   *out_obu = (uint8_t *)malloc(obu.size()); memcpy(*out_obu, obu.data(), obu.size()); *out_len = obu.size();
   if (recon) for (int i = 0; i < 3; i++) {
     recon[i] = nullptr;
-    if (i < p.np) { recon[i] = (uint16_t *)malloc((size_t)cfg->width * cfg->height * 2); HIP_OK(hipMemcpy2D(recon[i], (size_t)cfg->width * 2, p.dev.fin[i], (size_t)p.pw * 2, (size_t)cfg->width * 2, cfg->height, hipMemcpyDeviceToHost)); }
+    if (i < p.np) { recon[i] = (uint16_t *)malloc((size_t)cfg->width * cfg->height * 2); HIP_OK(hipMemcpy2D(recon[i], (size_t)cfg->width * 2, p.cfg.lrf ? p.dev.lrp[i] : p.dev.fin[i], (size_t)p.pw * 2, (size_t)cfg->width * 2, cfg->height, hipMemcpyDeviceToHost)); }
   }
   hipFree(d_frame); hipFree(d_jobs); hipFree(d_pre); hipFree(arena); hipStreamDestroy(s);
   return MI_OK;

@@ -1,0 +1,278 @@
+// restoration.h -- kernel K5: loop restoration (spec 7.17), self-guided filter only (rav1e never searches Wiener).
+// One workgroup (4 wavefronts) per (restoration unit, plane, frame).  Units are 64x64 for every plane (lr_unit_shift 0),
+// i.e. one 64-row stripe of one superblock column; the last unit of a row / column absorbs a remainder < 32 samples, so a
+// unit is walked as 1, 2 or 4 chunks of at most 64x64 samples that each lie inside one stripe.  Per chunk the source window
+// (CDEF output inside the stripe, deblocked frame for the two rows above / below it, spec get_source_sample) is staged in
+// LDS once; per parameter set the box sums -> (A, B) maps live in LDS, the two filtered values of a thread's 16 samples in
+// registers.  Search = rav1e lrf.rs sgrproj_solve per set (least-squares projection weights, integer restatement shared
+// with oracle/av1o_lrf.c) + RD choice against RESTORE_NONE (rdo.rs::rdo_loop_decision); then the winner is applied.
+#pragma once
+#include "dev_common.h"
+
+#define LR_WP 70                                   // window pitch: 64 + 2 * 3
+#define LR_AP 66                                   // (A, B) pitch: 64 + 2
+struct LrLds {
+  uint16_t win[LR_WP * LR_WP];
+  uint16_t A[LR_AP * LR_AP];
+  uint32_t B[LR_AP * LR_AP];
+  uint16_t a2tab[256];
+  long long red[4][6];
+  long long tot[6];
+  int xq[2];
+};
+
+__device__ __forceinline__ void sgr_param(int set, int *r0, int *s0, int *r1, int *s1) {
+  const short t[16][4] = { { 2, 140, 1, 3236 }, { 2, 112, 1, 2158 }, { 2, 93, 1, 1618 }, { 2, 80, 1, 1438 }, { 2, 70, 1, 1295 }, { 2, 58, 1, 1177 },
+                           { 2, 47, 1, 1079 }, { 2, 37, 1, 996 }, { 2, 30, 1, 925 }, { 2, 25, 1, 863 }, { 0, -1, 1, 2589 }, { 0, -1, 1, 1618 },
+                           { 0, -1, 1, 1177 }, { 0, -1, 1, 925 }, { 2, 56, 0, -1 }, { 2, 22, 0, -1 } };
+  *r0 = t[set][0]; *s0 = t[set][1]; *r1 = t[set][2]; *s1 = t[set][3];
+}
+__device__ __forceinline__ int lr_units_of(int size) { const int n = (size + 32) / 64; return n < 1 ? 1 : n; }
+
+// bits of decode_signed_subexp_with_ref_bool(lo, hi_excl, k = 4, ref) for v; *bits = the MSB-first bit string
+__device__ __forceinline__ int lr_recenter(int r, int x) { return x > 2 * r ? x : (x >= r ? (x - r) << 1 : ((r - x) << 1) - 1); }
+__device__ inline int lr_subexp_code(int v, int lo, int hi_excl, int ref, uint32_t *bits) {
+  const int mx = hi_excl - lo, x = v - lo, r = ref - lo;
+  const int t = (r << 1) <= mx ? lr_recenter(r, x) : lr_recenter(mx - 1 - r, mx - 1 - x);
+  uint32_t acc = 0; int nb = 0, i = 0, mk = 0;
+  for (;;) {
+    const int b2 = i ? 4 + i - 1 : 4, a = 1 << b2;
+    if (mx <= mk + 3 * a) {
+      const int nsy = mx - mk, val = t - mk;
+      int w = 0; while ((1 << w) <= nsy) w++;
+      const int m = (1 << w) - nsy;
+      if (val < m) { acc = (acc << (w - 1)) | (uint32_t)val; nb += w - 1; }
+      else { const int e = val + m; acc = (acc << (w - 1)) | (uint32_t)(e >> 1); acc = (acc << 1) | (uint32_t)(e & 1); nb += w; }
+      break;
+    }
+    if (t >= mk + a) { acc = (acc << 1) | 1; nb++; i++; mk += a; }
+    else { acc <<= 1; nb++; acc = (acc << b2) | (uint32_t)(t - mk); nb += b2; break; }
+  }
+  *bits = acc;
+  return nb;
+}
+
+__device__ inline int lr_ratio_q7(long long num, long long det) {
+  while (det >= (1LL << 54)) { det >>= 1; num >>= 1; }
+  const int neg = num < 0; if (neg) num = -num;
+  if (num >= det * 4) return neg ? -512 : 512;
+  const long long q = (num * 128 + det / 2) / det;
+  return (int)(neg ? -q : q);
+}
+__device__ inline void lr_sgr_solve(long long h00, long long h11, long long h01, long long c0, long long c1, int r0, int r1, int *xqd0, int *xqd1) {
+  long long m = 0;
+  const long long v[5] = { h00, h11, h01, c0, c1 };
+  for (int i = 0; i < 5; i++) { const long long a = v[i] < 0 ? -v[i] : v[i]; if (a > m) m = a; }
+  int sh = 0; while ((m >> sh) >= (1LL << 30)) sh++;
+  h00 >>= sh; h11 >>= sh; h01 >>= sh; c0 >>= sh; c1 >>= sh;
+  int xq0 = 0, xq1 = 0;
+  if (r0 == 0) { if (h11 > 0) xq1 = lr_ratio_q7(c1, h11); }
+  else if (r1 == 0) { if (h00 > 0) xq0 = lr_ratio_q7(c0, h00); }
+  else {
+    const long long det = h00 * h11 - h01 * h01;
+    if (det > 0) { xq0 = lr_ratio_q7(h11 * c0 - h01 * c1, det); xq1 = lr_ratio_q7(h00 * c1 - h01 * c0, det); }
+  }
+  int x0 = iclamp_(xq0, -96, 31);
+  int x1 = iclamp_(128 - x0 - xq1, -32, 95);
+  if (r0 == 0) x0 = 0;
+  if (r1 == 0) x1 = 95;
+  *xqd0 = x0; *xqd1 = x1;
+}
+__device__ __forceinline__ int lr_project(int cdef, int f0, int f1, int r0, int r1, int w0, int w1, int mx) {
+  const int u = cdef << 4, w2 = 128 - w0 - w1;
+  const int v = w1 * u + w0 * (r0 ? f0 : u) + w2 * (r1 ? f1 : u);
+  return iclamp_(round2_(v, 11), 0, mx);
+}
+
+struct LrChunk { int x0, y0, w, h, stripe_start, stripe_end; };
+
+// stage the chunk's source window (origin x0 - 3, y0 - 3) in LDS
+__device__ inline void lr_load_window(LrLds &L, const FrameDev *f, int plane, const LrChunk &c) {
+  const int ex = f->w - 1, ey = f->h - 1, st = f->stride;
+  const uint16_t *cdef = f->fin[plane], *dbk = f->rec[plane];
+  const int ww = c.w + 6, wh = c.h + 6;
+  for (int i = threadIdx.x; i < ww * wh; i += 256) {
+    const int wy = i / ww, wx = i - wy * ww;
+    const int x = iclamp_(c.x0 - 3 + wx, 0, ex); int y = iclamp_(c.y0 - 3 + wy, 0, ey);
+    int v;
+    if (y < c.stripe_start) { y = imax_(c.stripe_start - 2, y); v = dbk[(size_t)y * st + x]; }
+    else if (y > c.stripe_end) { y = imin_(c.stripe_end + 2, y); v = dbk[(size_t)y * st + x]; }
+    else v = cdef[(size_t)y * st + x];
+    L.win[wy * LR_WP + wx] = (uint16_t)v;
+  }
+  __syncthreads();
+}
+// box filter process of the chunk for one (radius, s, pass); flt[k] = value of sample tid + 256 k (row-major over w x h)
+__device__ inline void lr_box_filter(LrLds &L, const LrChunk &c, int r, int sparam, int pass, int bd, int flt[16]) {
+  const int n = (2 * r + 1) * (2 * r + 1), one_by_n = ((1 << 12) + n / 2) / n;
+  const int aw = c.w + 2, ah = c.h + 2;
+  for (int pos = threadIdx.x; pos < aw * ah; pos += 256) {
+    const int pi = pos / aw, pj = pos - pi * aw;             // (i + 1, j + 1)
+    if (pass == 0 && !((c.y0 + pi - 1) & 1)) continue;       // pass 0 weights rows of odd parity only
+    uint32_t a = 0, b = 0;
+    const int wy = pi + 2, wx = pj + 2;                      // window coordinates of (i, j)
+    for (int dy = -r; dy <= r; dy++) for (int dx = -r; dx <= r; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
+    const int s2 = 2 * (bd - 8), s1 = bd - 8;
+    const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
+    const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
+    const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
+    const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
+    const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
+    L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
+  }
+  __syncthreads();
+  const int npx = c.w * c.h;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int idx = threadIdx.x + 256 * k;
+    int out = 0;
+    if (idx < npx) {
+      const int py = idx / c.w, px = idx - py * c.w, yabs = c.y0 + py;
+      const int o = (py + 1) * LR_AP + px + 1;
+      int a, b, shift;
+      if (pass == 0) {
+        if (yabs & 1) { a = 6 * L.A[o] + 5 * (L.A[o - 1] + L.A[o + 1]); b = 6 * (int)L.B[o] + 5 * (int)(L.B[o - 1] + L.B[o + 1]); shift = 4; }
+        else {
+          a = 6 * (L.A[o - LR_AP] + L.A[o + LR_AP]) + 5 * (L.A[o - LR_AP - 1] + L.A[o - LR_AP + 1] + L.A[o + LR_AP - 1] + L.A[o + LR_AP + 1]);
+          b = 6 * (int)(L.B[o - LR_AP] + L.B[o + LR_AP]) + 5 * (int)(L.B[o - LR_AP - 1] + L.B[o - LR_AP + 1] + L.B[o + LR_AP - 1] + L.B[o + LR_AP + 1]);
+          shift = 5;
+        }
+      } else {
+        a = 4 * (L.A[o] + L.A[o - 1] + L.A[o + 1] + L.A[o - LR_AP] + L.A[o + LR_AP]) + 3 * (L.A[o - LR_AP - 1] + L.A[o - LR_AP + 1] + L.A[o + LR_AP - 1] + L.A[o + LR_AP + 1]);
+        b = 4 * (int)(L.B[o] + L.B[o - 1] + L.B[o + 1] + L.B[o - LR_AP] + L.B[o + LR_AP]) + 3 * (int)(L.B[o - LR_AP - 1] + L.B[o - LR_AP + 1] + L.B[o + LR_AP - 1] + L.B[o + LR_AP + 1]);
+        shift = 5;
+      }
+      const int cd = L.win[(py + 3) * LR_WP + px + 3];
+      out = round2_(a * cd + b, 4 + shift);
+    }
+    flt[k] = out;
+  }
+  __syncthreads();
+}
+
+// block-wide sum of up to 6 per-thread 64-bit values (|v| < 2^40) -> L.tot[], visible to all threads after return
+__device__ inline void lr_block_sum(LrLds &L, const long long *v, int n) {
+  const int wave = threadIdx.x >> 6;
+  for (int i = 0; i < n; i++) { const long long s = wave_sum_i64(v[i]); if (LANE == 0) L.red[wave][i] = s; }
+  __syncthreads();
+  if (threadIdx.x < n) L.tot[threadIdx.x] = L.red[0][threadIdx.x] + L.red[1][threadIdx.x] + L.red[2][threadIdx.x] + L.red[3][threadIdx.x];
+  __syncthreads();
+}
+
+__device__ __forceinline__ int lr_chunks(const FrameDev *f, int ur, int uc, int ucols, int urows, LrChunk *ch) {
+  const int W = f->w, H = f->h;
+  const int x0 = uc * 64, x1 = uc == ucols - 1 ? W : x0 + 64;
+  const int y0 = imax_(0, ur * 64 - 8), y1 = ur == urows - 1 ? H : ur * 64 + 56;
+  int n = 0;
+  for (int ys = y0; ys < y1;) {
+    const int stripe = (ys + 8) / 64, ye = imin_(y1, stripe * 64 + 56);
+    for (int xs = x0; xs < x1; xs += 64) {
+      LrChunk c; c.x0 = xs; c.w = imin_(64, x1 - xs); c.y0 = ys; c.h = ye - ys; c.stripe_start = stripe * 64 - 8; c.stripe_end = c.stripe_start + 63;
+      ch[n++] = c;
+    }
+    ys = ye;
+  }
+  return n;
+}
+
+// grid = (units, planes, frames)
+__global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
+  const FrameDev *f = frames + blockIdx.z;
+  const int plane = blockIdx.y;
+  if (plane >= f->np || !f->enable_restoration) return;
+  const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h);
+  const int ui = blockIdx.x;
+  if (ui >= ucols * urows) return;
+  const int ur = ui / ucols, uc = ui - ur * ucols;
+  __shared__ LrLds L;
+  L.a2tab[threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? 1 : ((threadIdx.x << 8) + threadIdx.x / 2) / (threadIdx.x + 1));
+  LrChunk ch[4];
+  const int nch = lr_chunks(f, ur, uc, ucols, urows, ch);
+  const int st = f->stride, bd = f->bd, mx = (1 << bd) - 1;
+  const uint16_t *cdef = f->fin[plane], *src = f->src[plane];
+  uint16_t *out = f->lrp[plane];
+  __syncthreads();
+  // RESTORE_NONE
+  long long acc[6];
+  {
+    int s = 0;
+    for (int q = 0; q < nch; q++) {
+      const LrChunk &c = ch[q];
+      for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) {
+        const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+        const int d = (int)cdef[o] - (int)src[o]; s += d * d;
+      }
+    }
+    acc[0] = s;
+    lr_block_sum(L, acc, 1);
+  }
+  long long best_cost = ((L.tot[0] * f->wq[plane]) >> 5) + (((long long)f->lr_cost[0] * f->rdmult + 256) >> 9);
+  int best_type = 0, best_set = 0, best_x0 = 0, best_x1 = 0;
+  const int nsets = f->sgr_full ? 16 : 4;
+  int flt0[16], flt1[16];
+  for (int si = 0; si <= nsets; si++) {
+    const bool apply = si == nsets;                            // last round: apply the winner
+    if (apply && !best_type) break;
+    const int reduced[4] = { 1, 3, 6, 11 };
+    const int set = apply ? best_set : (f->sgr_full ? si : reduced[si & 3]);
+    int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
+    int xq0 = best_x0, xq1 = best_x1;
+    // sweep 0: normal equations; sweep 1: SSE with the solved weights (search) / output (apply)
+    for (int sweep = apply ? 1 : 0; sweep < 2; sweep++) {
+      for (int i = 0; i < 6; i++) acc[i] = 0;
+      for (int q = 0; q < nch; q++) {
+        const LrChunk &c = ch[q];
+        if (sweep == 0 || nch > 1 || apply) {
+          lr_load_window(L, f, plane, c);
+          if (r0) lr_box_filter(L, c, r0, s0, 0, bd, flt0);
+          if (r1) lr_box_filter(L, c, r1, s1, 1, bd, flt1);
+        }
+        const int npx = c.w * c.h;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int idx = threadIdx.x + 256 * k;
+          if (idx < npx) {
+            const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+            const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
+            if (sweep == 0) {
+              const int u = cd << 4, e = (sv << 4) - u;
+              const int f0 = r0 ? flt0[k] - u : 0, f1 = r1 ? flt1[k] - u : 0;
+              acc[0] += (long long)(f0 * f0); acc[1] += (long long)(f1 * f1); acc[2] += (long long)(f0 * f1); acc[3] += (long long)(f0 * e); acc[4] += (long long)(f1 * e);
+            } else {
+              const int v = lr_project(cd, flt0[k], flt1[k], r0, r1, xq0, xq1, mx);
+              if (apply) out[o] = (uint16_t)v;
+              else { const int d = v - sv; acc[5] += (long long)(d * d); }
+            }
+          }
+        }
+        if (nch > 1) __syncthreads();                          // the window is re-staged for the next chunk
+      }
+      if (apply) break;
+      if (sweep == 0) {
+        lr_block_sum(L, acc, 5);
+        if (threadIdx.x == 0) { int a, b; lr_sgr_solve(L.tot[0], L.tot[1], L.tot[2], L.tot[3], L.tot[4], r0, r1, &a, &b); L.xq[0] = a; L.xq[1] = b; }
+        __syncthreads();
+        xq0 = L.xq[0]; xq1 = L.xq[1];
+      } else {
+        lr_block_sum(L, acc + 5, 1);
+        uint32_t rate = f->lr_cost[2] + 4 * 512, bits;
+        if (r0) rate += 512u * (uint32_t)lr_subexp_code(xq0, -96, 32, -32, &bits);
+        if (r1) rate += 512u * (uint32_t)lr_subexp_code(xq1, -32, 96, 31, &bits);
+        const long long cost = ((L.tot[0] * f->wq[plane]) >> 5) + (((long long)rate * f->rdmult + 256) >> 9);
+        if (cost < best_cost) { best_cost = cost; best_type = 1; best_set = set; best_x0 = xq0; best_x1 = xq1; }
+        __syncthreads();
+      }
+    }
+  }
+  if (!best_type) {
+    for (int q = 0; q < nch; q++) {
+      const LrChunk &c = ch[q];
+      for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) { const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px; out[o] = cdef[o]; }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const int n = ucols * urows;
+    f->lr_type[plane * n + ui] = (uint8_t)best_type; f->lr_set[plane * n + ui] = (uint8_t)best_set;
+    f->lr_xqd[(plane * n + ui) * 2] = (int8_t)best_x0; f->lr_xqd[(plane * n + ui) * 2 + 1] = (int8_t)best_x1;
+  }
+}

@@ -7,6 +7,7 @@
 #pragma once
 #include "dev_common.h"
 #include "dev_rate.h"
+#include "restoration.h"
 
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
@@ -84,6 +85,7 @@ struct TileWriter {
   const FrameDev *f; TileB t; RangeEncDev ec; LDS uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
   LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient records of the current transform block
+  LDS uint16_t *lr_cdf; LDS int *lr_ref;                           // switchable restoration_type CDF (3 symbols + counter), RefSgrXqd[plane][2]
   int cdef_pending;                                                 // the 64x64 superblock being walked has not signalled its cdef_idx yet
   int sb_cols_tile;
 };
@@ -227,11 +229,40 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
   return part;
 }
 
+// read_lr() of the superblock at (r, c) (spec 5.11.57 / 5.11.58): with 64x64 units at most one unit per plane
+__device__ __forceinline__ void write_lr_sb(TileWriter *w, int r, int c) {
+  const FrameDev *f = w->f;
+  if (!f->enable_restoration) return;
+  const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h), n = ucols * urows;
+  const int urs = (r * 4 + 63) / 64, ure = imin_(((r + 16) * 4 + 63) / 64, urows);
+  const int ucs = (c * 4 + 63) / 64, uce = imin_(((c + 16) * 4 + 63) / 64, ucols);
+  for (int p = 0; p < f->np; p++) for (int ur = urs; ur < ure; ur++) for (int uc = ucs; uc < uce; uc++) {
+    const int ui = p * n + ur * ucols + uc;
+    const int type = f->lr_type[ui];
+    re_symbol_dev(&w->ec, type ? 2 : 0, w->lr_cdf, 3);
+    if (!type) continue;
+    const int set = f->lr_set[ui];
+    re_literal_dev(&w->ec, (uint32_t)set, 4);
+    int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
+    for (int i = 0; i < 2; i++) {
+      const int v = f->lr_xqd[ui * 2 + i];
+      if (i == 0 ? r0 : r1) {
+        uint32_t bits; const int nb = lr_subexp_code(v, i == 0 ? -96 : -32, i == 0 ? 32 : 96, w->lr_ref[p * 2 + i], &bits);
+        re_literal_dev(&w->ec, bits, nb);
+      }
+      WAVE_SYNC();
+      if (LANE == 0) w->lr_ref[p * 2 + i] = v;
+      WAVE_SYNC();
+    }
+  }
+}
+
 // Iterative Z-order walk of one superblock (explicit stack, depth <= 5) so that every block-size instance of
 // write_block_dev is inlined exactly once and the range-coder state stays in registers.
 template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) {
   const FrameDev *f = w->f;
   w->cdef_pending = 1;
+  write_lr_sb(w, r0, c0);
   int sr[5], sc[5], sk[5];
   int sp = 0; sr[0] = r0; sc[0] = c0; sk[0] = 0;
   while (sp >= 0) {
@@ -276,6 +307,7 @@ template <int CS> struct EntropyLds {
   uint16_t scans[SCAN_LDS_ENTRIES(CS)];
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
+  uint16_t lr_cdf[4]; int lr_ref[6];
 };
 
 template <int MAXBS>
@@ -293,6 +325,9 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
   w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
+  w.lr_cdf = (LDS uint16_t *)L.lr_cdf; w.lr_ref = (LDS int *)L.lr_ref;
+  if (LANE < 4) L.lr_cdf[LANE] = (uint16_t)(LANE == 0 ? 32768 - 9413 : (LANE == 1 ? 32768 - 22581 : 0));   // libaom default_switchable_restore_cdf
+  if (LANE < 6) L.lr_ref[LANE] = (LANE & 1) ? 31 : -32;                                                      // Sgrproj_Xqd_Mid
   load_scans_to_lds((LDS uint16_t *)L.scans, CS);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];

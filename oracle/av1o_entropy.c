@@ -153,7 +153,8 @@ uint32_t av1o_coef_rate_full(const Av1oFrame *f, const int32_t *qc, int eob, int
 }
 
 /* ---------------- phase 2: tile writer ---------------- */
-typedef struct { RangeEnc ec; uint16_t cdf[CDF_TOTAL]; Av1oFrame *f; TileB t; uint8_t *cdef_done; } TileW;
+typedef struct { RangeEnc ec; uint16_t cdf[CDF_TOTAL]; Av1oFrame *f; TileB t; uint8_t *cdef_done; uint16_t lr_cdf[4]; int lr_ref[3][2]; } TileW;
+static void lr_sym(void *u, int s, int n) { TileW *w = (TileW *)u; re_symbol(&w->ec, s, w->lr_cdf, n); }
 static void ec_sym(void *u, int off, int s, int n) { TileW *w = (TileW *)u; re_symbol(&w->ec, s, w->cdf + off, n); }
 static void ec_lit(void *u, uint32_t v, int nb) { TileW *w = (TileW *)u; re_literal(&w->ec, v, nb); }
 
@@ -269,9 +270,14 @@ size_t av1o_code_tile(Av1oFrame *f, int tile_row, int tile_col, uint8_t **out) {
   memcpy(w->cdf, f->cdf0, sizeof(w->cdf));
   w->cdef_done = (uint8_t *)calloc((size_t)f->sb_rows * f->sb_cols, 1);
   re_init(&w->ec);
+  /* tile start: switchable restoration_type CDF (libaom AOM_CDF3(9413, 22581)), RefSgrXqd = Sgrproj_Xqd_Mid */
+  w->lr_cdf[0] = 32768 - 9413; w->lr_cdf[1] = 32768 - 22581; w->lr_cdf[2] = 0; w->lr_cdf[3] = 0;
+  for (int p = 0; p < 3; p++) { w->lr_ref[p][0] = -32; w->lr_ref[p][1] = 31; }
   for (int r = w->t.mi_row_start; r < w->t.mi_row_end; r += SB_MI)
-    for (int c = w->t.mi_col_start; c < w->t.mi_col_end; c += SB_MI)
+    for (int c = w->t.mi_col_start; c < w->t.mi_col_end; c += SB_MI) {
+      av1o_write_lr_sb(f, r, c, w->lr_ref, lr_sym, ec_lit, w);      /* read_lr() precedes decode_partition() (spec 5.11.2) */
       write_partition(w, r, c, BS_64);
+    }
   size_t n = re_finish(&w->ec, out);
   re_free(&w->ec);
   free(w->cdef_done);

@@ -266,10 +266,12 @@ void av1o_cdef_search_and_apply(Av1oFrame *f) {
   f->cdef_damping = 3; f->cdef_bits = 3;
   for (int i = 0; i < 8; i++) { f->cdef_y[i] = strengths[i]; f->cdef_uv[i] = strengths[i]; }
   for (int i = 0; i < f->sb_rows * f->sb_cols; i++) f->cdef_idx[i] = -1;
-  if (!f->enable_cdef) return;
   const size_t npx = (size_t)f->pw * f->ph;
   uint16_t *in[3], *tmp[3];
-  for (int p = 0; p < f->np; p++) { in[p] = (uint16_t *)malloc(npx * 2); memcpy(in[p], f->rec[p], npx * 2); tmp[p] = (uint16_t *)malloc(npx * 2); }
+  /* the deblocked frame is kept: loop restoration reads it across stripe boundaries (spec 7.17.6) */
+  for (int p = 0; p < f->np; p++) { in[p] = (uint16_t *)malloc(npx * 2); memcpy(in[p], f->rec[p], npx * 2); f->dbk[p] = in[p]; }
+  if (!f->enable_cdef) return;
+  for (int p = 0; p < f->np; p++) tmp[p] = (uint16_t *)malloc(npx * 2);
   const int cs = f->bd - 8, ms = f->mi_stride;
   int64_t wq[3];
   for (int p = 0; p < f->np; p++) wq[p] = (((int64_t)f->ac_q[0] * f->ac_q[0]) << 12) / ((int64_t)f->ac_q[p] * f->ac_q[p]);
@@ -316,5 +318,5 @@ void av1o_cdef_search_and_apply(Av1oFrame *f) {
       }
     }
   }
-  for (int p = 0; p < f->np; p++) { free(in[p]); free(tmp[p]); }
+  for (int p = 0; p < f->np; p++) free(tmp[p]);
 }

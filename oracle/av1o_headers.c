@@ -88,7 +88,10 @@ static void write_frame_header(const Av1oFrame *f, BitW *b, int tile_size_bytes)
     }
   }
   /* lr_params() */
-  if (f->enable_restoration) { for (int p = 0; p < f->np; p++) bw_put(b, 0, 2); }  /* RESTORE_NONE everywhere */
+  if (f->enable_restoration) {
+    for (int p = 0; p < f->np; p++) bw_put(b, 1, 2);   /* lr_type 1 -> RESTORE_SWITCHABLE (Remap_Lr_Type) */
+    bw_put(b, 0, 1);                                   /* lr_unit_shift = 0: 64x64 units; 4:4:4 / 4:0:0 -> no lr_uv_shift */
+  }
   bw_put(b, 0, 1);                     /* tx_mode_select = 0 -> TX_MODE_LARGEST */
   bw_put(b, (uint32_t)f->cfg.reduced_tx_set, 1);
 }
@@ -153,12 +156,13 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   av1o_select_quantizers(f);
   av1o_build_costs(f);
   av1o_setup_tiles(f);
-  f->enable_cdef = cfg->cdef; f->enable_restoration = 0;
+  f->enable_cdef = cfg->cdef; f->enable_restoration = cfg->lrf;
   /* phase 1 */
   for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++) av1o_search_tile(f, tr, tc);
   /* loop filter decisions + final reconstruction */
   av1o_deblock_frame(f);
   av1o_cdef_search_and_apply(f);
+  av1o_lr_search_and_apply(f);
   /* phase 2 */
   const int ntiles = f->tile_cols * f->tile_rows;
   uint8_t **td = (uint8_t **)zalloc(sizeof(uint8_t *) * (size_t)ntiles); size_t *tl = (size_t *)zalloc(sizeof(size_t) * (size_t)ntiles);
@@ -184,6 +188,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   for (int i = 0; i < 4; i++) out->lf_level[i] = f->lf_level[i];
   out->base_q_idx = f->base_q_idx; out->tile_cols = f->tile_cols; out->tile_rows = f->tile_rows;
   for (int p = 0; p < f->np; p++) { free(f->src[p]); free(f->rec[p]); free(f->coef[p]); free(f->m_lvl[p]); free(f->m_dc[p]); free(f->m_eob[p]); }
+  for (int p = 0; p < f->np; p++) { free(f->dbk[p]); free(f->lr_type[p]); free(f->lr_set[p]); free(f->lr_xqd[p]); }
   free(f->m_cfl_sign); free(f->m_cfl_au); free(f->m_cfl_av); free(f->m_angle_y); free(f->m_angle_uv); free(f->m_decoded); free(f->cdef_idx);
   free(f);
   return 0;

@@ -72,6 +72,11 @@ typedef struct Av1oFrame {
   int lf_level[4], lf_sharp;
   int cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
   int enable_cdef, enable_restoration;
+  /* loop restoration: deblocked (pre-CDEF) frame, per-unit decisions (64x64 units, raster over lr_unit_rows x lr_unit_cols) */
+  uint16_t *dbk[3];
+  int lr_unit_rows, lr_unit_cols;
+  uint8_t *lr_type[3], *lr_set[3]; int8_t *lr_xqd[3];
+  uint32_t lr_cost[3];          /* static cost of the switchable restoration_type symbols */
   int64_t sse[3];
 } Av1oFrame;
 
@@ -114,6 +119,10 @@ void av1o_txb_ctx(const Av1oFrame *f, const TileB *t, int plane, int r4, int c4,
 /* loop filters (spec 7.14, 7.15) */
 void av1o_deblock_frame(Av1oFrame *f);
 void av1o_cdef_search_and_apply(Av1oFrame *f);
+/* loop restoration (spec 7.17) */
+void av1o_lr_search_and_apply(Av1oFrame *f);
+int  av1o_lr_units(int size);
+void av1o_write_lr_sb(Av1oFrame *f, int r, int c, int ref_xqd[3][2], void (*sym)(void *, int, int), void (*lit)(void *, uint32_t, int), void *u);
 
 /* headers */
 size_t av1o_write_obus(Av1oFrame *f, uint8_t **tile_data, size_t *tile_len, uint8_t **out);
