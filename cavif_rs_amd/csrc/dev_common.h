@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include "av1_tables.h"
 
 #define MI_MAX_TILE_COLS 64
@@ -19,28 +20,37 @@ enum { TXC_2D = 0, TXC_HORIZ = 1, TXC_VERT = 2 };
 // Everything a kernel needs to know about one plane-set being encoded (one AV1 frame: the colour
 // image or the alpha plane of one input image).  Lives in device memory; pointers are device pointers.
 struct FrameDev {
+  // ---- head: what the tile search (K1) reads; this part is staged in LDS per tile (FRAMEDEV_K1_BYTES) ----
   int w, h, bd, np;
   int mi_cols, mi_rows, sb_cols, sb_rows;
   int pw, ph, stride, mi_stride, mi_h;
-  uint16_t *src[3], *rec[3], *fin[3];      // source, in-loop reconstruction (deblocked in place), post-CDEF output
-  uint16_t *lrp[3];                        // post-loop-restoration output (the final picture when enable_restoration)
-  uint8_t *lr_type, *lr_set; int8_t *lr_xqd;   // per (plane, restoration unit): 0 none / 1 sgrproj, parameter set, xqd[2]
-  uint32_t lr_cost[3];                     // static cost of the switchable restoration_type symbols (1/512 bit)
-  int enable_restoration, sgr_full;
+  uint16_t *src[3], *rec[3];               // source, in-loop reconstruction (deblocked in place)
   int32_t *coef[3];
   uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av, *m_decoded;
+  uint8_t *m_txsize;                       // luma transform size of the block (0 = 4x4 .. 4 = 64x64), uniform over the block
   int8_t *m_angle_y, *m_angle_uv;
   uint8_t *m_lvl[3], *m_dc[3];
   uint16_t *m_eob[3];
-  int8_t *cdef_idx;
   // quantizer / lambda
   int base_q_idx, qctx, dc_q[3], ac_q[3];
   uint32_t dc_recip[3], ac_recip[3];          // floor((2^32 - 1) / q): quantisation divides by multiply-high + one fix-up
   long long rdmult, wq[3];
   // tools
-  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, enable_cdef, fast_deblock;
+  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, tx_mode_select;
+  int tile_cols;
+  uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
+  int dbg;                   // debug bisect level (0 = off; probe builds only)
+  unsigned long long *prof_out;  // profiling builds: per launch-wide tile job, 4 waves x 16 phase cycle counters
+  unsigned long long *tile_clk;  // per tile: [start, end] of K1 and of K4 in wall_clock64 ticks (100 MHz), 4 values
+  // ---- tail: frame-level stages and the entropy coder ----
+  uint16_t *fin[3];                        // post-CDEF output
+  uint16_t *lrp[3];                        // post-loop-restoration output (the final picture when enable_restoration)
+  uint8_t *lr_type, *lr_set; int8_t *lr_xqd;   // per (plane, restoration unit): 0 none / 1 sgrproj, parameter set, xqd[2]
+  uint32_t lr_cost[3];                     // static cost of the switchable restoration_type symbols (1/512 bit)
+  int enable_restoration, sgr_full, enable_cdef, fast_deblock;
+  int8_t *cdef_idx;
   // tiles (SB units)
-  int tile_cols, tile_rows, tile_cols_log2, tile_rows_log2;
+  int tile_rows, tile_cols_log2, tile_rows_log2;
   int tile_col_start[MI_MAX_TILE_COLS + 1], tile_row_start[MI_MAX_TILE_ROWS + 1];
   // static rate table (cost per symbol in 1/512 bit, same flat layout as the CDF context) + initial CDFs
   const uint16_t *cost;      // [CDF_TOTAL]
@@ -49,16 +59,13 @@ struct FrameDev {
   int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
   long long *lf_tally;       // deblock level search: [3 planes][2 passes][65] SSE-delta difference arrays (zeroed per encode)
   int *lf_out;               // the frame's 4 chosen levels, read back by the host for the frame header
-  // per-tile scratch + outputs
-  uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
+  // per-tile outputs
   uint8_t *tile_out;         // per tile: tile_out_cap bytes
   uint32_t *tile_len;        // per tile
   uint32_t tile_out_cap;
   int tile_base;             // index of this frame's first tile in the launch-wide tile list
-  int dbg;                   // debug bisect level (0 = off)
-  unsigned long long *prof_out;  // profiling builds: per launch-wide tile job, 4 waves x 16 phase cycle counters
-  unsigned long long *tile_clk;  // per tile: [start, end] of K1 and of K4 in wall_clock64 ticks (100 MHz), 4 values
 };
+#define FRAMEDEV_K1_BYTES ((int)(offsetof(FrameDev, fin) + 15) & ~15)
 
 struct TileJob { int frame; int tile_row, tile_col; };
 

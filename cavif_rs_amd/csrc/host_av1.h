@@ -184,7 +184,7 @@ inline void put_leb128(std::vector<uint8_t> &o, uint64_t v) { do { uint8_t b = v
 struct FrameHeaderInfo {                                       // what the OBU writer needs about one frame
   mi_av1_config cfg; int np; int sb_cols, sb_rows; QuantSel q; Tiling tiles;
   int lf_level[4], lf_sharp; int enable_cdef, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
-  int enable_restoration;
+  int enable_restoration, tx_mode_select;
 };
 
 inline std::vector<uint8_t> sequence_header(const FrameHeaderInfo &h) {   // spec 5.5, reduced_still_picture_header
@@ -242,7 +242,7 @@ inline std::vector<uint8_t> frame_obu_header(const FrameHeaderInfo &h, int tile_
     for (int p = 0; p < h.np; p++) b.put(1, 2);
     b.put(0, 1);
   }
-  b.put(0, 1);                                    // tx_mode_select = 0 (TX_MODE_LARGEST)
+  b.put(h.tx_mode_select, 1);                     // tx_mode_select: TX_MODE_SELECT / TX_MODE_LARGEST
   b.put(h.cfg.reduced_tx_set, 1);
   b.align();
   if (ntiles > 1) { b.put(0, 1); b.align(); }     // tile_start_and_end_present_flag

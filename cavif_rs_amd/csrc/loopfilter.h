@@ -74,9 +74,10 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
   if (pass == 0 && c == 0) return 0;
   if (pass == 1 && r == 0) return 0;
   const int ms = f->mi_stride;
-  const int cur = imin_(64, 4 << f->m_bsize[r * ms + c]);
+  const uint8_t *txm = plane == 0 ? f->m_txsize : f->m_bsize;     // luma: the block's transform size; chroma (4:4:4): the block's largest transform
+  const int cur = imin_(64, 4 << txm[r * ms + c]);
   if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;
-  const int prev = pass == 0 ? imin_(64, 4 << f->m_bsize[r * ms + c - 1]) : imin_(64, 4 << f->m_bsize[(r - 1) * ms + c]);
+  const int prev = pass == 0 ? imin_(64, 4 << txm[r * ms + c - 1]) : imin_(64, 4 << txm[(r - 1) * ms + c]);
   const int base = imin_(cur, prev);
   return plane == 0 ? imin_(16, base) : imin_(8, base);
 }

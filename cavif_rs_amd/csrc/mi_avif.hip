@@ -96,7 +96,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     d.m_lvl[i] = take(nmi); d.m_dc[i] = take(nmi); d.m_eob[i] = (uint16_t *)take(nmi * 2);
   }
   d.m_bsize = take(nmi); d.m_skip = take(nmi); d.m_ymode = take(nmi); d.m_uvmode = take(nmi); d.m_txtype = take(nmi);
-  d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi);
+  d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi); d.m_txsize = take(nmi);
   // state the kernels expect zeroed before every encode, in one block (one memset): decoded flags + deblock tallies
   d.m_decoded = take(zeroed_bytes(p)); d.lf_tally = (long long *)(d.m_decoded + align_up(nmi, 256));
   d.lf_out = (int *)take(64);
@@ -132,6 +132,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
   for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
+  d.tx_mode_select = c.rdo_tx_decision || c.inter_tx_split;    // rav1e FrameInvariants.tx_mode_select (recall)
   d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef; d.fast_deblock = c.fast_deblock;
   d.enable_restoration = c.lrf; d.sgr_full = c.sgr_full;
   { const uint32_t cdf[3] = { 9413, 22581, 32768 }; uint32_t lo = 0; for (int i = 0; i < 3; i++) { d.lr_cost[i] = neg_log2_q9(cdf[i] - lo); lo = cdf[i]; } }   // libaom default_switchable_restore_cdf
@@ -149,7 +150,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   FrameHeaderInfo &h = p.hdr;
   h.cfg = c; h.np = p.np; h.sb_cols = p.sb_cols; h.sb_rows = p.sb_rows; h.q = p.q; h.tiles = p.tiles;
   for (int i = 0; i < 4; i++) h.lf_level[i] = d.lf_level[i];
-  h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3; h.enable_restoration = c.lrf;
+  h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3; h.enable_restoration = c.lrf; h.tx_mode_select = d.tx_mode_select;
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 

@@ -179,28 +179,40 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     }
   }
   if (f->np > 1) uvmode = f->m_uvmode[mi];
+  // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
+  const int txs_y = f->m_txsize[mi];
+  if (BS > 0 && f->tx_mode_select) {
+    const int maxw = 4 << BS;
+    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
+    re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
+  }
   if (skip) return;                                    // wave-uniform
-  constexpr int n = (4 << BS) < 32 ? (4 << BS) : 32;
+  // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
   for (int p = 0; p < f->np; p++) {
-    const int eob = f->m_eob[p][mi];
-    const int32_t *src = f->coef[p] + (size_t)(r * 4) * f->stride + c * 4;
-    WAVE_SYNC();
-    for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx / n) * f->stride + (idx % n)];
-    WAVE_SYNC();
-    build_level_map(w->qc, w->lev, n);
-    int txtype, off = -1, sym = 0, ns = 0, set;
-    if (p == 0) {
-      txtype = f->m_txtype[mi];
-      off = intra_tx_cdf(f, BS, ymode, &ns, &set);
-      if (off >= 0) sym = txtype_to_sym(set, txtype);
-    } else {
-      set = tx_set_of(BS, f->reduced_tx_set);
-      txtype = mode_to_txtype(uvmode);
-      if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
+    const int txs = p == 0 ? txs_y : BS, l2n = imin_(5, 2 + txs), n = 1 << l2n, step = 1 << txs, nblk = 1 << (BS - txs);
+    for (int bi = 0; bi < nblk * nblk; bi++) {
+      const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step, tmi = rr * ms + cc;
+      if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
+      const int eob = f->m_eob[p][tmi];
+      const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
+      WAVE_SYNC();
+      for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx >> l2n) * f->stride + (idx & (n - 1))];
+      WAVE_SYNC();
+      build_level_map(w->qc, w->lev, n);
+      int txtype, off = -1, sym = 0, ns = 0, set;
+      if (p == 0) {
+        txtype = f->m_txtype[tmi];
+        off = intra_tx_cdf(f, txs, ymode, &ns, &set);
+        if (off >= 0) sym = txtype_to_sym(set, txtype);
+      } else {
+        set = tx_set_of(txs, f->reduced_tx_set);
+        txtype = mode_to_txtype(uvmode);
+        if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
+      }
+      int sctx2, dctx;
+      txb_ctx_dev(f, t, p, rr, cc, txs, BS, &sctx2, &dctx);
+      code_coeffs_lane0(w, eob, p, txs, txtype, sctx2, dctx, off, sym, ns);
     }
-    int sctx2, dctx;
-    txb_ctx_dev(f, t, p, r, c, BS, BS, &sctx2, &dctx);
-    code_coeffs_lane0(w, eob, p, BS, txtype, sctx2, dctx, off, sym, ns);
   }
   WAVE_SYNC();
 }

@@ -27,6 +27,15 @@
 #ifndef MI_PROFILE
 #define MI_PROFILE 0
 #endif
+// bisect hooks (MI_DEBUG_LEVEL): probe builds only (-DMI_DEBUG_HOOKS=1); release builds carry no debug branches in K1
+#ifndef MI_DEBUG_HOOKS
+#define MI_DEBUG_HOOKS 0
+#endif
+#if MI_DEBUG_HOOKS
+#define DBG_IS(f, v) ((f)->dbg == (v))
+#else
+#define DBG_IS(f, v) false
+#endif
 // phase timers (profiling builds only): per wave, accumulated in LDS, flushed to the tile's clock record
 #if MI_PROFILE
 #define PH_BEGIN() unsigned long long ph_t_ = clock64()
@@ -60,6 +69,11 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t lpred[N <= 16 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
+  // luma transform-size trial: the full-size winner is parked (levels in lpred / qpark), the sub-blocks go through ssrc / spred
+  int lm_cul, lm_dcc, ssctx, sdctx, sub_eob[4]; long long lm_mode_j;
+  uint16_t ssrc[(N / 2) * (N / 2)];
+  int32_t qpark[N <= 16 ? 1 : (N < 32 ? N * N : 1024)];
+  uint16_t spred[N <= 16 ? 1 : (N / 2) * (N / 2)];
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -124,10 +138,10 @@ __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
 template <int MAXN, int BS>
 __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
-                                    LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr) {
+                                    LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
   const LDS FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
-  const LDS uint16_t *src = k.sh->srcb[plane];
+  const LDS uint16_t *src = src_override ? src_override : k.sh->srcb[plane];
 #if MI_PROFILE
   LDS SharedScratch<MAXN> *SH = k.sh; const int W = WAVE_ID;
 #endif
@@ -198,7 +212,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   PH(1);
   WG_SYNC();
   PH(2);
-  if (f->dbg == 3) return 0;
+  if (DBG_IS(f, 3)) return 0;
   int sctx_p[3], dctx_p[3];
   for (int p = 0; p < 3; p++) { sctx_p[p] = SH->sctx[p]; dctx_p[p] = SH->dctx[p]; }
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
@@ -306,6 +320,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx;        // one-level-smaller luma transforms are tried after the mode decision
+  LDS int32_t *qpark = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->qpark;
+  LDS uint16_t *spred = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->spred;
   // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
   const bool pred_cached = MAXN <= 16 && NW > 1 && ncand * nn <= 768;
   if (pred_cached) {
@@ -324,6 +341,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     PH(2);
   }
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
+  uint32_t my_mrate = 0;                                      // mode (+ angle) rate of this wave's best candidate
   // 4x4 / 8x8: the (mode x tx type) trials of the block sixteen at a time, four per wave (one per 16-lane row, dev_group.h):
   // ONE round for the 3 x 5 trials of speed 4, two for 3 x 7, four for 7 x 7.  Between rounds a wave parks its best
   // candidate's reconstruction and levels in S->dcp (idle during the luma trials).
@@ -361,6 +379,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             my_j = jg; my_e = eg; my_g = gg; improved = true;
             my_mode = __builtin_amdgcn_readlane(m, gg * 16); my_delta = __builtin_amdgcn_readlane(delta, gg * 16); my_tx = __builtin_amdgcn_readlane(txtype, gg * 16);
             my_tr.eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); my_tr.cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); my_tr.dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+            my_mrate = (uint32_t)__builtin_amdgcn_readlane((int)mode_rate, gg * 16);
           }
         }
         if (rounds > 1 && improved) {                      // wave-uniform
@@ -395,7 +414,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     TxRes tr;
     long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
-    if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; cur ^= 1; }
+    if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
   PH(6);
@@ -416,16 +435,124 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
     fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
     fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
-    if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
-    if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; }
+    fill_map_dev(f->m_txsize, ms, r, c, n4, BS);
+    if (f->np > 1 || tx_trial) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
+    if (tx_trial) for (int i = LANE; i < qn; i += 64) qpark[i] = best_qc[i];      // the full-size levels, should the split trial lose
+    if (LANE == 0) {
+      SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; SH->lm_cul = my_tr.cul; SH->lm_dcc = my_tr.dcc;
+      SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
+    }
   }
   PH(7);
   WG_SYNC();
   PH(2);
-  if (f->dbg == 5) return 0;
-  if (best_j >= budget) return best_j;                      // wave-uniform: every wave reads the same LDS values
+  if (DBG_IS(f, 5)) return 0;
   const int best_mode = SH->lm_mode, best_delta = SH->lm_delta;
-  long long total_j = best_j; int any_coef = SH->lm_eob > 0;
+  long long luma_j = best_j; int any_coef = SH->lm_eob > 0;
+  // ---- luma transform size (rav1e rdo_tx_size_type under TX_MODE_SELECT; oracle/av1o_search.c try_block): the largest
+  // transform against four transforms one level smaller with the winning mode.  Each sub-block is predicted from the
+  // reconstruction of the ones before it (spec transform_block), so the four steps are serial; inside a step the tx types
+  // of the sub-block are dealt to the waves (16-lane rows for 4x4 / 8x8 transforms) like the candidates of a block.
+  if constexpr (BS > 0) if (f->tx_mode_select) {
+    const int maxw = 4 << BS;
+    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
+    const uint16_t *dcost = k.cost + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
+    luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
+    if (tx_trial) {
+      constexpr int SBS = BS - 1, hn = n >> 1, half = n4 >> 1, hnn = hn * hn, SCS = hn < 32 ? hn : 32;
+      long long j_split = SH->lm_mode_j + (((long long)dcost[1] * f->rdmult + 256) >> 9);
+      int stx_ns = 0, stx_set = 0;
+      const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
+      const int sntx = stx_off >= 0 ? stx_ns : 1;
+      int sub_any = 0;
+#pragma unroll 1
+      for (int q = 0; q < 4; q++) {
+        if (!(j_split < luma_j)) break;
+        const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half, sx = cc * 4, sy = rr * 4;
+        const int sU = availU || (q >> 1), sL = availL || (q & 1);
+        if (W == 0) {
+          const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
+          const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
+          int sc_, dc_;
+          txb_ctx_dev(f, t, 0, rr, cc, SBS, BS, &sc_, &dc_);
+          if (LANE == 0) { SH->ssctx = sc_; SH->sdctx = dc_; }
+          const int so = (q >> 1) * hn * n + (q & 1) * hn;
+          for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
+          load_edges(f, 0, sx, sy, hn, sL, sU, s_ar, s_bl, SH->ra[0] + EDGE_OFF, SH->rl[0] + EDGE_OFF);
+          predict_block(f, sx, sy, log2w - 1, sL, sU, best_mode, best_delta, ftype_y, ra, rl, wa, wl, S->etmp, spred);
+        }
+        WG_SYNC();
+        const int ssc = SH->ssctx, sdc = SH->sdctx;
+        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
+        bool sgrouped = false;
+        if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
+          sgrouped = true;
+          const int g = GROUP_ID, e = W * 4 + g;
+          if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
+            const bool live = e < sntx;
+            int txtype;
+            if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
+            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+            GroupRes gr;
+            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, &gr);
+            long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+            if (!live) j = J_INF;
+#pragma unroll
+            for (int gg = 0; gg < 4; gg++) {
+              const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+              const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+              if (jg < sj || (jg == sj && eg < se)) {
+                sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
+                s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+              }
+            }
+          }
+        }
+        if (!sgrouped) {
+          if constexpr (!(SBS <= BS_8 && NW == 4 && MAXN <= 16))
+          for (int e = W; e < sntx; e += NW) {
+            int txtype;
+            if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
+            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+            TxRes tr;
+            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr, SH->ssrc);
+            if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
+          }
+        }
+        if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+        WG_SYNC();
+        int sw = 0;
+        for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
+        const long long sub_j = SH->wbest_j[sw];
+        if (W == sw) {
+          const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
+          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
+          commit_plane<SBS>(f, 0, rr, cc, srec, sqc, s_eob, s_cul, s_dcc);
+          fill_map_dev(f->m_txtype, ms, rr, cc, half, s_eob ? stx : DCT_DCT);
+          fill_map_dev(f->m_decoded, ms, rr, cc, half, 1);
+          if (LANE == 0) SH->sub_eob[q] = s_eob;
+        }
+        WG_SYNC();
+        sub_any |= SH->sub_eob[q] > 0;
+        j_split += sub_j;
+        (void)SCS;
+      }
+      if (j_split < luma_j) {
+        luma_j = j_split; any_coef = sub_any;
+        if (W == 0) {
+          fill_map_dev(f->m_txsize, ms, r, c, n4, SBS);
+          if (f->np > 1) { const uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x; for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = gr_[(i / n) * f->stride + (i % n)]; }
+        }
+      } else if (W == 0) {
+        // the undivided transform stays: put its reconstruction, levels and contexts back
+        commit_plane<BS>(f, 0, r, c, SH->luma_rec, qpark, SH->lm_eob, SH->lm_cul, SH->lm_dcc);
+        fill_map_dev(f->m_txtype, ms, r, c, n4, SH->lm_eob ? SH->lm_tx : DCT_DCT);
+      }
+      WG_SYNC();
+    }
+  }
+  if (luma_j >= budget) return luma_j;                      // wave-uniform: every wave reads the same LDS values
+  long long total_j = luma_j;
 
   // ---- chroma, 4x4 / 8x8 blocks with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four
   // waves (plane x half of the range), then every candidate of a plane in one grouped evaluation (dev_group.h) ----
@@ -717,7 +844,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     total_j += best_uv;
     (void)qn;
   }
-  if (f->dbg == 6) return 0;
+  if (DBG_IS(f, 6)) return 0;
   // ---- skip flag ----
   const int skip = !any_coef;
   if (W == 0) {
@@ -738,8 +865,8 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
   constexpr int n = 4 << BS, n4 = 1 << BS, T = 64 * NW;
   uint16_t *srec = (uint16_t *)snap;                         // [3][n*n]
   int32_t *scoef = (int32_t *)(snap + 3 * n * n * 2);        // [3][n*n]
-  uint8_t *smaps = snap + 3 * n * n * 6;                     // 16 byte-maps [n4*n4]
-  uint16_t *seob = (uint16_t *)(smaps + 16 * n4 * n4);       // [3][n4*n4]
+  uint8_t *smaps = snap + 3 * n * n * 6;                     // 17 byte-maps [n4*n4]
+  uint16_t *seob = (uint16_t *)(smaps + 18 * n4 * n4);       // [3][n4*n4] (2-byte aligned)
   const int tid = threadIdx.x;
   for (int p = 0; p < f->np; p++) {
     uint16_t *gr = f->rec[p] + (size_t)(r * 4) * f->stride + c * 4;
@@ -750,10 +877,10 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
       else { gr[o] = srec[p * n * n + idx]; gc[o] = scoef[p * n * n + idx]; }
     }
   }
-  uint8_t *maps[16] = { f->m_bsize, f->m_skip, f->m_ymode, f->m_uvmode, f->m_txtype, f->m_cfl_sign, f->m_cfl_au, f->m_cfl_av,
-                        (uint8_t *)f->m_angle_y, (uint8_t *)f->m_angle_uv, f->m_lvl[0], f->m_lvl[1], f->m_lvl[2], f->m_dc[0], f->m_dc[1], f->m_dc[2] };
+  uint8_t *maps[17] = { f->m_bsize, f->m_skip, f->m_ymode, f->m_uvmode, f->m_txtype, f->m_cfl_sign, f->m_cfl_au, f->m_cfl_av,
+                        (uint8_t *)f->m_angle_y, (uint8_t *)f->m_angle_uv, f->m_lvl[0], f->m_lvl[1], f->m_lvl[2], f->m_dc[0], f->m_dc[1], f->m_dc[2], f->m_txsize };
 #pragma unroll
-  for (int m = 0; m < 16; m++) {
+  for (int m = 0; m < 17; m++) {
     if (f->np == 1 && (m == 11 || m == 12 || m == 14 || m == 15)) continue;
     uint8_t *g = maps[m];
     for (int i = tid; i < n4 * n4; i += T) {
@@ -768,7 +895,7 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
     }
   WG_SYNC();
 }
-#define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 16 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
+#define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
 __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
@@ -789,7 +916,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
     const int must_split = px > f->part_max || !has_rows || !has_cols;
     const int can_split = px > f->part_min || must_split;
     if (known_j < 0 || must_split) set_decoded_wg<NW>(f, r, c, n4, 0);
-    if (!can_split || (f->dbg == 9 && BS == 1)) {
+    if (!can_split || (DBG_IS(f, 9) && BS == 1)) {
       if constexpr (BS <= MAXBS) { if (known_j < 0) try_block<MAXN, BS, NW>(k, r, c); else set_decoded_wg<NW>(f, r, c, n4, 1); }
       return 0;
     }
@@ -804,20 +931,20 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
         long long j_split = ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          if (!(j_split < j_none) || f->dbg == 7) break;
+          if (!(j_split < j_none) || DBG_IS(f, 7)) break;
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
           sub_j[q] = try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split);
           j_split += sub_j[q];
           if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
         }
-        if (j_split < j_none && f->dbg != 7 && f->dbg != 8 && !(f->dbg == 10 && BS == 1)) do_split = 1;
+        if (j_split < j_none && !DBG_IS(f, 7) && !DBG_IS(f, 8) && !(DBG_IS(f, 10) && BS == 1)) do_split = 1;
         else { area_copy_dev<BS, NW>(f, k.snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
       }
     }
     if (do_split) {
       set_decoded_wg<NW>(f, r, c, n4, 0);
-      int chain = !must_split && f->dbg != 11;      // the four trial results are in place until a sibling decides to split
+      int chain = !must_split && !DBG_IS(f, 11);      // the four trial results are in place until a sibling decides to split
 #pragma unroll
       for (int q = 0; q < 4; q++)
         if (RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half, chain ? sub_j[q] : -1)) chain = 0;
@@ -839,7 +966,7 @@ template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
 
 template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
   return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2 +
-         ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + ((sizeof(FrameDev) + 15) & ~(size_t)15);
+         ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + (size_t)FRAMEDEV_K1_BYTES;
 }
 
 template <int MAXBS, int NW>
@@ -859,21 +986,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   LDS uint16_t *lcc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES);
   LDS FrameDev *lf = (LDS FrameDev *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES + CC_BYTES);
   // the frame descriptor, the scan tables and the coefficient slices of the rate table are staged in LDS once per tile
-  for (int i = threadIdx.x; i < (int)(sizeof(FrameDev) / 4); i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];
+  for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];   // only the head: K1 never reads the tail through `lf`
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
   for (int i = LANE; i < (int)sizeof(k.s->lev); i += 64) k.s->lev[i] = 0;        // level-map padding stays zero for the whole tile
   load_coef_cost(&k.cc, lcc, gf->cost, MAXBS, threadIdx.x, 64 * NW);
   k.f = lf; k.cost = gf->cost; k.ls = lsc;
   WG_SYNC();
   const LDS FrameDev *f = lf;
-  k.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
-  k.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
+  k.t.mi_row_start = gf->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
+  k.t.mi_col_start = gf->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
   k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
 #if MI_PROFILE
   if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
 #endif
   WG_SYNC();
-  if (f->dbg == 1) return;
+  if (DBG_IS(f, 1)) return;
   const unsigned long long clk0 = wall_clock64();
   for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
     for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)

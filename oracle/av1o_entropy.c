@@ -202,29 +202,39 @@ static void write_block(TileW *w, int r, int c, int bs) {
     if (bs >= BS_8 && uvmode >= V_PRED && uvmode <= D67_PRED)
       re_symbol(&w->ec, f->m_angle_uv[mi] + 3, w->cdf + CDF_ANGLE + (uvmode - V_PRED) * CDF_ANGLE_STRIDE, 7);
   }
-  /* TX_MODE_LARGEST: no tx_size syntax.  residual(): one transform block per plane */
+  /* read_block_tx_size(): tx_depth for every intra block above 4x4 under TX_MODE_SELECT, coded even when skip */
+  const int txs_y = f->m_txsize[mi];
+  if (f->tx_mode_select && bs > BS_4) {
+    const int maxw = 4 << bs;
+    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
+    re_symbol(&w->ec, bs - txs_y, w->cdf + CDF_TX_SIZE + ((bs - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, bs == BS_8 ? 2 : 3);
+  }
   if (skip) return;
-  const int txs = bs, n = imin(32, 4 << txs);
+  /* residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not) */
   static int32_t qc[1024];
   for (int p = 0; p < f->np; p++) {
-    if (r >= f->mi_rows || c >= f->mi_cols) continue;   /* cannot happen: block origins are inside the frame */
-    const int eob = f->m_eob[p][mi];
-    const int32_t *src = f->coef[p] + (r * 4) * f->stride + c * 4;
-    for (int i = 0; i < n; i++) memcpy(qc + i * n, src + i * f->stride, sizeof(int32_t) * (size_t)n);
-    int txtype, off = -1, sym = 0, ns = 0, set;
-    if (p == 0) {
-      txtype = f->m_txtype[mi];
-      off = av1o_intra_tx_cdf(f, txs, ymode, &ns, &set);
-      if (off >= 0) sym = av1o_tx_type_to_symbol(set, txtype);
-    } else {
-      set = av1o_tx_set(txs, f->cfg.reduced_tx_set);
-      txtype = av1o_mode_to_txtype(uvmode);
-      if (!av1o_tx_type_in_set(set, txtype)) txtype = DCT_DCT;
+    const int txs = p == 0 ? txs_y : bs, n = imin(32, 4 << txs), step = 1 << txs, nblk = 1 << (bs - txs);
+    for (int by = 0; by < nblk; by++) for (int bx = 0; bx < nblk; bx++) {
+      const int rr = r + by * step, cc = c + bx * step, tmi = rr * ms + cc;
+      if (rr >= f->mi_rows || cc >= f->mi_cols) continue;   /* transform blocks that start outside the frame are not coded */
+      const int eob = f->m_eob[p][tmi];
+      const int32_t *src = f->coef[p] + (rr * 4) * f->stride + cc * 4;
+      for (int i = 0; i < n; i++) memcpy(qc + i * n, src + i * f->stride, sizeof(int32_t) * (size_t)n);
+      int txtype, off = -1, sym = 0, ns = 0, set;
+      if (p == 0) {
+        txtype = f->m_txtype[tmi];
+        off = av1o_intra_tx_cdf(f, txs, ymode, &ns, &set);
+        if (off >= 0) sym = av1o_tx_type_to_symbol(set, txtype);
+      } else {
+        set = av1o_tx_set(txs, f->cfg.reduced_tx_set);
+        txtype = av1o_mode_to_txtype(uvmode);
+        if (!av1o_tx_type_in_set(set, txtype)) txtype = DCT_DCT;
+      }
+      int sctx2, dctx, cul, dcc;
+      /* contexts must be derived from neighbours exactly as phase 1 left them */
+      av1o_txb_ctx(f, t, p, rr, cc, txs, bs, &sctx2, &dctx);
+      av1o_code_coeffs(f, qc, eob, p, txs, txtype, sctx2, dctx, off, sym, ns, &k, &cul, &dcc);
     }
-    int sctx2, dctx, cul, dcc;
-    /* contexts must be derived from neighbours exactly as phase 1 left them */
-    av1o_txb_ctx(f, t, p, r, c, txs, bs, &sctx2, &dctx);
-    av1o_code_coeffs(f, qc, eob, p, txs, txtype, sctx2, dctx, off, sym, ns, &k, &cul, &dcc);
   }
 }
 

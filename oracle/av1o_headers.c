@@ -92,7 +92,7 @@ static void write_frame_header(const Av1oFrame *f, BitW *b, int tile_size_bytes)
     for (int p = 0; p < f->np; p++) bw_put(b, 1, 2);   /* lr_type 1 -> RESTORE_SWITCHABLE (Remap_Lr_Type) */
     bw_put(b, 0, 1);                                   /* lr_unit_shift = 0: 64x64 units; 4:4:4 / 4:0:0 -> no lr_uv_shift */
   }
-  bw_put(b, 0, 1);                     /* tx_mode_select = 0 -> TX_MODE_LARGEST */
+  bw_put(b, (uint32_t)f->tx_mode_select, 1);   /* tx_mode_select: TX_MODE_SELECT / TX_MODE_LARGEST */
   bw_put(b, (uint32_t)f->cfg.reduced_tx_set, 1);
 }
 
@@ -150,7 +150,8 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   }
   f->m_bsize = (uint8_t *)zalloc(nmi); f->m_skip = (uint8_t *)zalloc(nmi); f->m_ymode = (uint8_t *)zalloc(nmi);
   f->m_uvmode = (uint8_t *)zalloc(nmi); f->m_txtype = (uint8_t *)zalloc(nmi); f->m_cfl_sign = (uint8_t *)zalloc(nmi);
-  f->m_cfl_au = (uint8_t *)zalloc(nmi); f->m_cfl_av = (uint8_t *)zalloc(nmi);
+  f->m_cfl_au = (uint8_t *)zalloc(nmi); f->m_cfl_av = (uint8_t *)zalloc(nmi); f->m_txsize = (uint8_t *)zalloc(nmi);
+  f->tx_mode_select = cfg->rdo_tx || cfg->inter_tx_split;
   f->m_angle_y = (int8_t *)zalloc(nmi); f->m_angle_uv = (int8_t *)zalloc(nmi); f->m_decoded = (uint8_t *)zalloc(nmi);
   f->cdef_idx = (int8_t *)zalloc((size_t)f->sb_cols * f->sb_rows);
   av1o_select_quantizers(f);
@@ -189,6 +190,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   out->base_q_idx = f->base_q_idx; out->tile_cols = f->tile_cols; out->tile_rows = f->tile_rows;
   for (int p = 0; p < f->np; p++) { free(f->src[p]); free(f->rec[p]); free(f->coef[p]); free(f->m_lvl[p]); free(f->m_dc[p]); free(f->m_eob[p]); }
   for (int p = 0; p < f->np; p++) { free(f->dbk[p]); free(f->lr_type[p]); free(f->lr_set[p]); free(f->lr_xqd[p]); }
+  free(f->m_txsize);
   free(f->m_cfl_sign); free(f->m_cfl_au); free(f->m_cfl_av); free(f->m_angle_y); free(f->m_angle_uv); free(f->m_decoded); free(f->cdef_idx);
   free(f);
   return 0;

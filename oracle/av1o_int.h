@@ -52,6 +52,8 @@ typedef struct Av1oFrame {
   int32_t *coef[3];             /* signed quantized levels at pixel positions */
   /* mode-info maps, one entry per 4x4 (mi) */
   uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av;
+  uint8_t *m_txsize;            /* luma transform size of the block (TX_4X4 .. TX_64X64), uniform over the block */
+  int tx_mode_select;           /* TX_MODE_SELECT: rdo_tx_decision || inter_tx_split (rav1e FrameInvariants, recall) */
   int8_t *m_angle_y, *m_angle_uv;
   uint8_t *m_lvl[3], *m_dc[3];  /* coefficient contexts left behind by each tx block */
   uint16_t *m_eob[3];           /* eob of the tx block whose top-left mi this is */

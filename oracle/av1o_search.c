@@ -21,7 +21,7 @@ typedef struct {            /* saved state of one block area (for NONE-vs-SPLIT 
   int n;
   uint16_t rec[3][64 * 64];
   int32_t coef[3][64 * 64];
-  uint8_t maps[10][16 * 16];
+  uint8_t maps[11][16 * 16];
   uint8_t lvl[3][16 * 16], dc[3][16 * 16];
   uint16_t eob[3][16 * 16];
 } AreaSnap;
@@ -30,7 +30,7 @@ static uint8_t *map_ptr(Av1oFrame *f, int i) {
   switch (i) {
     case 0: return f->m_bsize; case 1: return f->m_skip; case 2: return f->m_ymode; case 3: return f->m_uvmode;
     case 4: return f->m_txtype; case 5: return f->m_cfl_sign; case 6: return f->m_cfl_au; case 7: return f->m_cfl_av;
-    case 8: return (uint8_t *)f->m_angle_y; default: return (uint8_t *)f->m_angle_uv;
+    case 8: return (uint8_t *)f->m_angle_y; case 9: return (uint8_t *)f->m_angle_uv; default: return f->m_txsize;
   }
 }
 static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save) {
@@ -49,7 +49,7 @@ static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save)
       else { memcpy(f->m_lvl[p] + o, s->lvl[p] + i * n4, (size_t)n4); memcpy(f->m_dc[p] + o, s->dc[p] + i * n4, (size_t)n4); memcpy(f->m_eob[p] + o, s->eob[p] + i * n4, 2 * (size_t)n4); }
     }
   }
-  for (int m = 0; m < 10; m++) {
+  for (int m = 0; m < 11; m++) {
     uint8_t *mp = map_ptr(f, m);
     for (int i = 0; i < n4; i++) {
       if (save) memcpy(s->maps[m] + i * n4, mp + (r + i) * f->mi_stride + c, (size_t)n4);
@@ -92,10 +92,10 @@ static int64_t sse_block(const uint16_t *a, int as, const uint16_t *b, int bs_, 
 
 /* One transform block: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J. */
 typedef struct { int eob, cul, dcc; int64_t sse; uint32_t rate; } TxRes;
-static int64_t eval_tx(Search *s, int plane, int r, int c, int bs, const uint16_t *pred /* n x n, stride n */, int txtype,
+static int64_t eval_tx(Search *s, int plane, int r, int c, int txs, int bs /* block size (all-zero context) */, const uint16_t *pred /* n x n, stride n */, int txtype,
                        int tx_off, int tx_sym, int tx_ns, uint16_t *rec_out /* n x n */, int32_t *qc_out, TxRes *tr) {
   Av1oFrame *f = s->f;
-  const int n = 4 << bs, cs = imin(n, 32), x = c * 4, y = r * 4, txs = bs;
+  const int n = 4 << txs, cs = imin(n, 32), x = c * 4, y = r * 4;
   static int16_t resid[64 * 64]; static int32_t coef[32 * 32], dq[32 * 32];
   const uint16_t *src = f->src[plane] + y * f->stride + x;
   for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
@@ -167,7 +167,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   for (int i = 1; i < 13; i++) { int v = order[i], j = i; while (j > 0 && satd[order[j - 1]] > satd[v]) { order[j] = order[j - 1]; j--; } order[j] = v; }
   const int ncand = f->cfg.complex_modes ? 7 : 3;
   /* ---- full RD over surviving (mode, angle delta) x tx type ---- */
-  int64_t best_j = INT64_MAX; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
+  int64_t best_j = INT64_MAX, best_mode_j = 0; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
   int tx_ns, tx_set;
   for (int ci = 0; ci < ncand; ci++) {
     const int m = order[ci];
@@ -192,20 +192,66 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
       if (ntx > 1) txtype = av1o_symbol_to_tx_type(tx_set, ti);
       else { txtype = av1o_mode_to_txtype(m); if (tx_off < 0 || !av1o_tx_type_in_set(tx_set, txtype)) txtype = DCT_DCT; }
       TxRes tr;
-      int64_t j = eval_tx(s, 0, r, c, bs, pred, txtype, tx_off, tx_off >= 0 ? av1o_tx_type_to_symbol(tx_set, txtype) : 0, tx_ns, rec_tmp, qc_tmp, &tr);
+      int64_t j = eval_tx(s, 0, r, c, bs, bs, pred, txtype, tx_off, tx_off >= 0 ? av1o_tx_type_to_symbol(tx_set, txtype) : 0, tx_ns, rec_tmp, qc_tmp, &tr);
       j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
       if (j < best_j) {
+        best_mode_j = ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
         best_j = j; best_mode = m; best_delta = delta; best_tx = txtype; best_tr = tr;
         memcpy(rec_best[0], rec_tmp, 2 * (size_t)(n * n)); memcpy(qc_best[0], qc_tmp, 4 * (size_t)imin(n * n, 1024));
       }
     }
   }
-  commit_plane(f, 0, r, c, bs, rec_best[0], qc_best[0], &best_tr);
+  /* ---- luma transform size (rav1e rdo_tx_size_type; TX_MODE_SELECT): the largest transform against four transforms one
+   * level smaller, same prediction mode, each sub-block predicted from the reconstruction of the ones before it (spec
+   * transform_block) and free to pick its own tx type.  Depth 2 is not searched. */
+  int txs_final = bs, any_coef = best_tr.eob > 0;
+  if (f->tx_mode_select && bs > BS_4) {
+    const int maxw = 4 << bs;
+    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
+    const uint32_t *dcost = f->cost + CDF_TX_SIZE + ((bs - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
+    best_j += ((int64_t)dcost[0] * f->rdmult[0] + 256) >> 9;
+    if (f->cfg.rdo_tx) {
+      const int half = n4 >> 1, hn = n >> 1, stx = bs - 1;
+      int64_t j_split = best_mode_j + (((int64_t)dcost[1] * f->rdmult[0] + 256) >> 9);
+      int sub_any = 0;
+      static uint16_t spred[32 * 32], srec[2][32 * 32]; static int32_t sqc[2][32 * 32];
+      int stx_ns, stx_set;
+      const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
+      const int sntx = stx_off >= 0 ? stx_ns : 1;
+      for (int k = 0; k < 4 && j_split < best_j; k++) {
+        const int rr = r + (k >> 1) * half, cc = c + (k & 1) * half;
+        const int sU = availU || (k >> 1), sL = availL || (k & 1);
+        const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
+        const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
+        av1o_predict_intra(f, t, 0, cc * 4, rr * 4, log2w - 1, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
+        int64_t bj = INT64_MAX; int btx = DCT_DCT, cur = 0; TxRes btr = { 0, 0, 0, 0, 0 };
+        for (int ti = 0; ti < sntx; ti++) {
+          int txtype;
+          if (sntx > 1) txtype = av1o_symbol_to_tx_type(stx_set, ti);
+          else { txtype = av1o_mode_to_txtype(best_mode); if (stx_off < 0 || !av1o_tx_type_in_set(stx_set, txtype)) txtype = DCT_DCT; }
+          TxRes tr;
+          const int64_t j = eval_tx(s, 0, rr, cc, stx, bs, spred, txtype, stx_off, stx_off >= 0 ? av1o_tx_type_to_symbol(stx_set, txtype) : 0, stx_ns, srec[cur], sqc[cur], &tr);
+          if (j < bj) { bj = j; btx = txtype; btr = tr; cur ^= 1; }
+        }
+        commit_plane(f, 0, rr, cc, stx, srec[cur ^ 1], sqc[cur ^ 1], &btr);
+        fill_map(f->m_txtype, ms, rr, cc, half, btr.eob ? btx : DCT_DCT);
+        set_decoded(f, rr, cc, stx, 1);
+        sub_any |= btr.eob > 0;
+        j_split += bj;
+      }
+      set_decoded(f, r, c, bs, 0);
+      if (j_split < best_j) { best_j = j_split; txs_final = stx; any_coef = sub_any; }
+    }
+  }
+  if (txs_final == bs) {
+    commit_plane(f, 0, r, c, bs, rec_best[0], qc_best[0], &best_tr);
+    fill_map(f->m_txtype, ms, r, c, n4, best_tr.eob ? best_tx : DCT_DCT);
+  }
+  fill_map(f->m_txsize, ms, r, c, n4, txs_final);
   fill_map(f->m_ymode, ms, r, c, n4, best_mode);
   fill_map((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)best_delta);
-  fill_map(f->m_txtype, ms, r, c, n4, best_tr.eob ? best_tx : DCT_DCT);
   fill_map(f->m_bsize, ms, r, c, n4, bs);
-  int64_t total_j = best_j; int any_coef = best_tr.eob > 0;
+  int64_t total_j = best_j;
 
   /* ---- chroma ---- */
   if (f->np > 1) {
@@ -249,7 +295,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         } else {
           av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, um, delta, ftype_uv, pred, n);
         }
-        j += eval_tx(s, p, r, c, bs, pred, txtype, -1, 0, 0, rec_best[p], qc_best[p], &trs[p]);
+        j += eval_tx(s, p, r, c, bs, bs, pred, txtype, -1, 0, 0, rec_best[p], qc_best[p], &trs[p]);
       }
       j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
       if (j < best_uv) {
