@@ -38,6 +38,8 @@ struct FrameDev {
   // tools
   int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, tx_mode_select;
   int tile_cols;
+  // Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent)
+  const uint32_t *act, *svar8, *svar4; int tune_psnr;
   uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
   int dbg;                   // debug bisect level (0 = off; probe builds only)
   unsigned long long *prof_out;  // profiling builds: per launch-wide tile job, 4 waves x 16 phase cycle counters
@@ -108,6 +110,30 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #define WG_SYNC() __syncthreads()
 
 struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };
+
+// ---- Tune::Psychovisual helpers (oracle/av1o_common.c av1o_psy_boost_q14 / av1o_cell_var; rav1e dist.rs cdef_dist_kernel,
+// activity.rs, recalled): integer, bit-identical to the CPU restatement.
+__device__ inline uint32_t psy_boost_q14(uint32_t sv, uint32_t dv) {
+  const unsigned long long num = 4033ull * ((unsigned long long)sv + dv + 16384);
+  const unsigned long long rad = (16265089ull + (unsigned long long)sv * dv) << 16;
+  unsigned long long x = (unsigned long long)sqrt((double)rad);      // a guess; the two loops make it the exact floor root
+  while (x * x > rad) x--;
+  while ((x + 1) * (x + 1) <= rad) x++;
+  return (uint32_t)(((num << 8) + x / 2) / x);
+}
+// 64 x variance of a w x w cell (w = 8 or 4, 4x4 scaled to the 8x8 equivalent) on the 8-bit scale
+__device__ __forceinline__ uint32_t psy_cell_var(uint32_t sum, uint32_t sum2, int w, int bd) {
+  int v = w == 8 ? (int)sum2 - (int)((sum * sum + 32u) >> 6) : ((int)sum2 - (int)((sum * sum + 8u) >> 4)) << 2;
+  if (v < 0) v = 0;
+  return (uint32_t)v >> (2 * (bd - 8));
+}
+// distortion of one cell: SSE boosted by the SSIM-like factor, then by the cell's activity scale
+__device__ __forceinline__ int psy_cell_dist(uint32_t sse, uint32_t sd, uint32_t qd, uint32_t svar, uint32_t act, int w, int bd) {
+  const uint32_t b = psy_boost_q14(svar, psy_cell_var(sd, qd, w, bd));
+  unsigned long long d = ((unsigned long long)sse * b + 8192) >> 14;
+  d = (d * act + 8192) >> 14;
+  return (int)d;
+}
 
 __device__ __forceinline__ int tx_set_of(int txs, int reduced) { return txs >= 3 ? 0 : (reduced ? 2 : (txs == 2 ? 2 : 1)); }
 __device__ __forceinline__ int tx_set_count(int set) { return set == 0 ? 1 : (set == 1 ? 7 : 5); }

@@ -33,7 +33,7 @@ struct GroupRes { int eob, cul, dcc, sse; uint32_t rate; };
 template <int N, typename CostPtr>
 __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS uint16_t *ls, const LDS FrameDev *f, LDS GroupBuf8 *gb,
                                   const LDS uint16_t *src, const LDS uint16_t *pred, int plane, int txs, int txtype,
-                                  int skip_ctx, int dc_ctx, int tx_off, int tx_sym, GroupRes *res) {
+                                  int skip_ctx, int dc_ctx, int tx_off, int tx_sym, int psy_sv, int psy_act, GroupRes *res) {
   constexpr int P = N + 1, nc = N * N, IT = nc / 16, bwl = N == 4 ? 2 : 3, st = N + 4;
   const int gl = GROUP_LANE;
   const int bd = f->bd;
@@ -185,10 +185,14 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
     }
     WAVE_SYNC();
   }
-  int s = 0;
+  // distortion (Tune::Psychovisual): psy_sv >= 0 = luma, the block is one cdef-dist cell (its SSE boosted by the SSIM-like
+  // factor of source / reconstruction variance) x activity; psy_sv < 0 = plain SSE x the activity scale psy_act (Q14)
+  int s = 0, sd = 0, qd = 0;
 #pragma unroll
-  for (int k = 0; k < IT; k++) { const int idx = gl + 16 * k; const int d = (int)src[idx] - (int)gb->rec[idx]; s += __mul24(d, d); }
-  res->sse = row_sum_i32(s);                     // <= 64 * 1023^2 < 2^27
+  for (int k = 0; k < IT; k++) { const int idx = gl + 16 * k; const int rv = gb->rec[idx], d = (int)src[idx] - rv; s += __mul24(d, d); sd += rv; qd += __mul24(rv, rv); }
+  s = row_sum_i32(s);                            // <= 64 * 1023^2 < 2^27
+  if (psy_sv >= 0) { sd = row_sum_i32(sd); qd = row_sum_i32(qd); res->sse = psy_cell_dist((uint32_t)s, (uint32_t)sd, (uint32_t)qd, (uint32_t)psy_sv, (uint32_t)psy_act, N == 4 ? 4 : 8, bd); }
+  else res->sse = (int)(((unsigned long long)(uint32_t)s * (uint32_t)psy_act + 8192) >> 14);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

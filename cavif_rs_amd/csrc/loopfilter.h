@@ -295,6 +295,8 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
       long long cst[8];
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) cst[idx] = 0;
+      const int cell = (r >> 1) * (f->pw >> 3) + (c >> 1);
+      const uint32_t cell_sv = f->svar8[cell], cell_act = f->act[cell];
       for (int p = 0; p < f->np; p++) {
         const int y = r * 4 + py_l, x = c * 4 + px_l;
         const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
@@ -305,7 +307,10 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
           int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
           const int v = (pri == 0 && sec == 0) ? un : cdef_apply_taps(un, tap, valid, pri, sec, damping, cs);
           const int d = v - sv;
-          const long long sse = (long long)wave_sum_i32(__mul24(d, d));          // 64 samples * 1023^2 < 2^26
+          long long sse = (long long)wave_sum_i32(__mul24(d, d));                // 64 samples * 1023^2 < 2^26
+          // Tune::Psychovisual (rav1e rdo_loop_plane_error): luma through the cdef-dist kernel of the 8x8 block, chroma SSE x activity
+          if (p == 0 && !f->tune_psnr) sse = psy_cell_dist((uint32_t)sse, (uint32_t)wave_sum_i32(v), (uint32_t)wave_sum_i32(__mul24(v, v)), cell_sv, cell_act, 8, f->bd);
+          else sse = (long long)(((unsigned long long)sse * cell_act + 8192) >> 14);
           cst[idx] += (sse * f->wq[p]) >> 5;
         }
       }
@@ -342,6 +347,30 @@ __global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int w
       f->fin[p][(size_t)y * f->stride + x] = (uint16_t)v;
     }
   }
+}
+
+// ---------------------------------------------------------------- activity mask (Tune::Psychovisual)
+// One thread per 8x8 luma cell of the padded source: the four 4x4 variances (8x8-equivalent), the 8x8 variance and the cell's
+// activity scale = boost(var, var) (rav1e activity.rs ActivityMask::fill_scales; oracle av1o_activity).  grid = (cells / 256, frames)
+__global__ __launch_bounds__(256) void activity_kernel(const FrameDev *frames) {
+  const FrameDev *f = frames + blockIdx.y;
+  const int cw = f->pw >> 3, chh = f->ph >> 3, cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= cw * chh) return;
+  const int cy = cell / cw, cx = cell - cy * cw;
+  uint32_t s8 = 0, q8 = 0;
+  for (int k = 0; k < 4; k++) {
+    const int x0 = cx * 8 + (k & 1) * 4, y0 = cy * 8 + (k >> 1) * 4;
+    uint32_t s4 = 0, q4 = 0;
+    for (int i = 0; i < 4; i++) {
+      const uint16_t *row = f->src[0] + (size_t)(y0 + i) * f->stride + x0;
+      for (int j = 0; j < 4; j++) { const uint32_t v = row[j]; s4 += v; q4 += v * v; }
+    }
+    ((uint32_t *)f->svar4)[(y0 >> 2) * f->mi_stride + (x0 >> 2)] = psy_cell_var(s4, q4, 4, f->bd);
+    s8 += s4; q8 += q4;
+  }
+  const uint32_t v = psy_cell_var(s8, q8, 8, f->bd);
+  ((uint32_t *)f->svar8)[cell] = v;
+  ((uint32_t *)f->act)[cell] = f->tune_psnr ? 16384u : psy_boost_q14(v, v);
 }
 
 // ---------------------------------------------------------------- K0: front end

@@ -102,6 +102,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.lf_out = (int *)take(64);
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
+  { const size_t ncell = (size_t)(p.pw / 8) * (p.ph / 8); d.act = (const uint32_t *)take(ncell * 4); d.svar8 = (const uint32_t *)take(ncell * 4); d.svar4 = (const uint32_t *)take(nmi * 4); }
   {
     const size_t nlr = (size_t)lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) * p.np;
     for (int i = 0; i < 3; i++) d.lrp[i] = (i < p.np && p.cfg.lrf) ? (uint16_t *)take(npx * 2) : nullptr;
@@ -134,7 +135,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
   d.tx_mode_select = c.rdo_tx_decision || c.inter_tx_split;    // rav1e FrameInvariants.tx_mode_select (recall)
   d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef; d.fast_deblock = c.fast_deblock;
-  d.enable_restoration = c.lrf; d.sgr_full = c.sgr_full;
+  d.enable_restoration = c.lrf; d.sgr_full = c.sgr_full; d.tune_psnr = c.tune_psnr;
   { const uint32_t cdf[3] = { 9413, 22581, 32768 }; uint32_t lo = 0; for (int i = 0; i < 3; i++) { d.lr_cost[i] = neg_log2_q9(cdf[i] - lo); lo = cdf[i]; } }   // libaom default_switchable_restore_cdf
   d.tile_cols = p.tiles.cols; d.tile_rows = p.tiles.rows; d.tile_cols_log2 = p.tiles.cols_log2; d.tile_rows_log2 = p.tiles.rows_log2;
   for (int i = 0; i <= p.tiles.cols; i++) d.tile_col_start[i] = p.tiles.col_start[i];
@@ -430,7 +431,9 @@ int mi_batch_encode_async(mi_batch *b) {
   HIP_OK(hipMemcpyAsync(b->d_frames, b->hframes.data(), sizeof(FrameDev) * b->hframes.size(), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
-  // ---- K1 tile search
+  // ---- activity mask (Tune::Psychovisual), then K1 tile search
+  { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
+    hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
   HIP_OK(hipEventRecord(b->ev[1], s));
   for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
@@ -628,6 +631,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
+  hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
   HIP_OK(launch_search(p.maxbs, d_frame, d_jobs, njobs, s));
   const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
 #define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)

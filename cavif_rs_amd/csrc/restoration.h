@@ -204,9 +204,19 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
       }
     }
     acc[0] = s;
-    lr_block_sum(L, acc, 1);
+    // the unit's mean activity scale (Q14) over the 8x8 cells it covers: every distortion of the unit is scaled by it
+    const int ux0 = uc * 64, ux1 = uc == ucols - 1 ? f->w : ux0 + 64, uy0 = imax_(0, ur * 64 - 8), uy1 = ur == urows - 1 ? f->h : ur * 64 + 56;
+    const int cx0 = ux0 >> 3, cx1 = (ux1 - 1) >> 3, cy0 = uy0 >> 3, cy1 = (uy1 - 1) >> 3, ncx = cx1 - cx0 + 1, cnt = ncx * (cy1 - cy0 + 1);
+    long long a = 0;
+    for (int i = threadIdx.x; i < cnt; i += 256) a += f->act[(cy0 + i / ncx) * (f->pw >> 3) + cx0 + i % ncx];
+    acc[1] = a;
+    lr_block_sum(L, acc, 2);
+    if (threadIdx.x == 0) L.xq[0] = (int)((L.tot[1] + cnt / 2) / cnt);
+    __syncthreads();
   }
-  long long best_cost = ((L.tot[0] * f->wq[plane]) >> 5) + (((long long)f->lr_cost[0] * f->rdmult + 256) >> 9);
+  const long long unit_act = L.xq[0];
+  long long best_cost = ((((L.tot[0] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)f->lr_cost[0] * f->rdmult + 256) >> 9);
+  __syncthreads();
   int best_type = 0, best_set = 0, best_x0 = 0, best_x1 = 0;
   const int nsets = f->sgr_full ? 16 : 4;
   int flt0[16], flt1[16];
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
         uint32_t rate = f->lr_cost[2] + 4 * 512, bits;
         if (r0) rate += 512u * (uint32_t)lr_subexp_code(xq0, -96, 32, -32, &bits);
         if (r1) rate += 512u * (uint32_t)lr_subexp_code(xq1, -32, 96, 31, &bits);
-        const long long cost = ((L.tot[0] * f->wq[plane]) >> 5) + (((long long)rate * f->rdmult + 256) >> 9);
+        const long long cost = ((((L.tot[0] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)rate * f->rdmult + 256) >> 9);
         if (cost < best_cost) { best_cost = cost; best_type = 1; best_set = set; best_x0 = xq0; best_x1 = xq1; }
         __syncthreads();
       }

@@ -71,6 +71,10 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
   // luma transform-size trial: the full-size winner is parked (levels in lpred / qpark), the sub-blocks go through ssrc / spred
   int lm_cul, lm_dcc, ssctx, sdctx, sub_eob[4]; long long lm_mode_j;
+  // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
+  // its own variance), the four 4x4 variances of an 8x8 block, the same for the sub-block of the tx-size trial, and the
+  // block's mean activity for chroma
+  int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
   uint16_t ssrc[(N / 2) * (N / 2)];
   int32_t qpark[N <= 16 ? 1 : (N < 32 ? N * N : 1024)];
   uint16_t spred[N <= 16 ? 1 : (N / 2) * (N / 2)];
@@ -135,10 +139,41 @@ __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b
   return wave_sum_i64((long long)s);
 }
 
+// Psychovisual luma distortion of an n x n block by one wave (oracle av1o_psy_dist_luma): the 64 lanes are dealt to the 8x8
+// cells (64 / cells lanes per cell; a 4x4 block is one cell of 16 samples), sums reduce inside a cell's lane group, every
+// group prices its own cell (boost + activity) in parallel, the cells add up.
+template <int n> __device__ inline long long psy_dist_wave(const LDS uint16_t *src, const LDS uint16_t *rec, const LDS int *sv, const LDS int *act, int bd) {
+  constexpr int w = n == 4 ? 4 : 8, cp = n / w, ncell = cp * cp;
+  constexpr int LPC = n == 4 ? 16 : 64 / ncell, PPL = n == 4 ? 1 : 64 / LPC;
+  const int cell = LANE / LPC, li = LANE % LPC;
+  uint32_t sd = 0, qd = 0, se = 0;
+  if (cell < ncell) {
+    const int cy = cell / cp, cx = cell % cp;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+      const int q = li + LPC * k, o = (cy * w + q / w) * n + cx * w + q % w;
+      const int d = rec[o], e = (int)src[o] - d;
+      sd += (uint32_t)d; qd += (uint32_t)__mul24(d, d); se += (uint32_t)__mul24(e, e);
+    }
+  }
+  if constexpr (LPC == 64) { sd = (uint32_t)wave_sum_i32((int)sd); qd = (uint32_t)wave_sum_i32((int)qd); se = (uint32_t)wave_sum_i32((int)se); }
+  else if constexpr (LPC == 16) { sd = (uint32_t)row_sum_i32((int)sd); qd = (uint32_t)row_sum_i32((int)qd); se = (uint32_t)row_sum_i32((int)se); }
+  else if constexpr (LPC == 4) {
+    sd += (uint32_t)DPP_(0, sd, 0xB1, 0xF); sd += (uint32_t)DPP_(0, sd, 0x4E, 0xF);
+    qd += (uint32_t)DPP_(0, qd, 0xB1, 0xF); qd += (uint32_t)DPP_(0, qd, 0x4E, 0xF);
+    se += (uint32_t)DPP_(0, se, 0xB1, 0xF); se += (uint32_t)DPP_(0, se, 0x4E, 0xF);
+  }
+  int dist = 0;
+  if (cell < ncell && li == 0) dist = psy_cell_dist(se, sd, qd, (uint32_t)sv[cell], (uint32_t)act[cell], w, bd);
+  if constexpr (n >= 32) return wave_sum_i64((long long)dist);
+  return (long long)wave_sum_i32(dist);
+}
+
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
 template <int MAXN, int BS>
 __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
-                                    LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr) {
+                                    LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr,
+                                    const LDS int *psv = nullptr, const LDS int *pact = nullptr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
   const LDS FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
   const LDS uint16_t *src = src_override ? src_override : k.sh->srcb[plane];
@@ -161,7 +196,9 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   if (eob > 0) inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
   tr->eob = eob;
   PH(20);
-  tr->sse = sse_dev(src, rec_out, n * n);
+  // distortion: luma = psychovisual cdef-dist per 8x8 cell x activity; chroma = SSE x the block's mean activity
+  if (plane == 0 && !f->tune_psnr) tr->sse = psy_dist_wave<n>(src, rec_out, psv ? psv : (const LDS int *)k.sh->psv, pact ? pact : (const LDS int *)k.sh->pact, f->bd);
+  else { const long long e = sse_dev(src, rec_out, n * n); tr->sse = plane == 0 ? e : (e * k.sh->cact + 8192) >> 14; }
   PH(21);
   return ((tr->sse * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
 }
@@ -208,6 +245,18 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     const uint16_t *g = f->src[p] + (size_t)y * f->stride + x;
     for (int idx = LANE; idx < nn; idx += 64) SH->srcb[p][idx] = g[(idx / n) * f->stride + (idx % n)];
     load_edges(f, p, x, y, n, availL, availU, have_ar, have_bl, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF);
+  }
+  if (W == 0) {                                               // wave 0 stages no plane: the block's psychovisual references
+    constexpr int cp = n >= 8 ? n / 8 : 1, ncell = cp * cp;
+    const int cw = f->pw >> 3;
+    int a = 0;
+    if (LANE < ncell) {
+      const int cell = ((y >> 3) + LANE / cp) * cw + (x >> 3) + LANE % cp;
+      a = (int)f->act[cell]; SH->pact[LANE] = a; SH->psv[LANE] = (int)(n == 4 ? f->svar4[mi] : f->svar8[cell]);
+    }
+    if (BS == 1 && LANE < 4) SH->psv4[LANE] = (int)f->svar4[(r + (LANE >> 1)) * ms + c + (LANE & 1)];
+    const int tot = wave_sum_i32(a);
+    if (LANE == 0) SH->cact = (tot + ncell / 2) / ncell;
   }
   PH(1);
   WG_SYNC();
@@ -367,7 +416,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
         GroupRes gr;
         eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
-                      tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, &gr);
+                      tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, f->tune_psnr ? -1 : SH->psv[0], SH->pact[0], &gr);
         long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (!live) j = J_INF;
         bool improved = false;
@@ -476,6 +525,13 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
           int sc_, dc_;
           txb_ctx_dev(f, t, 0, rr, cc, SBS, BS, &sc_, &dc_);
           if (LANE == 0) { SH->ssctx = sc_; SH->sdctx = dc_; }
+          {
+            constexpr int scp = hn >= 8 ? hn / 8 : 1, pcp = n / 8;
+            if (LANE < scp * scp) {
+              if constexpr (hn == 4) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; }
+              else { const int pc = ((q >> 1) * scp + LANE / scp) * pcp + (q & 1) * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
+            }
+          }
           const int so = (q >> 1) * hn * n + (q & 1) * hn;
           for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
           load_edges(f, 0, sx, sy, hn, sL, sU, s_ar, s_bl, SH->ra[0] + EDGE_OFF, SH->rl[0] + EDGE_OFF);
@@ -494,7 +550,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             GroupRes gr;
-            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, &gr);
+            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, f->tune_psnr ? -1 : SH->spsv[0], SH->spact[0], &gr);
             long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
             if (!live) j = J_INF;
 #pragma unroll
@@ -515,7 +571,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             TxRes tr;
-            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr, SH->ssrc);
+            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr, SH->ssrc, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
             if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
           }
         }
@@ -635,7 +691,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, &gr);
+      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, -1, SH->cact, &gr);
       const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }

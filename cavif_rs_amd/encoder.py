@@ -31,7 +31,7 @@ class _Av1Config(C.Structure):
                 ('encode_bottomup', C.c_uint8), ('rdo_tx_decision', C.c_uint8), ('reduced_tx_set', C.c_uint8),
                 ('fine_directional_intra', C.c_uint8), ('fast_deblock', C.c_uint8), ('lrf', C.c_uint8), ('cdef', C.c_uint8),
                 ('inter_tx_split', C.c_uint8), ('tx_domain_rate', C.c_uint8), ('tx_domain_distortion', C.c_int8),
-                ('min_tile_size', C.c_uint16), ('tiles_override', C.c_int32), ('device', C.c_int32)]
+                ('min_tile_size', C.c_uint16), ('tiles_override', C.c_int32), ('device', C.c_int32), ('tune_psnr', C.c_uint8)]
 
 
 class _RavifEncoder(C.Structure):

@@ -39,6 +39,7 @@ typedef struct mi_av1_config {
   uint16_t min_tile_size;
   int32_t tiles_override;   /* >0 forces the tile target (tests) */
   int32_t device;           /* HIP ordinal */
+  uint8_t tune_psnr;        /* 0 = Tune::Psychovisual, what ravif always sets (:694); 1 = Tune::Psnr (plain SSE; ablation only) */
 } mi_av1_config;
 
 /* SpeedTweaks::from_my_preset (ravif/src/av1encoder.rs:554-606) */

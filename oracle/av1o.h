@@ -47,6 +47,7 @@ typedef struct Av1oConfig {
       bottomup, tx_domain_rate, inter_tx_split;
   int min_tile_size;
   int tiles_override;     /* >0: force this tile target (tests) */
+  int tune_psnr;          /* 0 = Tune::Psychovisual (what ravif always sets, av1encoder.rs:694), 1 = Tune::Psnr (plain SSE; ablation) */
 } Av1oConfig;
 
 typedef struct Av1oResult {

@@ -278,4 +278,74 @@ void av1o_setup_tiles(Av1oFrame *f) {
   f->tile_row_start[i] = sbr; f->tile_rows = i;
 }
 
+/* ---------------- Tune::Psychovisual (ravif/src/av1encoder.rs:694) ----------------
+ * [UPSTREAM-RECALL rav1e src/activity.rs ActivityMask, src/dist.rs cdef_dist_kernel + apply_ssim_boost, rdo.rs
+ *  compute_distortion]: luma distortion is the SSE of every 8x8 cell boosted by an SSIM-like factor of the source and
+ *  reconstruction variances, and every cell carries an activity scale = the same factor at equal variances.
+ *  Integer restatement (Q14), bit-identical on CPU and GPU:
+ *    boost(sv, dv) = 4033/16384 * (sv + dv + 16384) / sqrt(4033^2 + sv * dv)      variances = 64 x per-sample variance, 8-bit scale
+ *  4x4 blocks use their own 16-sample variance scaled to the 8x8 equivalent. */
+static uint64_t isqrt64(uint64_t n) {
+  uint64_t x = (uint64_t)sqrt((double)n);
+  while (x * x > n) x--;
+  while ((x + 1) * (x + 1) <= n) x++;
+  return x;
+}
+uint32_t av1o_psy_boost_q14(uint32_t svar, uint32_t dvar) {
+  const uint64_t num = 4033ull * ((uint64_t)svar + dvar + 16384);
+  const uint64_t den = isqrt64((16265089ull + (uint64_t)svar * dvar) << 16);     /* sqrt in Q8 */
+  return (uint32_t)(((num << 8) + den / 2) / den);
+}
+/* variance of a w x w cell (w = 8 or 4) as 64 x per-sample variance on the 8-bit scale */
+uint32_t av1o_cell_var(int64_t sum, int64_t sum2, int w, int bd) {
+  const int64_t v = w == 8 ? sum2 - ((sum * sum + 32) >> 6) : (sum2 - ((sum * sum + 8) >> 4)) << 2;
+  return (uint32_t)((v < 0 ? 0 : v) >> (2 * (bd - 8)));
+}
+void av1o_activity(Av1oFrame *f) {
+  const int cw = f->pw / 8, chh = f->ph / 8;
+  f->act = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)cw * chh);
+  f->svar8 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)cw * chh);
+  f->svar4 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)f->mi_stride * f->mi_h);
+  for (int cy = 0; cy < chh; cy++) for (int cx = 0; cx < cw; cx++) {
+    int64_t s8 = 0, q8 = 0;
+    for (int k = 0; k < 4; k++) {
+      int64_t s4 = 0, q4 = 0;
+      const int x0 = cx * 8 + (k & 1) * 4, y0 = cy * 8 + (k >> 1) * 4;
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { const int v = f->src[0][(size_t)(y0 + i) * f->stride + x0 + j]; s4 += v; q4 += v * v; }
+      f->svar4[(y0 >> 2) * f->mi_stride + (x0 >> 2)] = av1o_cell_var(s4, q4, 4, f->bd);
+      s8 += s4; q8 += q4;
+    }
+    const uint32_t v = av1o_cell_var(s8, q8, 8, f->bd);
+    f->svar8[cy * cw + cx] = v;
+    f->act[cy * cw + cx] = f->cfg.tune_psnr ? 16384u : av1o_psy_boost_q14(v, v);
+  }
+}
+/* luma distortion of the n x n block at pixel (x, y): rec has pitch rs */
+int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n) {
+  const int cw = f->pw / 8, w = n == 4 ? 4 : 8;
+  int64_t total = 0;
+  for (int by = 0; by < n; by += w) for (int bx = 0; bx < n; bx += w) {
+    int64_t sd = 0, qd = 0, sse = 0;
+    for (int i = 0; i < w; i++) for (int j = 0; j < w; j++) {
+      const int d = rec[(by + i) * rs + bx + j], sv = f->src[0][(size_t)(y + by + i) * f->stride + x + bx + j];
+      sd += d; qd += d * d; sse += (int64_t)(sv - d) * (sv - d);
+    }
+    if (f->cfg.tune_psnr) { total += sse; continue; }
+    const int cell = ((y + by) >> 3) * cw + ((x + bx) >> 3);
+    const uint32_t svar = w == 4 ? f->svar4[((y + by) >> 2) * f->mi_stride + ((x + bx) >> 2)] : f->svar8[cell];
+    const uint32_t b = av1o_psy_boost_q14(svar, av1o_cell_var(sd, qd, w, f->bd));
+    int64_t d = (sse * b + 8192) >> 14;
+    d = (d * f->act[cell] + 8192) >> 14;
+    total += d;
+  }
+  return total;
+}
+/* mean activity scale (Q14) of the cells covered by [x, x + w) x [y, y + h) */
+uint32_t av1o_act_mean(const Av1oFrame *f, int x, int y, int w, int h) {
+  const int cw = f->pw / 8, cx0 = x >> 3, cx1 = (x + w - 1) >> 3, cy0 = y >> 3, cy1 = (y + h - 1) >> 3;
+  uint64_t s = 0; const uint64_t cnt = (uint64_t)(cx1 - cx0 + 1) * (cy1 - cy0 + 1);
+  for (int cy = cy0; cy <= cy1; cy++) for (int cx = cx0; cx <= cx1; cx++) s += f->act[cy * cw + cx];
+  return (uint32_t)((s + cnt / 2) / cnt);
+}
+
 void av1o_free(void *p) { free(p); }

@@ -300,7 +300,11 @@ void av1o_cdef_search_and_apply(Av1oFrame *f) {
           if (pri == 0 && sec == 0) { for (int i = 0; i < 8; i++) memcpy(tmp[p] + (y0 + i) * f->stride + x0, in[p] + (y0 + i) * f->stride + x0, 16); }
           else cdef_filter8(f, in[p], tmp[p], x0, y0, pri, sec, damping, dir);
           int64_t sse = 0;
-          for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { int d = (int)tmp[p][(y0 + i) * f->stride + x0 + j] - (int)f->src[p][(y0 + i) * f->stride + x0 + j]; sse += d * d; }
+          if (p == 0) sse = av1o_psy_dist_luma(f, tmp[p] + (size_t)y0 * f->stride + x0, f->stride, x0, y0, 8);
+          else {
+            for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { int d = (int)tmp[p][(y0 + i) * f->stride + x0 + j] - (int)f->src[p][(y0 + i) * f->stride + x0 + j]; sse += d * d; }
+            sse = (sse * f->act[(y0 >> 3) * (f->pw / 8) + (x0 >> 3)] + 8192) >> 14;
+          }
           cost += (sse * wq[p]) >> 5;
         }
       }

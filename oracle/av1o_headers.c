@@ -157,6 +157,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   av1o_select_quantizers(f);
   av1o_build_costs(f);
   av1o_setup_tiles(f);
+  av1o_activity(f);
   f->enable_cdef = cfg->cdef; f->enable_restoration = cfg->lrf;
   /* phase 1 */
   for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++) av1o_search_tile(f, tr, tc);
@@ -190,7 +191,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   out->base_q_idx = f->base_q_idx; out->tile_cols = f->tile_cols; out->tile_rows = f->tile_rows;
   for (int p = 0; p < f->np; p++) { free(f->src[p]); free(f->rec[p]); free(f->coef[p]); free(f->m_lvl[p]); free(f->m_dc[p]); free(f->m_eob[p]); }
   for (int p = 0; p < f->np; p++) { free(f->dbk[p]); free(f->lr_type[p]); free(f->lr_set[p]); free(f->lr_xqd[p]); }
-  free(f->m_txsize);
+  free(f->m_txsize); free(f->act); free(f->svar8); free(f->svar4);
   free(f->m_cfl_sign); free(f->m_cfl_au); free(f->m_cfl_av); free(f->m_angle_y); free(f->m_angle_uv); free(f->m_decoded); free(f->cdef_idx);
   free(f);
   return 0;

@@ -79,6 +79,8 @@ typedef struct Av1oFrame {
   int lr_unit_rows, lr_unit_cols;
   uint8_t *lr_type[3], *lr_set[3]; int8_t *lr_xqd[3];
   uint32_t lr_cost[3];          /* static cost of the switchable restoration_type symbols */
+  /* Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent) */
+  uint32_t *act, *svar8, *svar4;
   int64_t sse[3];
 } Av1oFrame;
 
@@ -97,6 +99,11 @@ uint32_t av1o_cost_from_icdf(const uint16_t *icdf, int s, int nsyms);
 void av1o_build_costs(Av1oFrame *f);
 void av1o_select_quantizers(Av1oFrame *f);               /* rav1e rate.rs constant-Q key frame rule (recall) */
 void av1o_setup_tiles(Av1oFrame *f);
+uint32_t av1o_psy_boost_q14(uint32_t svar, uint32_t dvar);
+uint32_t av1o_cell_var(int64_t sum, int64_t sum2, int w, int bd);
+void av1o_activity(Av1oFrame *f);
+int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n);
+uint32_t av1o_act_mean(const Av1oFrame *f, int x, int y, int w, int h);
 
 /* prediction (spec 7.11.2) */
 typedef struct { uint16_t above[2 * 64 + 16 + 32], left[2 * 64 + 16 + 32]; } EdgeBuf;  /* index +16 = position 0 */

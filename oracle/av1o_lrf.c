@@ -156,6 +156,10 @@ void av1o_lr_search_and_apply(Av1oFrame *f) {
       const int uw = x1 - x0, ui = ur * f->lr_unit_cols + uc;
       int64_t sse_none = 0;
       for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) { const int d = (int)f->rec[p][(size_t)y * f->stride + x] - (int)f->src[p][(size_t)y * f->stride + x]; sse_none += d * d; }
+      /* distortions of a unit are scaled by its mean activity (rav1e prices LRF decisions with the same per-8x8 bias;
+         the cdef-dist kernel itself is not used here) */
+      const int64_t act = av1o_act_mean(f, x0, y0, x1 - x0, y1 - y0);
+      sse_none = (sse_none * act + 8192) >> 14;
       int64_t best_cost = ((sse_none * wq[p]) >> 5) + (((int64_t)lr_rate(f, 0, 0, 0, 0) * f->rdmult[0] + 256) >> 9);
       int best_type = 0, best_set = 0, best_x0 = 0, best_x1 = 0;
       for (int si = 0; si < nsets; si++) {
@@ -184,6 +188,7 @@ void av1o_lr_search_and_apply(Av1oFrame *f) {
           const int v = sgr_project(f->rec[p][(size_t)y * f->stride + x], flt[0][k], flt[1][k], r0, r1, xq0, xq1, bd);
           const int d = v - (int)f->src[p][(size_t)y * f->stride + x]; sse += d * d;
         }
+        sse = (sse * act + 8192) >> 14;
         const int64_t cost = ((sse * wq[p]) >> 5) + (((int64_t)lr_rate(f, 1, set, xq0, xq1) * f->rdmult[0] + 256) >> 9);
         if (cost < best_cost) { best_cost = cost; best_type = 1; best_set = set; best_x0 = xq0; best_x1 = xq1; }
       }

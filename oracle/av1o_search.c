@@ -110,7 +110,9 @@ static int64_t eval_tx(Search *s, int plane, int r, int c, int txs, int bs /* bl
     av1o_inv_txfm2d_add(dq, rec_out, n, txs, txtype, f->bd);
   }
   tr->eob = eob;
-  tr->sse = sse_block(src, f->stride, rec_out, n, n);
+  /* distortion: luma = psychovisual cdef-dist per 8x8 cell x activity; chroma = SSE x the block's mean activity */
+  if (plane == 0) tr->sse = av1o_psy_dist_luma(f, rec_out, n, x, y, n);
+  else tr->sse = (sse_block(src, f->stride, rec_out, n, n) * av1o_act_mean(f, x, y, n, n) + 8192) >> 14;
   (void)cs;
   return ((tr->sse * s->wq[plane]) >> 5) + (((int64_t)tr->rate * f->rdmult[0] + 256) >> 9);
 }

@@ -10,7 +10,7 @@ class Av1oConfig(C.Structure):
         'has_color_desc', 'color_primaries', 'transfer', 'matrix', 'threads',
         'part_min', 'part_max', 'complex_modes', 'fine_directional', 'rdo_tx', 'reduced_tx_set',
         'fast_deblock', 'cdef', 'lrf', 'sgr_full', 'bottomup', 'tx_domain_rate', 'inter_tx_split',
-        'min_tile_size', 'tiles_override')]
+        'min_tile_size', 'tiles_override', 'tune_psnr')]
 
 class Av1oResult(C.Structure):
     _fields_ = [('obu', C.POINTER(C.c_uint8)), ('obu_len', C.c_size_t),
