@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/mi_avif.h"
 
@@ -49,9 +52,27 @@ int main(int argc, char **argv) {
   float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0;
   bool overwrite = false, quiet = false, dirty_alpha = false, have_output = false, output_stdio = false;
   std::string output; std::vector<std::string> images; std::vector<int> devices;
+  // clap syntax (src/main.rs:45-110): --name value, --name=value, -n value, -nvalue, -n=value, combined short flags (-fq)
+  std::vector<std::string> args;
+  bool only_positional = false;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
-    auto value = [&](const char *name) -> const char * { if (i + 1 >= argc) { usage((std::string("missing value for ") + name).c_str()); exit(1); } return argv[++i]; };
+    if (only_positional || a == "-" || a.size() < 2 || a[0] != '-') { args.push_back(a); continue; }
+    if (a == "--") { only_positional = true; continue; }
+    if (a[1] == '-') { const size_t eq = a.find('='); if (eq == std::string::npos) args.push_back(a); else { args.push_back(a.substr(0, eq)); args.push_back(a.substr(eq + 1)); } continue; }
+    for (size_t k = 1; k < a.size(); k++) {
+      const char c = a[k];
+      args.push_back(std::string("-") + c);
+      if (c == 'Q' || c == 's' || c == 'j' || c == 'o') {          // takes a value: the rest of the token, if any
+        if (k + 1 < a.size()) args.push_back(a.substr(k + 1 + (a[k + 1] == '=' ? 1 : 0)));
+        break;
+      }
+    }
+  }
+  const int nargs = (int)args.size();
+  for (int i = 0; i < nargs; i++) {
+    const std::string a = args[i];
+    auto value = [&](const char *name) -> const char * { if (i + 1 >= nargs) { usage((std::string("missing value for ") + name).c_str()); exit(1); } return args[++i].c_str(); };
     if (a == "-Q" || a == "--quality") {
       char *end; quality = strtof(value("--quality"), &end);
       if (*end || !(quality >= 1.f && quality <= 100.f)) return usage("quality must be a number between 1 and 100");      // parse_quality, src/main.rs:24-33
@@ -99,7 +120,8 @@ int main(int argc, char **argv) {
   // load + decide output paths (process(), :169-200); failures are collected per file and reported at the end
   struct Job { std::string in_name, out_path; bool out_stdio = false; uint8_t *rgba = nullptr; uint32_t w = 0, h = 0; std::string error; };
   std::vector<Job> jobs(files.size());
-  for (size_t i = 0; i < files.size(); i++) {
+  // the reference loads inside files.into_par_iter() (src/main.rs:223): file reads + PNG decodes fan out over the host cores
+  auto load = [&](size_t i) {
     Job &j = jobs[i]; const Input &in = files[i];
     j.in_name = in.is_stdio ? "stdin" : in.path;
     std::vector<uint8_t> data;
@@ -114,6 +136,13 @@ int main(int argc, char **argv) {
     else if (in.is_stdio) j.out_path = output;
     else j.out_path = use_dir ? output + "/" + with_extension_avif(file_name(in.path)) : output;
     if (j.error.empty() && !j.out_stdio && !overwrite && exists(j.out_path)) j.error = j.out_path + " already exists; skipping";
+  };
+  {
+    const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(threads > 0 ? (unsigned)threads : 64u, std::thread::hardware_concurrency())));
+    std::atomic<size_t> next{ 0 };
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nw; t++) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < files.size();) load(i); });
+    for (auto &t : pool) t.join();
   }
   // encode everything that is still alive, across the selected devices
   std::vector<mi_image_desc> desc; std::vector<size_t> who;

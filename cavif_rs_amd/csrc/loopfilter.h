@@ -406,6 +406,18 @@ __global__ __launch_bounds__(256) void frontend_kernel(const uint8_t *pix, int w
   if (A != 255 && x < w && y < h && alpha_flag) *alpha_flag = 1;
 }
 
+// ---------------------------------------------------------------- AlphaColorMode::Premultiplied
+// convert_alpha_8bit, Premultiplied branch (ravif/src/av1encoder.rs:282-296), as written: a == 0 or a == 255 -> RGBA8::default(),
+// otherwise every colour channel becomes (c * 255 / a) as u8 (the cast wraps).  One thread per pixel.
+__global__ __launch_bounds__(256) void premultiply_kernel(const uint8_t *src, uint8_t *dst, size_t npx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npx) return;
+  const uchar4 p = ((const uchar4 *)src)[i];
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  if (p.w != 0 && p.w != 255) { o.x = (uint8_t)((unsigned)p.x * 255u / p.w); o.y = (uint8_t)((unsigned)p.y * 255u / p.w); o.z = (uint8_t)((unsigned)p.z * 255u / p.w); o.w = p.w; }
+  ((uchar4 *)dst)[i] = o;
+}
+
 // ---------------------------------------------------------------- dirty-alpha cleaner (ravif/src/dirtyalpha.rs:17-124)
 // Three 3x3 stencil passes over RGBA8 in HBM, window clamped to the image (loop9 convention):
 //   scan  : (256-a)-weighted mean colour of semi-transparent pixels that touch a fully transparent one  (:24-33)

@@ -9,6 +9,7 @@
 #include <memory>
 #include <thread>
 #include <atomic>
+#include <exception>
 #include "host_av1.h"
 #include "png_reader.h"
 #include "tile_search.h"
@@ -35,10 +36,11 @@ __global__ void pack_tiles_kernel(const FrameDev *frames, const TileJob *jobs, i
 // ---- per-device read-only tables ----
 struct DeviceTables { uint16_t *cost[4] = { 0, 0, 0, 0 }; uint16_t *cdf0[4] = { 0, 0, 0, 0 }; bool ready = false; };
 static std::mutex g_tab_mu;
-static DeviceTables g_tabs[16];
+#define MI_MAX_DEVICES 64
+static DeviceTables g_tabs[MI_MAX_DEVICES];
 static int ensure_tables(int dev) {
   std::lock_guard<std::mutex> lk(g_tab_mu);
-  if (dev < 0 || dev >= 16) return MI_INVALID_ARGUMENT;
+  if (dev < 0 || dev >= MI_MAX_DEVICES) { fprintf(stderr, "mi_avif: HIP ordinal %d outside the supported 0..%d\n", dev, MI_MAX_DEVICES - 1); return MI_INVALID_ARGUMENT; }
   DeviceTables &t = g_tabs[dev];
   if (t.ready) return MI_OK;
   for (int q = 0; q < 4; q++) {
@@ -141,7 +143,11 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i <= p.tiles.cols; i++) d.tile_col_start[i] = p.tiles.col_start[i];
   for (int i = 0; i <= p.tiles.rows; i++) d.tile_row_start[i] = p.tiles.row_start[i];
   d.cost = tab.cost[p.q.qctx]; d.cdf0 = tab.cdf0[p.q.qctx];
+#if MI_DEBUG_HOOKS
   d.dbg = getenv("MI_DEBUG_LEVEL") ? atoi(getenv("MI_DEBUG_LEVEL")) : 0;
+#else
+  d.dbg = 0;
+#endif
   // fast_deblock: the q formula; otherwise K2a searches the levels on the device and the host reads them back for the header
   const int lvl = c.fast_deblock ? deblock_level_from_q(p.q.ac_q[0], c.bit_depth) : 0;
   d.lf_level[0] = d.lf_level[1] = d.lf_level[2] = d.lf_level[3] = lvl; d.lf_sharp = 0;
@@ -197,6 +203,7 @@ using namespace mi;
 // ================================================================ batch object
 struct mi_batch {
   mi_ravif_encoder enc{}; int n = 0; uint32_t w = 0, h = 0; int channels = 3, device = 0, depth = 10;
+  std::vector<uint8_t> exif;                                       // the batch's own copy of enc.exif (the caller's buffer need not outlive mi_batch_create)
   hipStream_t stream = nullptr;
   uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // n * w*h*channels
   int *d_alpha_flags = nullptr; std::vector<int> alpha_flags;
@@ -300,13 +307,15 @@ size_t mi_avif_serialize(const uint8_t *color, size_t color_len, const uint8_t *
 }
 
 mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels) {
-  if (!e || n_images < 1 || w < 1 || h < 1 || (channels != 3 && channels != 4)) return nullptr;
+  if (!e || n_images < 1 || w < 1 || h < 1 || w > 65536 || h > 65536 || (channels != 3 && channels != 4) || e->alpha_mode > 2) return nullptr;
   if (e->speed < 1 || e->speed > 10 || !(e->quality >= 1.f && e->quality <= 100.f) || !(e->alpha_quality >= 1.f && e->alpha_quality <= 100.f)) return nullptr;
   if (mi_device_count() <= e->device) { fprintf(stderr, "mi_avif: no HIP device %d (the HIP path is mandatory; there is no CPU fallback)\n", e->device); return nullptr; }
   if (hipSetDevice(e->device) != hipSuccess) return nullptr;
   if (ensure_tables(e->device) != MI_OK) return nullptr;
   mi_batch *b = new mi_batch();
   b->enc = *e; b->n = n_images; b->w = w; b->h = h; b->channels = channels; b->device = e->device; b->depth = e->depth == 8 ? 8 : 10;
+  if (e->exif && e->exif_len) b->exif.assign(e->exif, e->exif + e->exif_len);
+  b->enc.exif = b->exif.empty() ? nullptr : b->exif.data(); b->enc.exif_len = b->exif.size();
   b->alpha_flags.assign(n_images, 0);
   b->pixel_bytes = (size_t)n_images * w * h * channels;
   bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess &&
@@ -314,6 +323,7 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   if (ok && channels == 4 && e->alpha_mode == 1)
     ok = hipMalloc(&b->d_clean, b->pixel_bytes) == hipSuccess && hipMalloc(&b->d_clean_tmp, (size_t)w * h * 4) == hipSuccess &&
          hipMalloc(&b->d_alpha_acc, sizeof(unsigned long long) * 4 * n_images) == hipSuccess;
+  if (ok && channels == 4 && e->alpha_mode == 2) ok = hipMalloc(&b->d_clean, b->pixel_bytes) == hipSuccess;   // premultiplied pixels
   for (int i = 0; i < 8 && ok; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   if (ok) ok = batch_alloc(b) == MI_OK;
   if (!ok) { mi_batch_destroy(b); return nullptr; }
@@ -367,7 +377,12 @@ int mi_batch_encode_async(mi_batch *b) {
   const FrontConsts fc = front_consts(b->depth);
   FrontParams fp{ fc.sy_r, fc.sy_g, fc.sy_b, fc.scale, fc.kcb, fc.kcr, fc.shift, b->depth, b->enc.color_model, b->channels };
   const uint8_t *front_src = b->d_pixels;
-  if (b->d_clean) {                                            // convert_alpha_8bit: UnassociatedClean (av1encoder.rs:277-281)
+  if (b->d_clean && b->enc.alpha_mode == 2) {                  // convert_alpha_8bit: Premultiplied (av1encoder.rs:282-296)
+    const size_t npx = (size_t)b->n * b->w * b->h;
+    hipLaunchKernelGGL(premultiply_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, b->d_pixels, b->d_clean, npx);
+    HIP_OK(hipGetLastError());
+    front_src = b->d_clean;
+  } else if (b->d_clean) {                                     // convert_alpha_8bit: UnassociatedClean (av1encoder.rs:277-281)
     HIP_OK(hipMemsetAsync(b->d_alpha_acc, 0, sizeof(unsigned long long) * 4 * b->n, s));
     const dim3 g((b->w + 255) / 256, b->h), blk(256);
     for (int i = 0; i < b->n; i++) {
@@ -550,11 +565,15 @@ int mi_ravif_encode_rgba(const mi_ravif_encoder *e, const uint8_t *rgba, uint32_
 // PNG -> RGBA8 (cavif's load_rgba, src/main.rs:265-283); host code, no GPU involved
 int mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_t *w, uint32_t *h) {
   if (!data || !rgba || !w || !h) return MI_INVALID_ARGUMENT;
-  std::vector<uint8_t> px;
-  const int st = png_decode_rgba(data, len, px, *w, *h);
-  if (st) return st;
-  *rgba = (uint8_t *)malloc(px.size()); memcpy(*rgba, px.data(), px.size());
-  return MI_OK;
+  try {                                                       // nothing may unwind through the C ABI
+    std::vector<uint8_t> px;
+    const int st = png_decode_rgba(data, len, px, *w, *h);
+    if (st) return st;
+    *rgba = (uint8_t *)malloc(px.size());
+    if (!*rgba) return MI_ENCODING_ERROR;
+    memcpy(*rgba, px.data(), px.size());
+    return MI_OK;
+  } catch (const std::exception &) { return MI_ENCODING_ERROR; }
 }
 
 // The reference's files.into_par_iter() (src/main.rs:223) over the GPUs of one node: images are independent, so a host
@@ -602,21 +621,31 @@ int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t 
 
 // level 1: caller-supplied planes (encode_to_av1). Planes go straight into the frame's src[] (edge-replicated on the host).
 int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], const size_t stride_bytes[3], uint8_t **out_obu, size_t *out_len, uint16_t *recon[3]) {
-  if (!cfg || !planes || !planes[0] || !out_obu || !out_len || cfg->width < 1 || cfg->height < 1 || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return MI_INVALID_ARGUMENT;
+  if (!cfg || !planes || !planes[0] || !stride_bytes || !out_obu || !out_len || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return MI_INVALID_ARGUMENT;
+  // rav1e rejects these with InvalidWidth / InvalidHeight (the sequence header carries at most 16 bits per dimension)
+  if (cfg->width < 1 || cfg->height < 1 || cfg->width > 65536 || cfg->height > 65536) return MI_INVALID_ARGUMENT;
+  auto pow2_4_64 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+  if (!pow2_4_64(cfg->part_min) || !pow2_4_64(cfg->part_max) || cfg->part_min > cfg->part_max || cfg->chroma > 1) return MI_INVALID_ARGUMENT;
   if (mi_device_count() <= cfg->device) { fprintf(stderr, "mi_avif: no HIP device %d (no CPU fallback)\n", cfg->device); return MI_NO_DEVICE; }
   HIP_OK(hipSetDevice(cfg->device));
   if (int st = ensure_tables(cfg->device)) return st;
   const DeviceTables &tab = g_tabs[cfg->device];
   FramePlan p; p.cfg = *cfg; plan_geometry(p);
+  for (int i = 0; i < p.np; i++) if (!planes[i]) return MI_TOO_FEW_PIXELS;
   const uint32_t cap = tile_capacity(p);
   p.arena_bytes = carve(p, nullptr, cap);
-  hipStream_t s; HIP_OK(hipStreamCreate(&s));
-  uint8_t *arena = nullptr; HIP_OK(hipMalloc(&arena, p.arena_bytes));
-  carve(p, arena, cap); fill_dev(p, tab); p.dev.tile_base = 0;
+  // every device allocation and the stream are owned by this guard: all return paths release them
+  struct Guard {
+    hipStream_t s = nullptr; uint8_t *arena = nullptr; FrameDev *d_frame = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_pre = nullptr;
+    ~Guard() { if (d_frame) (void)hipFree(d_frame); if (d_jobs) (void)hipFree(d_jobs); if (d_pre) (void)hipFree(d_pre); if (arena) (void)hipFree(arena); if (s) (void)hipStreamDestroy(s); }
+  } g;
+  HIP_OK(hipStreamCreate(&g.s));
+  hipStream_t s = g.s;
+  HIP_OK(hipMalloc(&g.arena, p.arena_bytes));
+  carve(p, g.arena, cap); fill_dev(p, tab); p.dev.tile_base = 0;
   const size_t npx = (size_t)p.pw * p.ph;
   std::vector<uint16_t> host(npx);
   for (int i = 0; i < p.np; i++) {
-    if (!planes[i]) { hipFree(arena); return MI_TOO_FEW_PIXELS; }
     for (int y = 0; y < p.ph; y++) {
       const uint8_t *row = (const uint8_t *)planes[i] + (size_t)std::min<int>(y, cfg->height - 1) * stride_bytes[i];
       for (int x = 0; x < p.pw; x++) { const int sx = std::min<int>(x, cfg->width - 1); host[(size_t)y * p.pw + x] = cfg->bit_depth == 8 ? row[sx] : ((const uint16_t *)row)[sx]; }
@@ -626,20 +655,15 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
-  FrameDev *d_frame; TileJob *d_jobs; uint16_t *d_pre;
-  HIP_OK(hipMalloc(&d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&d_pre, (size_t)jobs.size() * cap * 2));
+  HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * cap * 2));
+  FrameDev *d_frame = g.d_frame; TileJob *d_jobs = g.d_jobs; uint16_t *d_pre = g.d_pre;
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
   hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
   HIP_OK(launch_search(p.maxbs, d_frame, d_jobs, njobs, s));
-  const int dbgmask = getenv("MI_DEBUG_STAGES") ? atoi(getenv("MI_DEBUG_STAGES")) : 0; int dbgbit = 1;
-#define DBG_STAGE(name) do { const int bit_ = dbgbit; dbgbit <<= 1; if (dbgmask & bit_) { hipError_t e2 = hipStreamSynchronize(s); fprintf(stderr, "mi_avif: stage %s -> %s\n", name, hipGetErrorString(e2)); if (e2 != hipSuccess) return MI_ENCODING_ERROR; } } while (0)
-  DBG_STAGE("tile_search");
   HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, s, nullptr));
-  DBG_STAGE("loop filters");
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
-  DBG_STAGE("entropy");
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);
   HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
@@ -647,18 +671,22 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipStreamSynchronize(s));
   std::vector<std::vector<uint8_t>> td(njobs); std::vector<std::pair<const uint8_t *, size_t>> tl;
   for (int j = 0; j < njobs; j++) {
-    if (lens[j] == 0xFFFFFFFFu) return MI_ENCODING_ERROR;
+    if (lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer\n", j); return MI_ENCODING_ERROR; }
     td[j].resize(lens[j]);
     HIP_OK(hipMemcpy(td[j].data(), p.dev.tile_out + (size_t)j * cap, lens[j], hipMemcpyDeviceToHost));
     tl.push_back({ td[j].data(), td[j].size() });
   }
   std::vector<uint8_t> obu = assemble_obus(p.hdr, tl);
-  *out_obu = (uint8_t *)malloc(obu.size()); memcpy(*out_obu, obu.data(), obu.size()); *out_len = obu.size();
-  if (recon) for (int i = 0; i < 3; i++) {
-    recon[i] = nullptr;
-    if (i < p.np) { recon[i] = (uint16_t *)malloc((size_t)cfg->width * cfg->height * 2); HIP_OK(hipMemcpy2D(recon[i], (size_t)cfg->width * 2, p.cfg.lrf ? p.dev.lrp[i] : p.dev.fin[i], (size_t)p.pw * 2, (size_t)cfg->width * 2, cfg->height, hipMemcpyDeviceToHost)); }
+  uint16_t *rec_out[3] = { nullptr, nullptr, nullptr };
+  if (recon) for (int i = 0; i < p.np; i++) {
+    rec_out[i] = (uint16_t *)malloc((size_t)cfg->width * cfg->height * 2);
+    const hipError_t e = rec_out[i] ? hipMemcpy2D(rec_out[i], (size_t)cfg->width * 2, p.cfg.lrf ? p.dev.lrp[i] : p.dev.fin[i], (size_t)p.pw * 2, (size_t)cfg->width * 2, cfg->height, hipMemcpyDeviceToHost) : hipErrorOutOfMemory;
+    if (e != hipSuccess) { for (int k = 0; k <= i; k++) free(rec_out[k]); return MI_ENCODING_ERROR; }
   }
-  hipFree(d_frame); hipFree(d_jobs); hipFree(d_pre); hipFree(arena); hipStreamDestroy(s);
+  *out_obu = (uint8_t *)malloc(obu.size());
+  if (!*out_obu) { for (int k = 0; k < 3; k++) free(rec_out[k]); return MI_ENCODING_ERROR; }
+  memcpy(*out_obu, obu.data(), obu.size()); *out_len = obu.size();
+  if (recon) for (int i = 0; i < 3; i++) recon[i] = rec_out[i];
   return MI_OK;
 }
 

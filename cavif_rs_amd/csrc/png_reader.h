@@ -4,6 +4,7 @@
 // scanline filters, Adam7).  JPEG input (the reference also accepts it through load_image) is not handled: callers get
 // MI_UNSUPPORTED.
 #pragma once
+#include <algorithm>
 #include <zlib.h>
 #include <cstdint>
 #include <cstring>
@@ -79,13 +80,23 @@ inline int png_decode_rgba(const uint8_t *d, size_t len, std::vector<uint8_t> &r
     if (w <= ps.x0 || h <= ps.y0 || !pw || !ph) continue;
     total += (size_t)ph * (1 + ((size_t)pw * bits_pp + 7) / 8);
   }
+  // a deflate stream expands at most ~1032x: a tiny file that claims a huge canvas is refused before anything is allocated
+  if (total > idat.size() * 1040 + 65536) return 3;
   std::vector<uint8_t> raw(total);
   {
     z_stream zs; memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return 3;
-    zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size(); zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
-    const int zr = inflate(&zs, Z_FINISH);
-    const size_t got = zs.total_out;
+    // zlib counts in uInt: feed and drain in chunks so that streams and canvases beyond 4 GiB work
+    size_t in_pos = 0, out_pos = 0; int zr = Z_OK;
+    const size_t chunk = (size_t)1 << 30;
+    while (zr == Z_OK || zr == Z_BUF_ERROR) {
+      if (zs.avail_in == 0 && in_pos < idat.size()) { const size_t k = std::min(chunk, idat.size() - in_pos); zs.next_in = idat.data() + in_pos; zs.avail_in = (uInt)k; in_pos += k; }
+      if (zs.avail_out == 0 && out_pos < total) { const size_t k = std::min(chunk, total - out_pos); zs.next_out = raw.data() + out_pos; zs.avail_out = (uInt)k; out_pos += k; }
+      const uInt in_before = zs.avail_in, out_before = zs.avail_out;
+      zr = inflate(&zs, Z_NO_FLUSH);
+      if (zr == Z_BUF_ERROR && in_before == zs.avail_in && out_before == zs.avail_out && (in_pos >= idat.size() || out_pos >= total)) break;   // no progress possible
+    }
+    const size_t got = out_pos - zs.avail_out;
     inflateEnd(&zs);
     if ((zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR) || got != total) return 3;
   }

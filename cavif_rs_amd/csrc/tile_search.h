@@ -607,6 +607,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       WG_SYNC();
     }
   }
+  PH(13);
   if (luma_j >= budget) return luma_j;                      // wave-uniform: every wave reads the same LDS values
   long long total_j = luma_j;
 

@@ -30,7 +30,10 @@ typedef struct mi_av1_config {
   uint8_t speed;            /* 1..10 (informational once the tweaks below are filled) */
   uint8_t chroma;           /* 0 = Cs444, 1 = Cs400 */
   uint8_t pixel_range;      /* 0 = Limited, 1 = Full */
-  int32_t threads;          /* <=0: unspecified (only bounds the tile count, :665-668) */
+  int32_t threads;          /* bounds the tile target min(threads, w*h / min_tile_size^2) (:665-668).  <= 0 = unspecified: the
+                               reference then takes rayon::current_num_threads() (:666), i.e. the host's core count; a GPU has no
+                               such number, so the target is left uncapped (1080p speed 4 -> 31, i.e. 32 tiles).  Pass the
+                               reference box's core count for an equal-tile comparison (cavif_mi -j N does). */
   int8_t has_color_desc; uint8_t matrix, transfer, primaries;
   /* resolved SpeedTweaks (mi_av1_tweaks_from_preset fills them; callers may override) */
   uint8_t part_min, part_max, complex_pred_modes, sgr_full, encode_bottomup, rdo_tx_decision,
@@ -63,7 +66,7 @@ typedef struct mi_ravif_encoder {
   uint8_t depth;                  /* 8, 10, 0 = Auto (== 10, :266,:339) */
   uint8_t alpha_mode;             /* 0 UnassociatedDirty, 1 UnassociatedClean, 2 Premultiplied (:197) */
   int32_t threads;                /* with_num_threads :187; <=0 = None */
-  const uint8_t *exif; size_t exif_len;
+  const uint8_t *exif; size_t exif_len;   /* with_exif :208; copied by mi_batch_create / every encode call, need not outlive it */
   int32_t device;
   int32_t tiles_override;
 } mi_ravif_encoder;

@@ -157,6 +157,16 @@ static int encode_planes(const RavifOracleEncoder *e, int w, int h, uint16_t *pl
 static int encode_common(const RavifOracleEncoder *e, const uint8_t *px, int bpp, int w, int h, int stride_px, RavifOracleImage *out) {
   if (!e || !px || w < 1 || h < 1) return 4;
   uint8_t *cleaned = NULL;
+  if (bpp == 4 && e->alpha_mode == 2) {                       /* convert_alpha_8bit: Premultiplied (:282-296), as written: a == 0 or
+                                                                 a == 255 -> RGBA8::default(); else (c * 255 / a) as u8 (wraps) */
+    cleaned = (uint8_t *)malloc((size_t)w * h * 4);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+      const uint8_t *p = px + ((size_t)y * stride_px + x) * 4; uint8_t *o = cleaned + ((size_t)y * w + x) * 4;
+      if (p[3] == 0 || p[3] == 255) { o[0] = o[1] = o[2] = o[3] = 0; }
+      else { for (int k = 0; k < 3; k++) o[k] = (uint8_t)((unsigned)p[k] * 255u / p[3]); o[3] = p[3]; }
+    }
+    px = cleaned; stride_px = w;
+  }
   if (bpp == 4 && e->alpha_mode == 1) {                       /* convert_alpha_8bit: UnassociatedClean -> blurred_dirty_alpha (:277-281) */
     cleaned = (uint8_t *)malloc((size_t)w * h * 4);
     if (av1o_blurred_dirty_alpha(px, w, h, stride_px, cleaned)) { px = cleaned; stride_px = w; } else { free(cleaned); cleaned = NULL; }

@@ -1,0 +1,115 @@
+"""-m gpu: the parity cells VERDICT r01 listed as untested -- raw-planes entry points incl. Limited range, 10-bit GBR,
+AlphaColorMode::Premultiplied, BASELINE config 1 on the reference's own fixture through the command line (file + stdin,
+tests/stdio.rs:4-43), every tool switch HIP == oracle, and full-size configs 3 / 5 against committed sha256 vectors."""
+import hashlib
+import json
+import os
+import subprocess
+import numpy as np
+import pytest
+from tests.helpers.images import planes, rgba_gradient
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, 'cavif_rs_amd', 'cavif_mi')
+
+
+@pytest.mark.parametrize('over', [dict(lrf=0), dict(rdo_tx_decision=0), dict(fast_deblock=1), dict(tune_psnr=1), dict(cdef=0), dict(sgr_full=1),
+                                  dict(rdo_tx_decision=0, inter_tx_split=1), dict(lrf=0, cdef=0, fast_deblock=1, rdo_tx_decision=0, tune_psnr=1)])
+def test_tool_switches_hip_equals_oracle(oracle, over):
+    import cavif_rs_amd as m
+    w, h, bd = 264, 200, 10
+    pl = planes(h, w, seed=w + h, bd=bd)
+    names = {'rdo_tx_decision': 'rdo_tx'}
+    cfg = oracle.make_config(w, h, bd, False, 121, 4, **{names.get(k, k): v for k, v in over.items()})
+    r = oracle.encode_planes(cfg, pl)
+    obu, rec = m.encode_planes(pl, bd, 121, 4, False, **over)
+    assert obu == r['obu']
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('depth,full_range,with_alpha', [(8, 0, False), (8, 1, True), (10, 0, True), (10, 1, False)])
+def test_raw_planes_entry_points(oracle, avifdec, depth, full_range, with_alpha):
+    """encode_raw_planes_8_bit / _10_bit (av1encoder.rs:366,390) incl. PixelRange::Limited == oracle frames + container."""
+    import cavif_rs_amd as m
+    w, h = 150, 90
+    pl = planes(h, w, seed=11 + depth, bd=depth)
+    if not full_range:                                         # studio swing samples
+        lo, hi = (16, 235) if depth == 8 else (64, 940)
+        pl = [np.clip(p, lo, hi).astype(np.uint16) for p in pl]
+    alpha = planes(h, w, seed=5, bd=depth, mono=True)[0] if with_alpha else None
+    dt = np.uint8 if depth == 8 else np.uint16
+    yuv = np.stack(pl, -1).astype(dt)
+    e = m.Encoder().with_quality(70).with_alpha_quality(85).with_speed(5)
+    fn = e.encode_raw_planes_8_bit if depth == 8 else e.encode_raw_planes_10_bit
+    got = fn(w, h, yuv, None if alpha is None else alpha.astype(dt), color_pixel_range=full_range, matrix_coefficients=6)
+    L = oracle.lib()
+    cq, aq = L.av1o_quality_to_quantizer(70.0), L.av1o_quality_to_quantizer(85.0)
+    rc = oracle.encode_planes(oracle.make_config(w, h, depth, False, cq, 5, matrix=6, full_range=full_range), pl)
+    ra = oracle.encode_planes(oracle.make_config(w, h, depth, True, aq, 5), [alpha]) if with_alpha else None
+    want = oracle.container(rc['obu'], ra['obu'] if ra else None, w, h, depth, cp=1, tc=13, mc=6, full_range=1)
+    assert got.color_byte_size == len(rc['obu']) and got.alpha_byte_size == (len(ra['obu']) if ra else 0)
+    assert got.avif_file == want
+    d = avifdec.decode(got.avif_file)
+    # (the container's colr box always says full range -- ravif never forwards the range to avif-serialize, :457-473 --
+    #  so the range is carried by the AV1 sequence header alone; the header bit is covered by the byte comparison above)
+    for a, b in zip(d['planes'], rc['recon']):
+        assert np.array_equal(a, b)
+
+
+def test_ten_bit_gbr_equals_oracle(oracle):
+    """--color=rgb at depth 10: to_ten + G,B,R plane order (av1encoder.rs:485-498) against the oracle, RGB and RGBA."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    e = m.Encoder().with_quality(75).with_speed(6).with_bit_depth(10).with_internal_color_model('rgb')
+    rgb = synth_image(176, 112, index=9)
+    assert e.encode_rgb(rgb).avif_file == oracle.ravif_encode(rgb, quality=75, speed=6, color_model=1, depth=10)[0]
+    rgba = rgba_gradient(120, 88)
+    assert e.encode_rgba(rgba).avif_file == oracle.ravif_encode(rgba, quality=75, speed=6, color_model=1, depth=10)[0]
+
+
+def test_premultiplied_equals_oracle(oracle):
+    import cavif_rs_amd as m
+    rgba = rgba_gradient(136, 72)
+    rgba[:10, :, 3] = 255; rgba[10:20, :, 3] = 0
+    e = m.Encoder().with_quality(60).with_alpha_quality(70).with_speed(7).with_alpha_color_mode('premultiplied')
+    got = e.encode_rgba(rgba)
+    ref, cs, als = oracle.ravif_encode(rgba, quality=60, alpha_quality=70, speed=7, alpha_mode=2)
+    assert got.avif_file == ref and b'prem' in ref and als > 0
+
+
+def test_config1_reference_fixture_through_the_cli(oracle, tmp_path):
+    """BASELINE config 1: tests/testimage.png (committed as tests/golden/testimage_128x85.json), `--speed=10`, path -> `-o -`
+    and stdin -> stdout exactly as tests/stdio.rs:4-43 drives the reference binary; bytes == oracle on the same pixels."""
+    from tests.helpers.fixtures import testimage_png_bytes
+    png, rgba = testimage_png_bytes()
+    (tmp_path / 'testimage.png').write_bytes(png)
+    aq = min((80.0 + 100.0) / 2.0, 80.0 + 80.0 / 4.0 + 2.0)                     # src/main.rs:115-116
+    ref, cs, als = oracle.ravif_encode(rgba, quality=80.0, alpha_quality=aq, speed=10, alpha_mode=1)
+    r = subprocess.run([CLI, str(tmp_path / 'testimage.png'), '--speed=10', '-o', '-'], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout[4:12] == b'ftypavif' and r.stdout == ref
+    r = subprocess.run([CLI, '-', '--speed=10'], input=png, capture_output=True)
+    assert r.returncode == 0 and r.stdout == ref
+    # the same through the 8-bit path the survey's config line names (--depth=8, one thread)
+    r = subprocess.run([CLI, '-', '--speed=10', '--depth=8', '-j1'], input=png, capture_output=True)
+    assert r.returncode == 0 and r.stdout == oracle.ravif_encode(rgba, quality=80.0, alpha_quality=aq, speed=10, alpha_mode=1, depth=8, threads=1)[0]
+
+
+G = os.path.join(ROOT, 'tests', 'golden', 'fullsize_golden.json')
+
+
+@pytest.mark.skipif(not os.path.exists(G), reason='tests/golden/fullsize_golden.json not generated yet (tests/golden/make_fullsize_golden.py)')
+@pytest.mark.parametrize('name', ['config3_4096x4096_rgba_s4_q80', 'config5_7680x4320_rgb_s1_q80'])
+def test_full_size_configs_equal_oracle_vectors(name):
+    """BASELINE configs 3 and 5 at full size: the HIP path == the oracle's output, which was produced once on the host
+    (minutes of scalar C) and committed as sha256 (tests/golden/make_fullsize_golden.py)."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    g = json.load(open(G))[name]
+    img = synth_image(g['w'], g['h'], index=g['index'], alpha=g['alpha'])
+    e = m.Encoder().with_quality(g['quality']).with_alpha_quality(g['alpha_quality']).with_speed(g['speed']).with_bit_depth(g['depth'])
+    got = e.encode_rgba(img) if g['alpha'] else e.encode_rgb(img)
+    assert got.color_byte_size == g['color_byte_size'] and got.alpha_byte_size == g['alpha_byte_size']
+    assert len(got.avif_file) == g['avif_len'] and hashlib.sha256(got.avif_file).hexdigest() == g['avif_sha256']

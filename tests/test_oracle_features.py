@@ -1,0 +1,115 @@
+"""CPU: the tools the reference's speed=4/q80 setting switches on (deblock level search, loop restoration, tx-size RDO,
+Tune::Psychovisual) in the oracle -- each decoder-visible one pinned by dav1d, the encoder-side ones by self-checks and
+known answers."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from tests.helpers.images import planes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _roundtrip(oracle, avifdec, w, h, bd, speed, q, mono=False, **over):
+    pl = planes(h, w, seed=w + h, bd=bd, mono=mono)
+    cfg = oracle.make_config(w, h, bd, mono, q, speed, **over)
+    r = oracle.encode_planes(cfg, pl)
+    d = avifdec.decode(oracle.container(r['obu'], None, w, h, bd, mono_color=int(mono)))
+    for a, b in zip(d['planes'], r['recon']):
+        assert np.array_equal(a, b)
+    return cfg, r
+
+
+@pytest.mark.parametrize('over', [dict(lrf=0), dict(rdo_tx=0), dict(fast_deblock=1), dict(tune_psnr=1), dict(cdef=0), dict(lrf=1, cdef=0),
+                                  dict(sgr_full=1), dict(rdo_tx=0, inter_tx_split=1)])
+def test_tool_switches_stay_decodable(oracle, avifdec, over):
+    """Every tool on / off: dav1d reproduces the oracle's reconstruction bit for bit (incl. stripe boundaries: 3 stripes)."""
+    _roundtrip(oracle, avifdec, 200, 150, 10, 4, 121, **over)
+
+
+def test_speed4_q80_switches_are_on(oracle, avifdec):
+    cfg, r = _roundtrip(oracle, avifdec, 264, 200, 10, 4, 121)
+    assert cfg.lrf == 1 and cfg.rdo_tx == 1 and cfg.fast_deblock == 0 and cfg.cdef == 1      # av1encoder.rs:580,586,589,590
+    off = oracle.encode_planes(oracle.make_config(264, 200, 10, False, 121, 4, lrf=0), planes(200, 264, seed=464, bd=10))
+    assert sum(r['sse']) < sum(off['sse'])                                                   # restoration lowers the error
+    fast = oracle.encode_planes(oracle.make_config(264, 200, 10, False, 121, 4, fast_deblock=1), planes(200, 264, seed=464, bd=10))
+    assert r['lf_level'] != fast['lf_level'] and fast['lf_level'][0] == fast['lf_level'][3]   # searched vs the q formula
+
+
+def test_deblock_tallies_equal_brute_force():
+    """AV1O_SELFCHECK: the analytic per-edge tallies == the real filter run on every line at every level (aborts otherwise)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.helpers import oracle\nfrom tests.helpers.images import planes\n"
+            "for (w, h, bd, sp, q, mono) in [(129, 101, 10, 4, 121, False), (136, 72, 8, 4, 10, False), (200, 136, 10, 1, 66, True), (136, 72, 8, 6, 200, False)]:\n"
+            "    oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, sp), planes(h, w, seed=w + h, bd=bd, mono=mono))\nprint('ok')\n") % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, AV1O_SELFCHECK='1'), timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-1500:]
+
+
+def test_subexp_code_known_answers(oracle):
+    """decode_signed_subexp_with_ref_bool restated as an encoder: decoded back with the spec's procedure."""
+    L = oracle.lib()
+    L.av1o_subexp_code.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+
+    def decode(bits, nb, lo, hi, ref):
+        pos = [0]
+        def L1(n):
+            v = 0
+            for _ in range(n):
+                v = (v << 1) | ((bits >> (nb - 1 - pos[0])) & 1); pos[0] += 1
+            return v
+        mx, r, k = hi - lo, ref - lo, 4
+        i = mk = 0
+        while True:
+            b2 = k + i - 1 if i else k
+            a = 1 << b2
+            if mx <= mk + 3 * a:
+                n = mx - mk; w = n.bit_length(); m = (1 << w) - n
+                v = L1(w - 1)
+                if v >= m:
+                    v = (v << 1) - m + L1(1)
+                t = v + mk; break
+            if L1(1):
+                i += 1; mk += a
+            else:
+                t = L1(b2) + mk; break
+        def inv(r_, v_):
+            return v_ if v_ > 2 * r_ else (r_ - ((v_ + 1) >> 1) if v_ & 1 else r_ + (v_ >> 1))
+        x = inv(r, t) if (r << 1) <= mx else mx - 1 - inv(mx - 1 - r, t)
+        assert pos[0] == nb
+        return x + lo
+    for lo, hi in ((-96, 32), (-32, 96)):
+        for ref in (lo, -32, 0, 31, hi - 1):
+            for v in range(lo, hi):
+                bits, nb = C.c_uint32(), C.c_int()
+                L.av1o_subexp_code(v, lo, hi, ref, C.byref(bits), C.byref(nb))
+                assert decode(bits.value, nb.value, lo, hi, ref) == v
+
+
+def test_psy_boost_known_answers(oracle):
+    L = oracle.lib()
+    L.av1o_psy_boost_q14.argtypes = [C.c_uint32, C.c_uint32]; L.av1o_psy_boost_q14.restype = C.c_uint32
+    assert L.av1o_psy_boost_q14(0, 0) == 16384                       # flat source and reconstruction: no boost
+    for sv, dv in ((4033, 4033), (100000, 100000), (4161600, 4161600), (0, 500000), (1234, 987654)):
+        want = 16384.0 * (4033.0 / 16384.0) * (sv + dv + 16384.0) / np.sqrt(16265089.0 + float(sv) * dv)
+        assert abs(L.av1o_psy_boost_q14(sv, dv) - want) <= 1.0
+    assert L.av1o_psy_boost_q14(4161600, 4161600) < 16384 * 0.5     # busy cells are discounted towards (x/2)^(-1/3)-like 0.49
+
+
+def test_premultiplied_pixel_map(oracle, avifdec):
+    """AlphaColorMode::Premultiplied (av1encoder.rs:282-296), as written: a in {0, 255} -> RGBA8::default()."""
+    y, x = np.mgrid[0:40, 0:56]
+    img = np.stack([(x * 4) % 256, (y * 6) % 256, (x + y) * 2 % 256, 40 + x * 3], -1).astype(np.uint8)
+    img[:8, :, 3] = 255; img[8:16, :, 3] = 0
+    data, cs, als = oracle.ravif_encode(img, quality=95, alpha_quality=98, speed=6, alpha_mode=2, depth=8, color_model=1)
+    assert als > 0 and b'prem' in data
+    d = avifdec.decode(data)
+    a = img[..., 3].astype(np.int64)
+    want_a = np.where((a == 0) | (a == 255), 0, a)
+    assert np.mean(np.abs(d['alpha'].astype(int) - want_a)) <= 2.0
+    want = np.where(((a == 0) | (a == 255))[..., None], 0, (img[..., :3].astype(np.int64) * 255 // np.maximum(a, 1)[..., None]) & 255)
+    g, b, r = d['planes']                                                 # identity matrix: planes are G, B, R
+    err = np.abs(np.stack([r, g, b], -1).astype(int) - want)
+    assert np.median(err) <= 4 and np.all(np.stack([r, g, b], -1)[:16].astype(int).mean() < 8)   # the a in {0,255} rows are black

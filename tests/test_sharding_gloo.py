@@ -43,3 +43,52 @@ def test_two_rank_sharding(tmp_path):
     sigs = [s for _, sg in res['shards'] for s in sg]
     assert len(set(sigs)) == 6                           # every rank encodes different images
     assert res['tmax'] == 2.0                            # MAX over ranks
+
+
+GPU_WORKER = textwrap.dedent('''
+    import os, sys, json, hashlib
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B = 2
+    mine = [rank * B + i for i in range(B)]                  # bench.py's shard rule
+    enc = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10).with_device(rank %% m.device_count())
+    bt = m.BatchEncoder(enc, B, 192, 128, channels=3)
+    for k, i in enumerate(mine):
+        bt.upload(k, synth_image(192, 128, index=i))
+    dist.barrier()
+    bt.encode()
+    out = [(i, hashlib.sha256(bt.get(k).avif_file).hexdigest()) for k, i in enumerate(mine)]
+    got = [None] * world
+    dist.all_gather_object(got, out)
+    if rank == 0:
+        print(json.dumps({'files': [x for g in got for x in g]}))
+    bt.close()
+    dist.barrier()
+    dist.destroy_process_group()
+''') % ROOT
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_encode_their_shards(oracle, tmp_path):
+    """The N>1 path with the encoder in it: two ranks (sharing the box's GPU when it has one) encode disjoint image shards
+    through the HIP path; every file == the oracle's for that global image index."""
+    import hashlib, json
+    from cavif_rs_amd.synth import synth_image
+    script = tmp_path / 'gpu_worker.py'
+    script.write_text(GPU_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29579', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29579', str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert sorted(i for i, _ in res['files']) == [0, 1, 2, 3]
+    for i, sha in res['files']:
+        ref, _, _ = oracle.ravif_encode(synth_image(192, 128, index=i), quality=80, speed=4, depth=10)
+        assert hashlib.sha256(ref).hexdigest() == sha

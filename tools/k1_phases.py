@@ -9,7 +9,7 @@ b = m.BatchEncoder(e, B, 1920, 1080, 3)
 for i in range(B): b.upload(i, synth_image(1920, 1080, index=i))
 b.encode(); b.encode()
 p = b.phase_profile().astype(np.float64)          # [tiles][wave][phase] cycles
-names = ['txb_ctx', 'stage_src_edges', 'WAIT_barrier', 'satd13', 'sort', 'delta_satd', 'luma_rd', 'luma_commit', 'cfl_alpha', 'chroma_eval', 'chroma_commit', 'final', 'luma_final_pred']
+names = ['txb_ctx', 'stage_src_edges', 'WAIT_barrier', 'satd13', 'sort', 'delta_satd', 'luma_rd', 'luma_commit', 'cfl_alpha', 'chroma_eval', 'chroma_commit', 'final', 'luma_final_pred', 'tx_size_trial']
 bw = p[:, :, 22:32]
 sub = p[:, :, 16:22]                               # eval_tx sub-phases (nested inside luma_rd / chroma_eval)
 p = p[:, :, :16].copy()
