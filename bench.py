@@ -2,17 +2,25 @@
 """bench.py -- MPix/s of the AVIF still-image encode hot path (speed=4, quality=80, 1080p batch) on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
-torch.distributed.run, one rank per GPU.  A step = one pass of the hot path (K0 front end -> K1 tile
-search -> K2 deblock -> K3 CDEF -> K4 entropy coding -> pack/D2H -> host OBU+container assembly) over one
-batch of synthetic images that is ALREADY RESIDENT in HBM (RGB8, uploaded before the timed region).
-Images shard across ranks with no data-path collective (weak scaling: --batch images per GPU).
-Rank 0 prints one JSON line; `roofline` is for the dominant kernel (tile search) from HIP events,
-`cpu_baseline` is the scalar C oracle (a port, not the reference) on this box's host cores.
+torch.distributed.run, one rank per GPU.  A step = one pass of the hot path (K0 front end -> activity mask -> K1 tile
+search -> K2a/K2 deblock level search + filter -> K3 CDEF -> K5 loop restoration -> K4 entropy coding -> pack/D2H -> host
+OBU+container assembly) over one batch of synthetic images that is ALREADY RESIDENT in HBM (RGB8, uploaded before the
+timed region): that is `value`.  The same run then repeats the timed loop with the H2D of every batch (pinned host memory ->
+HBM, async on the batch's stream, overlapped with the other slots' compute) inside the region: `value_pcie_inclusive`, the
+"encode-only" clock of SURVEY.md 8(d) (RGBA8/RGB8 in pinned host memory -> .avif bytes in host memory).
+Images shard across ranks with no data-path collective (weak scaling: --batch images per GPU); every resident batch slot
+holds DIFFERENT images.  Rank 0 prints one JSON line; `roofline` is for the dominant kernel (tile search) from HIP events of
+a launch with nothing else in flight, `cpu_baseline` is the scalar C oracle (a port, not the reference) on this box's host
+cores, `cpu_baseline_standin` is libaom (through Pillow) at its matching speed on the same inputs -- both stand-ins: the
+reference itself (rav1e) cannot be built in this image.  `--secondary` adds single-image latency lines for BASELINE
+configs 2, 3 and 5; `--end-to-end N` adds the PNG-file -> .avif-file clock of the command line on N synthetic PNGs.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -48,23 +56,92 @@ def _oracle_worker(job):
     return time.time() - t, len(data)
 
 
-def cpu_baseline(w, h, speed, quality, depth, max_seconds=30.0):
-    """Oracle (kind 'port') on the host cores: one image per worker process, bounded sample."""
+def _aom_worker(job):
+    idx, w, h, speed, quality, depth = job
+    import io
+    sys.path.insert(0, ROOT)
+    from PIL import Image
+    from cavif_rs_amd.synth import synth_image
+    im = Image.fromarray(synth_image(w, h, index=idx), 'RGB')
+    t = time.time()
+    buf = io.BytesIO()
+    im.save(buf, format='AVIF', quality=int(quality), speed=speed, codec='aom', subsampling='4:4:4', max_threads=1)
+    return time.time() - t, buf.tell()
+
+
+def _pool_baseline(worker, w, h, speed, quality, depth, n_images, kind, what):
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
+    jobs = [(i, w, h, speed, quality, depth) for i in range(n_images if n_images else cores)]
+    t = time.time()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        res = pool.map(worker, jobs)
+    wall = time.time() - t
+    return {"value": round(len(jobs) * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": kind,
+            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, %s, one process per image, %.1f s wall (%.1f s mean per image, %.0f bytes mean)"
+                      % (len(jobs), w, h, speed, quality, depth, what, wall, sum(r[0] for r in res) / len(res), sum(r[1] for r in res) / len(res))}
+
+
+def cpu_baseline(w, h, speed, quality, depth):
+    """Oracle (kind 'port') on the host cores: one image per worker process, bounded sample."""
     try:
         from tests.helpers import oracle
         oracle.lib()
     except Exception as e:      # oracle not built: report nothing rather than a fake number
         return {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": "oracle unavailable: %s" % e}
-    jobs = [(i, w, h, speed, quality, depth) for i in range(cores)]
-    t = time.time()
-    with mp.get_context('spawn').Pool(cores) as pool:
-        res = pool.map(_oracle_worker, jobs)
-    wall = time.time() - t
-    return {"value": round(len(jobs) * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": "port",
-            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, oracle/ scalar C, one process per image, %.1f s wall (%.1f s mean per image)"
-                      % (len(jobs), w, h, speed, quality, depth, wall, sum(r[0] for r in res) / len(res))}
+    return _pool_baseline(_oracle_worker, w, h, speed, quality, depth, 0, "port", "oracle/ scalar C restatement of THIS encoder (not rav1e)")
+
+
+def cpu_standin(w, h, speed, quality, depth):
+    """libaom through Pillow's bundled libavif: a different AV1 encoder at a comparable speed setting (SURVEY 8(d)(ii) stand-in)."""
+    try:
+        from PIL import features
+        import PIL._avif as _avif
+        if not _avif.encoder_codec_available('aom'):
+            raise RuntimeError('Pillow has no aom encoder')
+        r = _pool_baseline(_aom_worker, w, h, speed, quality, 8, 0, "stand-in", "libaom via Pillow (8-bit 4:4:4, single-threaded per image; NOT the reference)")
+        r["note"] = "a different encoder (libaom, not rav1e) at its own speed %d; comparable settings, not comparable output" % speed
+        return r
+    except Exception as e:
+        return {"value": None, "unit": "MPix/s", "cores": 0, "kind": "stand-in", "sample": "unavailable: %s" % e}
+
+
+def single_image_line(m, name, w, h, alpha, index, speed, quality, alpha_quality, depth, device, reps=2):
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(w, h, index=index, alpha=alpha)
+    enc = m.Encoder().with_quality(quality).with_alpha_quality(alpha_quality).with_speed(speed).with_bit_depth(depth).with_device(device)
+    bt = m.BatchEncoder(enc, 1, w, h, channels=4 if alpha else 3)
+    bt.pinned_input(0)[...] = img
+    best = None
+    for _ in range(reps + 1):                                   # first pass warms up
+        t = time.perf_counter()
+        bt.upload_async(0, 1); bt.encode_async(); bt.wait()
+        dt = time.perf_counter() - t
+        best = dt if best is None or dt < best else best
+    st = bt.stage_ms()
+    out = {"workload": name, "latency_ms": round(best * 1e3, 2), "MPix_per_s": round(w * h / 1e6 / best, 2), "tiles": bt.num_tiles(),
+           "bytes": len(bt.get(0).avif_file), "stage_ms": {k_: round(v_, 2) for k_, v_ in st.items()}}
+    bt.close()
+    return out
+
+
+def end_to_end(n_files, w, h, speed, quality, depth):
+    """PNG files -> .avif files through the command line (cavif_mi), the clock comparable with `cavif` itself."""
+    from scripts.gen_synth_png import write_png
+    from cavif_rs_amd.synth import synth_image
+    cli = os.path.join(ROOT, 'cavif_rs_amd', 'cavif_mi')
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, 'in')); os.makedirs(os.path.join(d, 'out'))
+        for i in range(n_files):
+            write_png(os.path.join(d, 'in', 'synth_%04d.png' % i), synth_image(w, h, index=i))
+        files = sorted(os.path.join(d, 'in', f) for f in os.listdir(os.path.join(d, 'in')))
+        cmd = [cli, '-s', str(speed), '-Q', '%g' % quality, '--depth', str(depth), '-f', '-q', '-o', os.path.join(d, 'out')] + files
+        t = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True)
+        dt = time.perf_counter() - t
+        n_out = len(os.listdir(os.path.join(d, 'out')))
+    return {"files": n_files, "ok": r.returncode == 0 and n_out == n_files, "seconds": round(dt, 3), "MPix_per_s": round(n_files * w * h / 1e6 / dt, 2),
+            "what": "cavif_mi -s%d -Q%g --depth %d -o out/ in/*.png: PNG decode on the host cores + RGBA8 upload + encode + file writes, process start included" % (speed, quality, depth)}
 
 
 def main():
@@ -80,6 +157,9 @@ def main():
     ap.add_argument('--depth', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-identity-check', action='store_true')
+    ap.add_argument('--no-pcie-loop', action='store_true', help='skip the second timed loop (H2D inside the region)')
+    ap.add_argument('--secondary', action='store_true', help='also time BASELINE configs 2, 3 and 5 (single images; config 5 takes a while)')
+    ap.add_argument('--end-to-end', type=int, default=0, metavar='N', help='also run cavif_mi on N synthetic PNG files')
     ap.add_argument('--pipeline', type=int, default=3, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 3 measured best on MI355X)')
     args = ap.parse_args()
 
@@ -109,18 +189,21 @@ def main():
     batches = [m.BatchEncoder(enc, B, w, h, channels=3) for _ in range(depth_q)]
     batch = batches[0]
     first = None
-    for i in range(B):
-        img = synth_image(w, h, index=rank * B + i)
-        if i == 0:
-            first = img
-        for bt in batches:
-            bt.upload(i, img)         # H2D happens here, outside the timed region (every pipeline slot holds the same batch)
+    # slot s of rank r holds images (r * slots + s) * B ... + B - 1: every slot (and every rank) encodes different pictures.
+    # The pictures are written into the batches' pinned host staging once; H2D happens per step (second loop) or here (first loop).
+    for s_, bt in enumerate(batches):
+        for i in range(B):
+            img = synth_image(w, h, index=(rank * depth_q + s_) * B + i)
+            if s_ == 0 and i == 0:
+                first = img
+            bt.pinned_input(i)[...] = img
+        bt.upload_async(0, B)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def run_steps(n):
+    def run_steps(n, with_h2d):
         """n steps; step k runs on slot k % depth_q; a slot is waited for right before it is reused and at the end."""
         stats = []
         inflight = []
@@ -128,38 +211,48 @@ def main():
             bt = batches[k_ % depth_q]
             if len(inflight) == depth_q:
                 old = inflight.pop(0); old.wait(); stats.append(old.stage_ms())
+            if with_h2d:
+                bt.upload_async(0, B)    # pinned host -> HBM on the slot's stream, ahead of its front end; overlaps the other slots' kernels
             bt.encode_async(); inflight.append(bt)
         for old in inflight:
             old.wait(); stats.append(old.stage_ms())   # returns after the stream is drained and the .avif bytes are on the host
         return stats
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    stats = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(with_h2d):
+        run_steps(args.warmup, with_h2d)
+        barrier()
+        t0 = time.perf_counter()
+        stats = run_steps(args.steps, with_h2d)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt[0])
+        return elapsed, stats
+
+    elapsed, stats = timed(False)                                # `value`: inputs resident in HBM
+    elapsed_pcie = None
+    if not args.no_pcie_loop:
+        elapsed_pcie, _ = timed(True)                            # `value_pcie_inclusive`: H2D from pinned host memory inside the region
     search_ms, stage_acc = [], {}
     for st in stats:
         search_ms.append(st['tile_search'])
         for k_, v_ in st.items():
             stage_acc[k_] = stage_acc.get(k_, 0.0) + v_
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
 
     # one more step with nothing else in flight (outside the timed region): the tile search's launch duration without the
-    # stretching that overlapping launches of the other batch slots cause -- reported next to the timed-region figure
+    # stretching that overlapping launches of the other batch slots cause.  This is the kernel's busy time (it agrees with
+    # the rocprofv3 kernel trace, profiles/), and it is what roofline.achieved / frac are computed from.
     batches[0].encode_async(); batches[0].wait()
     isolated_k1_ms = batches[0].stage_ms()['tile_search']
     if rank == 0:
         total_px = world * B * w * h * args.steps
         value = total_px / 1e6 / elapsed
-        k1 = sum(search_ms) / len(search_ms) / 1e3                        # seconds per launch (HIP events, batch stream)
-        algo = ALGO_BYTES_PER_PX.get(args.depth, 10.0) * B * w * h           # algorithmic HBM-read bytes per launch
-        achieved = algo / k1 / 1e9
+        k1_overlapped = sum(search_ms) / len(search_ms)                  # ms per launch inside the timed region (slots overlap)
+        algo = ALGO_BYTES_PER_PX.get(args.depth, 10.0) * B * w * h        # algorithmic HBM-read bytes per launch
+        achieved = algo / (isolated_k1_ms / 1e3) / 1e9
         out = {
             "metric": "MPix/s encoded at speed=4 q=80, 1080p batch; bit-exact vs CPU oracle",
             "value": round(value, 3), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,16 +261,22 @@ def main():
             "config": {"workload": "batch of %d synthetic %dx%d RGB8 images per GPU, speed=%d quality=%g depth=%d, 4:4:4 BT.601, %d tiles per step per GPU"
                                    % (B, w, h, args.speed, args.quality, args.depth, batch.num_tiles()),
                        "images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth,
-                       "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU driven alternately" % (world, depth_q)},
+                       "tile_target": "T = threads unspecified (ravif None): target w*h/min_tile_size^2 uncapped -> %d tiles per image" % (batch.num_tiles() // B),
+                       "tools": "partition 4..16, 13 modes + angle deltas, tx-type + tx-size RDO (TX_MODE_SELECT), CfL, Tune::Psychovisual, deblock level search, CDEF search, sgrproj loop restoration (reduced sets)",
+                       "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU, each holding different images, driven in rotation" % (world, depth_q)},
             "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8),
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
                                                                              "quality": args.quality, "bit_depth": args.depth}),
-                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json; ~200x the algorithmic bytes: register-spill scratch (callee-saved VGPR save/restore of the block search) served by L2 / Infinity Cache, not source re-reads",
-                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(k1 * 1e3, 3),
-                         "isolated_launch_ms": round(isolated_k1_ms, 3), "achieved_isolated": round(algo / (isolated_k1_ms / 1e3) / 1e9, 4)},
+                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: private-segment (spill / call frame) traffic served by L2 / Infinity Cache, not source re-reads",
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
+                         "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
+                         "overlapped_launch_ms": round(k1_overlapped, 3)},
             "stage_ms_per_step": {k_: round(v_ / args.steps, 3) for k_, v_ in stage_acc.items()},
         }
+        if elapsed_pcie is not None:
+            out["value_pcie_inclusive"] = round(total_px / 1e6 / elapsed_pcie, 3)
+            out["pcie_note"] = "same loop with every batch's H2D (pinned host -> HBM, %.1f MB per step, async on the slot's stream) inside the timed region" % (B * w * h * 3 / 1e6)
         if not args.no_identity_check:
             try:
                 from tests.helpers import oracle
@@ -187,9 +286,20 @@ def main():
                 out["output_identity"] = "unchecked: %s" % e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, args.speed, args.quality, args.depth)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline_standin"] = cpu_standin(w, h, args.speed, args.quality, args.depth)
     for bt in batches:
         bt.close()
+    if rank == 0:
+        if args.secondary:
+            aq = min((args.quality + 100.0) / 2.0, args.quality + args.quality / 4.0 + 2.0)
+            out["secondary"] = [
+                single_image_line(m, "config 2: 1 x 1920x1080 RGB, speed 4, q80, 10-bit", 1920, 1080, False, 0, 4, 80.0, aq, 10, device),
+                single_image_line(m, "config 3: 1 x 4096x4096 RGBA (alpha plane = second frame), speed 4, q80", 4096, 4096, True, 3, 4, 80.0, aq, 10, device),
+                single_image_line(m, "config 5: 1 x 7680x4320 RGB, speed 1, q80, 10-bit (reference asks for <= 7 tiles -> 8)", 7680, 4320, False, 5, 1, 80.0, aq, 10, device, reps=1),
+            ]
+        if args.end_to_end:
+            out["end_to_end"] = end_to_end(args.end_to_end, w, h, args.speed, args.quality, args.depth)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -205,7 +205,9 @@ struct mi_batch {
   mi_ravif_encoder enc{}; int n = 0; uint32_t w = 0, h = 0; int channels = 3, device = 0, depth = 10;
   std::vector<uint8_t> exif;                                       // the batch's own copy of enc.exif (the caller's buffer need not outlive mi_batch_create)
   hipStream_t stream = nullptr;
-  uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // n * w*h*channels
+  int cap = 0;                                                     // images the batch was created for (n = images of the current run <= cap)
+  uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // cap * w*h*channels
+  uint8_t *h_pixels = nullptr;                                     // pinned staging of the same size: the H2D source (async, no pageable copies)
   int *d_alpha_flags = nullptr; std::vector<int> alpha_flags;
   uint8_t *d_clean = nullptr, *d_clean_tmp = nullptr; unsigned long long *d_alpha_acc = nullptr;   // dirty-alpha cleaner (RGBA, UnassociatedClean)
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
@@ -313,12 +315,12 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   if (hipSetDevice(e->device) != hipSuccess) return nullptr;
   if (ensure_tables(e->device) != MI_OK) return nullptr;
   mi_batch *b = new mi_batch();
-  b->enc = *e; b->n = n_images; b->w = w; b->h = h; b->channels = channels; b->device = e->device; b->depth = e->depth == 8 ? 8 : 10;
+  b->enc = *e; b->n = b->cap = n_images; b->w = w; b->h = h; b->channels = channels; b->device = e->device; b->depth = e->depth == 8 ? 8 : 10;
   if (e->exif && e->exif_len) b->exif.assign(e->exif, e->exif + e->exif_len);
   b->enc.exif = b->exif.empty() ? nullptr : b->exif.data(); b->enc.exif_len = b->exif.size();
   b->alpha_flags.assign(n_images, 0);
   b->pixel_bytes = (size_t)n_images * w * h * channels;
-  bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess &&
+  bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess && hipHostMalloc(&b->h_pixels, b->pixel_bytes) == hipSuccess &&
             hipMalloc(&b->d_alpha_flags, sizeof(int) * n_images) == hipSuccess;
   if (ok && channels == 4 && e->alpha_mode == 1)
     ok = hipMalloc(&b->d_clean, b->pixel_bytes) == hipSuccess && hipMalloc(&b->d_clean_tmp, (size_t)w * h * 4) == hipSuccess &&
@@ -331,12 +333,30 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   return b;
 }
 
-int mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px) {
-  if (!b || index < 0 || index >= b->n || !pixels) return MI_INVALID_ARGUMENT;
+// The batch owns a pinned host staging area laid out like its HBM input slot; H2D always starts from there.
+uint8_t *mi_batch_input(mi_batch *b, int index) {
+  if (!b || index < 0 || index >= b->cap) return nullptr;
+  return b->h_pixels + (size_t)index * b->w * b->h * b->channels;
+}
+int mi_batch_set_count(mi_batch *b, int n_images) {
+  if (!b || b->in_flight || n_images < 1 || n_images > b->cap) return MI_INVALID_ARGUMENT;
+  b->n = n_images; b->alpha_flags.assign(n_images, 0);
+  return MI_OK;
+}
+// enqueue the H2D of images [first, first + count) from the pinned staging on the batch's stream; returns at once
+int mi_batch_upload_async(mi_batch *b, int first, int count) {
+  if (!b || first < 0 || count < 1 || first + count > b->cap) return MI_INVALID_ARGUMENT;
   hipSetDevice(b->device);
+  const size_t img = (size_t)b->w * b->h * b->channels;
+  HIP_OK(hipMemcpyAsync(b->d_pixels + first * img, b->h_pixels + first * img, count * img, hipMemcpyHostToDevice, b->stream));
+  return MI_OK;
+}
+int mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px) {
+  if (!b || index < 0 || index >= b->cap || !pixels) return MI_INVALID_ARGUMENT;
   const size_t row = (size_t)b->w * b->channels;
-  uint8_t *dst = b->d_pixels + (size_t)index * b->w * b->h * b->channels;
-  HIP_OK(hipMemcpy2DAsync(dst, row, pixels, stride_px * b->channels, row, b->h, hipMemcpyHostToDevice, b->stream));
+  uint8_t *dst = mi_batch_input(b, index);
+  for (uint32_t y = 0; y < b->h; y++) memcpy(dst + y * row, pixels + (size_t)y * stride_px * b->channels, row);
+  if (int st = mi_batch_upload_async(b, index, 1)) return st;
   HIP_OK(hipStreamSynchronize(b->stream));
   return MI_OK;
 }
@@ -541,6 +561,7 @@ void mi_batch_destroy(mi_batch *b) {
   hipSetDevice(b->device);
   batch_free_device(b);
   if (b->d_pixels) hipFree(b->d_pixels);
+  if (b->h_pixels) hipHostFree(b->h_pixels);
   if (b->d_alpha_flags) hipFree(b->d_alpha_flags);
   if (b->d_clean) hipFree(b->d_clean);
   if (b->d_clean_tmp) hipFree(b->d_clean_tmp);
@@ -590,25 +611,56 @@ int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_de
   for (size_t i = 0; i < n; i++) { out[i].avif_file = nullptr; out[i].avif_len = out[i].color_byte_size = out[i].alpha_byte_size = 0; }
   std::atomic<size_t> cursor{ 0 };
   const size_t max_run = 32;
+  // Per device: two resident batch objects per image shape, created on first use and kept for the whole call.  While one
+  // batch encodes, the host fills the other one's pinned staging and enqueues its H2D + encode, so uploads, tile search,
+  // entropy coding and the host-side assembly of consecutive runs overlap (the same rotation bench.py drives).
   auto worker = [&](int dev) {
     mi_ravif_encoder enc = *e; enc.device = dev;
+    struct Slot { mi_batch *b = nullptr; size_t i0 = 0, i1 = 0; bool busy = false; };
+    struct Shape { uint32_t w, h; int ch; Slot slot[2]; int next = 0; };
+    std::vector<Shape> shapes;
+    auto collect = [&](Slot &sl) {
+      if (!sl.busy) return;
+      const int rc = mi_batch_wait(sl.b);
+      for (size_t i = sl.i0; i < sl.i1; i++) st[i] = rc == MI_OK ? mi_batch_get(sl.b, (int)(i - sl.i0), &out[i]) : rc;
+      sl.busy = false;
+    };
     for (;;) {
       // claim a run [i0, i1) of images with the same shape
       size_t i0 = cursor.load(), i1;
+      bool done = false;
       do {
-        if (i0 >= n) return;
+        if (i0 >= n) { done = true; break; }
         i1 = i0 + 1;
         while (i1 < n && i1 - i0 < max_run && in[i1].width == in[i0].width && in[i1].height == in[i0].height && in[i1].channels == in[i0].channels) i1++;
       } while (!cursor.compare_exchange_weak(i0, i1));
+      if (done) break;
       const mi_image_desc &d0 = in[i0];
-      int rc = (d0.pixels && d0.width && d0.height && (d0.channels == 3 || d0.channels == 4)) ? MI_OK : MI_INVALID_ARGUMENT;
-      mi_batch *b = rc == MI_OK ? mi_batch_create(&enc, (int)(i1 - i0), d0.width, d0.height, d0.channels) : nullptr;
-      if (rc == MI_OK && !b) rc = MI_ENCODING_ERROR;
-      for (size_t i = i0; i < i1 && rc == MI_OK; i++) rc = in[i].pixels ? mi_batch_upload(b, (int)(i - i0), in[i].pixels, in[i].stride_px ? in[i].stride_px : in[i].width) : MI_INVALID_ARGUMENT;
-      if (rc == MI_OK) rc = mi_batch_encode(b);
-      for (size_t i = i0; i < i1; i++) st[i] = rc == MI_OK ? mi_batch_get(b, (int)(i - i0), &out[i]) : rc;
-      if (b) mi_batch_destroy(b);
+      bool ok = d0.pixels && d0.width && d0.height && (d0.channels == 3 || d0.channels == 4);
+      for (size_t i = i0; i < i1 && ok; i++) ok = in[i].pixels != nullptr;
+      if (!ok) { for (size_t i = i0; i < i1; i++) st[i] = MI_INVALID_ARGUMENT; continue; }
+      Shape *sh = nullptr;
+      for (Shape &c : shapes) if (c.w == d0.width && c.h == d0.height && c.ch == d0.channels) sh = &c;
+      if (!sh) { shapes.push_back(Shape{ d0.width, d0.height, d0.channels, {}, 0 }); sh = &shapes.back(); }
+      Slot &sl = sh->slot[sh->next]; sh->next ^= 1;
+      collect(sl);                                           // the slot's previous run, if any
+      if (!sl.b) sl.b = mi_batch_create(&enc, (int)max_run, d0.width, d0.height, d0.channels);
+      int rc = sl.b ? mi_batch_set_count(sl.b, (int)(i1 - i0)) : MI_ENCODING_ERROR;
+      if (rc == MI_OK) {
+        const size_t row = (size_t)d0.width * d0.channels;
+        for (size_t i = i0; i < i1; i++) {
+          uint8_t *dst = mi_batch_input(sl.b, (int)(i - i0));
+          const size_t sp = in[i].stride_px ? in[i].stride_px : in[i].width;
+          if (sp == in[i].width) memcpy(dst, in[i].pixels, row * d0.height);
+          else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, in[i].pixels + (size_t)y * sp * d0.channels, row);
+        }
+        rc = mi_batch_upload_async(sl.b, 0, (int)(i1 - i0));
+      }
+      if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
+      if (rc != MI_OK) { for (size_t i = i0; i < i1; i++) st[i] = rc; continue; }
+      sl.i0 = i0; sl.i1 = i1; sl.busy = true;
     }
+    for (Shape &c : shapes) for (Slot &sl : c.slot) { collect(sl); if (sl.b) mi_batch_destroy(sl.b); }
   };
   std::vector<std::thread> th;
   for (int d : devs) th.emplace_back(worker, d);

@@ -71,6 +71,10 @@ def load_library():
     L.mi_batch_create.argtypes = [C.POINTER(_RavifEncoder), C.c_int, C.c_uint32, C.c_uint32, C.c_int]
     L.mi_batch_create.restype = C.c_void_p
     L.mi_batch_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.mi_batch_input.argtypes = [C.c_void_p, C.c_int]
+    L.mi_batch_input.restype = C.c_void_p
+    L.mi_batch_upload_async.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mi_batch_set_count.argtypes = [C.c_void_p, C.c_int]
     L.mi_batch_encode.argtypes = [C.c_void_p]
     L.mi_batch_encode_async.argtypes = [C.c_void_p]
     L.mi_batch_wait.argtypes = [C.c_void_p]
@@ -311,6 +315,24 @@ class BatchEncoder:
         a = np.ascontiguousarray(pixels, dtype=np.uint8)
         assert a.shape == (self.h, self.w, self.channels)
         st = self._L.mi_batch_upload(self._h, index, a.ctypes.data, self.w)
+        if st:
+            raise AvifError(st)
+
+    def pinned_input(self, index):
+        """numpy view of the batch's PINNED host staging of image `index`: fill it in place, then upload_async()."""
+        ptr = self._L.mi_batch_input(self._h, index)
+        if not ptr:
+            raise AvifError(4)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(self.h, self.w, self.channels))
+
+    def upload_async(self, first=0, count=None):
+        """enqueue pinned host -> HBM for a range of images on the batch's stream (returns at once)"""
+        st = self._L.mi_batch_upload_async(self._h, first, self.n if count is None else count)
+        if st:
+            raise AvifError(st)
+
+    def set_count(self, n_images):
+        st = self._L.mi_batch_set_count(self._h, n_images)
         if st:
             raise AvifError(st)
 

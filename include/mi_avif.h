@@ -95,7 +95,12 @@ int  mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_
 typedef struct mi_batch mi_batch;
 /* n images of w x h, channels 3 (RGB8) or 4 (RGBA8) on HIP device `e->device` */
 mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels);
-int  mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px);   /* H2D into the batch's HBM input slot */
+int  mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride_px);   /* copy into the pinned staging + H2D into the batch's HBM input slot (blocking) */
+/* zero-copy form: fill the batch's PINNED host staging of image `index` (w*h*channels bytes, rows packed) in place, then enqueue
+ * the H2D of a range of images on the batch's stream (returns at once; ordered before the next mi_batch_encode[_async]) */
+uint8_t *mi_batch_input(mi_batch *b, int index);
+int  mi_batch_upload_async(mi_batch *b, int first, int count);
+int  mi_batch_set_count(mi_batch *b, int n_images);                                       /* images of the next run (<= the count the batch was created for) */
 int  mi_batch_encode(mi_batch *b);                                                        /* the hot path over all resident images */
 /* split form: enqueue the GPU work and return; wait = sync + one packed D2H + OBU/container assembly.  Two batches
  * driven alternately overlap one batch's entropy coding / loop filters with the next batch's tile search. */
