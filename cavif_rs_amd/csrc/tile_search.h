@@ -69,15 +69,18 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t lpred[N <= 16 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
-  // luma transform-size trial: the full-size winner is parked (levels in lpred / qpark), the sub-blocks go through ssrc / spred
-  int lm_cul, lm_dcc, ssctx, sdctx, sub_eob[4]; long long lm_mode_j;
+  // luma transform-size trial, LDS-resident: the undivided winner is already committed to the frame; the four sub-blocks are
+  // reconstructed into split_rec / split_qc (for MAXN <= 16 these alias lpred, which is dead after the mode decision) and only
+  // reach the frame if the split wins.  ssrc = the four sub-sources, spred = the current sub-block's prediction, nb_* = the
+  // (level, dc) contexts the block's outer neighbours left behind.
+  int sub_tx[4], sub_eob[4], sub_cul[4], sub_dcc[4], sflag; long long lm_mode_j;
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
-  // its own variance), the four 4x4 variances of an 8x8 block, the same for the sub-block of the tx-size trial, and the
-  // block's mean activity for chroma
+  // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
   int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
-  uint16_t ssrc[(N / 2) * (N / 2)];
-  int32_t qpark[N <= 16 ? 1 : (N < 32 ? N * N : 1024)];
-  uint16_t spred[N <= 16 ? 1 : (N / 2) * (N / 2)];
+  uint16_t ssrc[N * N], spred[(N / 2) * (N / 2)];
+  uint8_t nb_top[16][2], nb_left[16][2];
+  int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
+  uint16_t split_rec[N <= 16 ? 1 : N * N];
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -370,8 +373,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
   const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx;        // one-level-smaller luma transforms are tried after the mode decision
-  LDS int32_t *qpark = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->qpark;
-  LDS uint16_t *spred = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->spred;
+  LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;
+  LDS uint16_t *split_rec = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->split_rec;
+  LDS uint16_t *spred = SH->spred;
   // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
   const bool pred_cached = MAXN <= 16 && NW > 1 && ncand * nn <= 768;
   if (pred_cached) {
@@ -485,10 +489,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
     fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
     fill_map_dev(f->m_txsize, ms, r, c, n4, BS);
-    if (f->np > 1 || tx_trial) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
-    if (tx_trial) for (int i = LANE; i < qn; i += 64) qpark[i] = best_qc[i];      // the full-size levels, should the split trial lose
+    if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
     if (LANE == 0) {
-      SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob; SH->lm_cul = my_tr.cul; SH->lm_dcc = my_tr.dcc;
+      SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob;
       SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
     }
   }
@@ -508,49 +511,106 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     const uint16_t *dcost = k.cost + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
     if (tx_trial) {
-      constexpr int SBS = BS - 1, hn = n >> 1, half = n4 >> 1, hnn = hn * hn, SCS = hn < 32 ? hn : 32;
+      constexpr int SBS = BS - 1, hn = n >> 1, half = n4 >> 1, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
       long long j_split = SH->lm_mode_j + (((long long)dcost[1] * f->rdmult + 256) >> 9);
       int stx_ns = 0, stx_set = 0;
       const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
       const int sntx = stx_off >= 0 ? stx_ns : 1;
       int sub_any = 0;
+      // ---- stage 0, all waves: the four sub-sources; wave 0: outer neighbour contexts + the two decoded flags that lie outside the block
+      for (int q = W; q < 4; q += NW) {
+        const int so = (q >> 1) * hn * n + (q & 1) * hn;
+        for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[q * hnn + idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
+      }
+      if (W == 0) {
+        if (LANE < n4) {
+          const int k2 = LANE;
+          int l = 0, d = 0;
+          if (availU && c + k2 < f->mi_cols) { l = f->m_lvl[0][(r - 1) * ms + c + k2]; d = f->m_dc[0][(r - 1) * ms + c + k2]; }
+          SH->nb_top[k2][0] = (uint8_t)l; SH->nb_top[k2][1] = (uint8_t)d;
+          l = 0; d = 0;
+          if (availL && r + k2 < f->mi_rows) { l = f->m_lvl[0][(r + k2) * ms + c - 1]; d = f->m_dc[0][(r + k2) * ms + c - 1]; }
+          SH->nb_left[k2][0] = (uint8_t)l; SH->nb_left[k2][1] = (uint8_t)d;
+        }
+        if (LANE == 0) {
+          const int ar3 = (c + n4 < t->mi_col_end) && f->m_decoded[(r + half - 1) * ms + c + n4];
+          const int bl3 = (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c + half - 1];
+          SH->sflag = ar3 | (bl3 << 1);
+        }
+      }
+      WG_SYNC();
+      const int sflag = SH->sflag;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
         if (!(j_split < luma_j)) break;
-        const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half, sx = cc * 4, sy = rr * 4;
+        const int sx = x + (q & 1) * hn, sy = y + (q >> 1) * hn;
         const int sU = availU || (q >> 1), sL = availL || (q & 1);
         if (W == 0) {
-          const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
-          const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
-          int sc_, dc_;
-          txb_ctx_dev(f, t, 0, rr, cc, SBS, BS, &sc_, &dc_);
-          if (LANE == 0) { SH->ssctx = sc_; SH->sdctx = dc_; }
-          {
-            constexpr int scp = hn >= 8 ? hn / 8 : 1, pcp = n / 8;
-            if (LANE < scp * scp) {
-              if constexpr (hn == 4) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; }
-              else { const int pc = ((q >> 1) * scp + LANE / scp) * pcp + (q & 1) * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
+          // raw edges of the sub-block (spec 7.11.2 / load_edges) from the block's raw edges and the sub-blocks reconstructed so far
+          LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+          const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride;
+          const uint16_t *grec = f->rec[0];
+          for (int i = LANE - 1; i < 2 * hn; i += 64) {
+            int a, l;
+            if (q == 0) { a = ra[i]; l = rl[i]; }
+            else if (q == 1) {
+              a = availU ? ra[hn + i] : split_rec[hn - 1];
+              l = i < 0 ? a : split_rec[imin_(i, hn - 1) * n + hn - 1];
+            } else if (q == 2) {
+              a = split_rec[(hn - 1) * n + imax_(i, 0)];
+              l = availL ? rl[hn + i] : split_rec[(hn - 1) * n];
+              if (i < 0) a = l;
+            } else {
+              a = i < hn ? split_rec[(hn - 1) * n + hn + i] : ((sflag & 1) ? (int)grec[(size_t)(sy - 1) * rs + imin_(max_x, sx + i)] : (int)split_rec[(hn - 1) * n + n - 1]);
+              l = i < hn ? split_rec[(hn + imax_(i, 0)) * n + hn - 1] : ((sflag & 2) ? (int)grec[(size_t)imin_(max_y, sy + i) * rs + sx - 1] : (int)split_rec[(n - 1) * n + hn - 1]);
+              if (i < 0) l = a;
             }
+            A[i] = (uint16_t)a; Lf[i] = (uint16_t)l;
           }
-          const int so = (q >> 1) * hn * n + (q & 1) * hn;
-          for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
-          load_edges(f, 0, sx, sy, hn, sL, sU, s_ar, s_bl, SH->ra[0] + EDGE_OFF, SH->rl[0] + EDGE_OFF);
-          predict_block(f, sx, sy, log2w - 1, sL, sU, best_mode, best_delta, ftype_y, ra, rl, wa, wl, S->etmp, spred);
+          WAVE_SYNC();
+          predict_block(f, sx, sy, log2w - 1, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, spred);
         }
         WG_SYNC();
-        const int ssc = SH->ssctx, sdc = SH->sdctx;
+        // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs) from the staged neighbour contexts
+        int ssc, sdc;
+        {
+          int top = 0, left = 0, dcs = 0;
+#pragma unroll
+          for (int k2 = 0; k2 < half; k2++) {
+            int l, d;
+            if ((q >> 1) == 0) { l = SH->nb_top[(q & 1) * half + k2][0]; d = SH->nb_top[(q & 1) * half + k2][1]; } else { l = SH->sub_cul[q - 2]; d = SH->sub_dcc[q - 2]; }
+            top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+            if ((q & 1) == 0) { l = SH->nb_left[(q >> 1) * half + k2][0]; d = SH->nb_left[(q >> 1) * half + k2][1]; } else { l = SH->sub_cul[q - 1]; d = SH->sub_dcc[q - 1]; }
+            left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+          }
+          sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+          if (top == 0 && left == 0) ssc = 1;
+          else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+          else if (imax_(top, left) <= 3) ssc = 4;
+          else if (imin_(top, left) <= 3) ssc = 5;
+          else ssc = 6;
+        }
+        // psychovisual references of the sub-block
+        if (W == 0) {
+          constexpr int scp = hn >= 8 ? hn / 8 : 1, pcp = n / 8;
+          if (LANE < scp * scp) {
+            if constexpr (hn == 4) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; }
+            else { const int pc = ((q >> 1) * scp + LANE / scp) * pcp + (q & 1) * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
+          }
+        }
         long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
-        bool sgrouped = false;
         if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
-          sgrouped = true;
           const int g = GROUP_ID, e = W * 4 + g;
+          constexpr int pcp = n / 8;
+          const int psv_q = hn == 4 ? SH->psv4[q] : SH->psv[(q >> 1) * pcp + (q & 1)], pact_q = hn == 4 ? SH->pact[0] : SH->pact[(q >> 1) * pcp + (q & 1)];
           if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
             const bool live = e < sntx;
             int txtype;
             if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             GroupRes gr;
-            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, f->tune_psnr ? -1 : SH->spsv[0], SH->spact[0], &gr);
+            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
+                           f->tune_psnr ? -1 : psv_q, pact_q, &gr);
             long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
             if (!live) j = J_INF;
 #pragma unroll
@@ -563,15 +623,15 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
               }
             }
           }
-        }
-        if (!sgrouped) {
-          if constexpr (!(SBS <= BS_8 && NW == 4 && MAXN <= 16))
+        } else {
+          WG_SYNC();                                           // spsv / spact staged by wave 0
           for (int e = W; e < sntx; e += NW) {
             int txtype;
             if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             TxRes tr;
-            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr, SH->ssrc, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
+            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
+                                                   SH->ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
             if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
           }
         }
@@ -580,29 +640,37 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         int sw = 0;
         for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
         const long long sub_j = SH->wbest_j[sw];
-        if (W == sw) {
+        if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
           const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
           if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
-          commit_plane<SBS>(f, 0, rr, cc, srec, sqc, s_eob, s_cul, s_dcc);
-          fill_map_dev(f->m_txtype, ms, rr, cc, half, s_eob ? stx : DCT_DCT);
-          fill_map_dev(f->m_decoded, ms, rr, cc, half, 1);
-          if (LANE == 0) SH->sub_eob[q] = s_eob;
+          const int ro = (q >> 1) * hn * n + (q & 1) * hn;
+          for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
+          for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
+          if (LANE == 0) { SH->sub_eob[q] = s_eob; SH->sub_cul[q] = s_cul; SH->sub_dcc[q] = s_dcc; SH->sub_tx[q] = s_eob ? stx : DCT_DCT; }
         }
         WG_SYNC();
         sub_any |= SH->sub_eob[q] > 0;
         j_split += sub_j;
-        (void)SCS;
       }
       if (j_split < luma_j) {
+        // the split wins: its reconstruction, levels and contexts replace the undivided transform's in the frame
         luma_j = j_split; any_coef = sub_any;
+        const int tid = threadIdx.x, T = 64 * NW;
+        uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x;
+        int32_t *gc_ = f->coef[0] + (size_t)y * f->stride + x;
+        for (int i = tid; i < nn; i += T) { const uint16_t v = split_rec[i]; gr_[(i / n) * f->stride + (i % n)] = v; if (f->np > 1) SH->luma_rec[i] = v; }
+        for (int i = tid; i < 4 * sqn; i += T) { const int q = i / sqn, j2 = i - q * sqn; gc_[((q >> 1) * hn + j2 / SCS) * f->stride + (q & 1) * hn + j2 % SCS] = split_qc[i]; }
         if (W == 0) {
           fill_map_dev(f->m_txsize, ms, r, c, n4, SBS);
-          if (f->np > 1) { const uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x; for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = gr_[(i / n) * f->stride + (i % n)]; }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
+            fill_map_dev(f->m_lvl[0], ms, rr, cc, half, SH->sub_cul[q]);
+            fill_map_dev(f->m_dc[0], ms, rr, cc, half, SH->sub_dcc[q]);
+            fill_map_dev(f->m_txtype, ms, rr, cc, half, SH->sub_tx[q]);
+            if (LANE == 0) f->m_eob[0][rr * ms + cc] = (uint16_t)SH->sub_eob[q];
+          }
         }
-      } else if (W == 0) {
-        // the undivided transform stays: put its reconstruction, levels and contexts back
-        commit_plane<BS>(f, 0, r, c, SH->luma_rec, qpark, SH->lm_eob, SH->lm_cul, SH->lm_dcc);
-        fill_map_dev(f->m_txtype, ms, r, c, n4, SH->lm_eob ? SH->lm_tx : DCT_DCT);
       }
       WG_SYNC();
     }
