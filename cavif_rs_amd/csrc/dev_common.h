@@ -48,6 +48,7 @@ struct FrameDev {
   uint16_t *fin[3];                        // post-CDEF output
   uint16_t *lrp[3];                        // post-loop-restoration output (the final picture when enable_restoration)
   uint8_t *lr_type, *lr_set; int8_t *lr_xqd;   // per (plane, restoration unit): 0 none / 1 sgrproj, parameter set, xqd[2]
+  void *lr_cand;                           // search scratch: per (plane, unit, set) { cost, xqd } (restoration.h LrCand, 16 per unit)
   uint32_t lr_cost[3];                     // static cost of the switchable restoration_type symbols (1/512 bit)
   int enable_restoration, sgr_full, enable_cdef, fast_deblock;
   int8_t *cdef_idx;
@@ -113,13 +114,20 @@ struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };
 
 // ---- Tune::Psychovisual helpers (oracle/av1o_common.c av1o_psy_boost_q14 / av1o_cell_var; rav1e dist.rs cdef_dist_kernel,
 // activity.rs, recalled): integer, bit-identical to the CPU restatement.
+__device__ __forceinline__ uint32_t psy_isqrt46(unsigned long long n) {       // floor(sqrt(n)), n < 2^46: float guess + exact integer correction
+  uint32_t x = (uint32_t)sqrtf((float)n);
+  while ((unsigned long long)x * x > n) x--;
+  while ((unsigned long long)(x + 1) * (x + 1) <= n) x++;
+  return x;
+}
 __device__ inline uint32_t psy_boost_q14(uint32_t sv, uint32_t dv) {
   const unsigned long long num = 4033ull * ((unsigned long long)sv + dv + 16384);
-  const unsigned long long rad = (16265089ull + (unsigned long long)sv * dv) << 16;
-  unsigned long long x = (unsigned long long)sqrt((double)rad);      // a guess; the two loops make it the exact floor root
-  while (x * x > rad) x--;
-  while ((x + 1) * (x + 1) <= rad) x++;
-  return (uint32_t)(((num << 8) + x / 2) / x);
+  const uint32_t den = psy_isqrt46(16265089ull + (unsigned long long)sv * dv);
+  const unsigned long long t = num + den / 2;
+  uint32_t q = (uint32_t)((float)t / (float)den);              // guess, then exact
+  while ((unsigned long long)q * den > t) q--;
+  while ((unsigned long long)(q + 1) * den <= t) q++;
+  return q;
 }
 // 64 x variance of a w x w cell (w = 8 or 4, 4x4 scaled to the 8x8 equivalent) on the 8-bit scale
 __device__ __forceinline__ uint32_t psy_cell_var(uint32_t sum, uint32_t sum2, int w, int bd) {

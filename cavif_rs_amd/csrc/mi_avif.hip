@@ -109,6 +109,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     const size_t nlr = (size_t)lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) * p.np;
     for (int i = 0; i < 3; i++) d.lrp[i] = (i < p.np && p.cfg.lrf) ? (uint16_t *)take(npx * 2) : nullptr;
     d.lr_type = take(nlr); d.lr_set = take(nlr); d.lr_xqd = (int8_t *)take(nlr * 2);
+    d.lr_cand = p.cfg.lrf ? take(nlr * 16 * sizeof(LrCand)) : nullptr;
   }
   d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
@@ -185,14 +186,17 @@ static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJ
 
 // The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
 // points: K2a deblock level search -> level pick -> K2 deblock (vertical, horizontal edges) -> K3 CDEF.
-static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, int max_lr_units, hipStream_t s, hipEvent_t ev_cdef) {
+static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, int max_lr_units, int max_lr_sets, hipStream_t s, hipEvent_t ev_cdef) {
   hipLaunchKernelGGL(deblock_tally_kernel, dim3((max_mi_cells + 255) / 256, 6, nframes), dim3(256), 0, s, d_frames, nframes);
   hipLaunchKernelGGL(deblock_pick_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
   for (int pass = 0; pass < 2; pass++)
     hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, d_frames, nframes, pass);
   if (ev_cdef) { hipError_t e = hipEventRecord(ev_cdef, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, d_frames, 1);
-  if (max_lr_units > 0) hipLaunchKernelGGL(lr_kernel, dim3(max_lr_units, 3, nframes), dim3(256), 0, s, d_frames);
+  if (max_lr_units > 0) {
+    hipLaunchKernelGGL(lr_search_kernel, dim3(max_lr_units, 3 * max_lr_sets, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(lr_kernel, dim3(max_lr_units, 3, nframes), dim3(256), 0, s, d_frames);
+  }
   return hipGetLastError();
 }
 
@@ -442,7 +446,7 @@ int mi_batch_encode_async(mi_batch *b) {
   }
   // ---- tile job list, frame descriptors
   b->jobs.clear();
-  int max_mi_cells = 0, max_sb = 0, max_lr = 0, class_begin[6] = { 0, 0, 0, 0, 0, 0 };
+  int max_mi_cells = 0, max_sb = 0, max_lr = 0, max_lr_sets = 4, class_begin[6] = { 0, 0, 0, 0, 0, 0 };
   // tile jobs grouped by block-size class (one K1 instantiation per class); tile_base indexes the grouped list
   for (int cls = 2; cls <= 4; cls++) {
     class_begin[cls] = (int)b->jobs.size();
@@ -458,7 +462,7 @@ int mi_batch_encode_async(mi_batch *b) {
   for (size_t k = 0; k < b->frames.size(); k++) {
     FramePlan &p = b->frames[k];
     max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
-    if (p.cfg.lrf) max_lr = std::max(max_lr, lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height));
+    if (p.cfg.lrf) { max_lr = std::max(max_lr, lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height)); if (p.cfg.sgr_full) max_lr_sets = 16; }
     // clear the state the kernels rely on being zero
     HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   }
@@ -473,7 +477,7 @@ int mi_batch_encode_async(mi_batch *b) {
   for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
-  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, s, b->ev[3]));
+  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
@@ -714,7 +718,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   const int njobs = (int)jobs.size();
   hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
   HIP_OK(launch_search(p.maxbs, d_frame, d_jobs, njobs, s));
-  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, s, nullptr));
+  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);

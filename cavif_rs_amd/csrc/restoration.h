@@ -102,25 +102,78 @@ __device__ inline void lr_load_window(LrLds &L, const FrameDev *f, int plane, co
   }
   __syncthreads();
 }
-// box filter process of the chunk for one (radius, s, pass); flt[k] = value of sample tid + 256 k (row-major over w x h)
-__device__ inline void lr_box_filter(LrLds &L, const LrChunk &c, int r, int sparam, int pass, int bd, int flt[16]) {
-  const int n = (2 * r + 1) * (2 * r + 1), one_by_n = ((1 << 12) + n / 2) / n;
+// Box filter process of a chunk (spec 7.17.3) in three steps, so that the search can reuse the first one across parameter sets:
+//   raw : per thread, the (sum of squares, sum) box sums of its positions of the (w + 2) x (h + 2) grid -- they depend on the
+//         radius only.  Radius 2 (pass 0) weights rows of odd parity only, so only those rows are computed.
+//   map : (a, b) -> (A, B) of one parameter set (its s), into LDS.
+//   F   : the 3x3 weighting of (A, B) -> filtered value of the thread's 16 samples (tid + 256 k, row-major over w x h).
+template <int R> struct LrRaw { static constexpr int NP = R == 2 ? 9 : 18; uint32_t a[NP], b[NP]; };
+template <int R> __device__ __forceinline__ bool lr_pos(const LrChunk &c, int k, int *pi, int *pj) {
   const int aw = c.w + 2, ah = c.h + 2;
-  for (int pos = threadIdx.x; pos < aw * ah; pos += 256) {
-    const int pi = pos / aw, pj = pos - pi * aw;             // (i + 1, j + 1)
-    if (pass == 0 && !((c.y0 + pi - 1) & 1)) continue;       // pass 0 weights rows of odd parity only
-    uint32_t a = 0, b = 0;
-    const int wy = pi + 2, wx = pj + 2;                      // window coordinates of (i, j)
-    for (int dy = -r; dy <= r; dy++) for (int dx = -r; dx <= r; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
-    const int s2 = 2 * (bd - 8), s1 = bd - 8;
-    const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
-    const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
-    const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
-    const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
-    const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
-    L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
+  const int nrows = R == 2 ? (ah - (c.y0 & 1) + 1) >> 1 : ah;
+  const int pos = threadIdx.x + 256 * k;
+  if (pos >= nrows * aw) return false;
+  const int row = pos / aw;
+  *pj = pos - row * aw; *pi = R == 2 ? (c.y0 & 1) + 2 * row : row;           // pi = i + 1, pj = j + 1
+  return true;
+}
+template <int R> __device__ inline void lr_box_raw(LrLds &L, const LrChunk &c, LrRaw<R> &raw) {
+#pragma unroll
+  for (int k = 0; k < LrRaw<R>::NP; k++) {
+    int pi, pj; uint32_t a = 0, b = 0;
+    if (lr_pos<R>(c, k, &pi, &pj)) {
+      const int wy = pi + 2, wx = pj + 2;                      // window coordinates of (i, j)
+#pragma unroll
+      for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
+    }
+    raw.a[k] = a; raw.b[k] = b;
+  }
+}
+template <int R> __device__ inline void lr_box_map(LrLds &L, const LrChunk &c, const LrRaw<R> &raw, int sparam, int bd) {
+  constexpr int n = (2 * R + 1) * (2 * R + 1), one_by_n = ((1 << 12) + n / 2) / n;
+  const int s2 = 2 * (bd - 8), s1 = bd - 8;
+#pragma unroll
+  for (int k = 0; k < LrRaw<R>::NP; k++) {
+    int pi, pj;
+    if (lr_pos<R>(c, k, &pi, &pj)) {
+      const uint32_t a = raw.a[k], b = raw.b[k];
+      const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
+      const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
+      const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
+      const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
+      const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
+      L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
+    }
   }
   __syncthreads();
+}
+// raw + map fused (nothing kept between parameter sets): (A, B) of one (radius, s) straight into LDS
+template <int R> __device__ inline void lr_box_AB(LrLds &L, const LrChunk &c, int sparam, int bd) {
+  constexpr int n = (2 * R + 1) * (2 * R + 1), one_by_n = ((1 << 12) + n / 2) / n;
+  const int s2 = 2 * (bd - 8), s1 = bd - 8;
+#pragma unroll 2
+  for (int k = 0; k < LrRaw<R>::NP; k++) {
+    int pi, pj;
+    if (lr_pos<R>(c, k, &pi, &pj)) {
+      uint32_t a = 0, b = 0;
+      const int wy = pi + 2, wx = pj + 2;
+#pragma unroll
+      for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
+      const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
+      const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
+      const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
+      const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
+      const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
+      L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
+    }
+  }
+  __syncthreads();
+}
+__device__ inline void lr_box_F(LrLds &L, const LrChunk &c, int pass, int flt[16]) {
   const int npx = c.w * c.h;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -175,6 +228,88 @@ __device__ __forceinline__ int lr_chunks(const FrameDev *f, int ur, int uc, int 
   return n;
 }
 
+// One candidate of the search: (unit, plane, parameter set) -> least-squares weights, activity-scaled SSE, RD cost.
+// grid = (units, planes * nsets, frames).  Results go to f->lr_cand[(plane * units + unit) * 16 + set index].
+struct LrCand { long long cost; int xq0, xq1; };
+__global__ __launch_bounds__(256) void lr_search_kernel(const FrameDev *frames) {
+  const FrameDev *f = frames + blockIdx.z;
+  const int nsets = f->sgr_full ? 16 : 4;
+  const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;
+  if (plane >= f->np || !f->enable_restoration) return;
+  const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h);
+  const int ui = blockIdx.x;
+  if (ui >= ucols * urows) return;
+  const int ur = ui / ucols, uc = ui - ur * ucols;
+  __shared__ LrLds L;
+  L.a2tab[threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? 1 : ((threadIdx.x << 8) + threadIdx.x / 2) / (threadIdx.x + 1));
+  LrChunk ch[4];
+  const int nch = lr_chunks(f, ur, uc, ucols, urows, ch);
+  const int st = f->stride, bd = f->bd, mx = (1 << bd) - 1;
+  const uint16_t *src = f->src[plane];
+  const int reduced[4] = { 1, 3, 6, 11 };
+  const int set = f->sgr_full ? si : reduced[si & 3];
+  int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
+  __syncthreads();
+  int flt0[16], flt1[16];
+  long long acc[6];
+  int xq0 = 0, xq1 = 0;
+  // sweep 0: normal equations; sweep 1: SSE with the solved weights
+  for (int sweep = 0; sweep < 2; sweep++) {
+    for (int i = 0; i < 6; i++) acc[i] = 0;
+    for (int q = 0; q < nch; q++) {
+      const LrChunk c = ch[q];
+      if (sweep == 0 || nch > 1) {
+        lr_load_window(L, f, plane, c);
+        if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt0); }
+        if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt1); }
+      }
+      const int npx = c.w * c.h;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx < npx) {
+          const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+          const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
+          if (sweep == 0) {
+            const int u = cd << 4, e = (sv << 4) - u;
+            const int f0 = r0 ? flt0[k] - u : 0, f1 = r1 ? flt1[k] - u : 0;
+            acc[0] += (long long)(f0 * f0); acc[1] += (long long)(f1 * f1); acc[2] += (long long)(f0 * f1); acc[3] += (long long)(f0 * e); acc[4] += (long long)(f1 * e);
+          } else {
+            const int d = lr_project(cd, flt0[k], flt1[k], r0, r1, xq0, xq1, mx) - sv;
+            acc[5] += (long long)(d * d);
+          }
+        }
+      }
+      if (nch > 1) __syncthreads();                            // the window is re-staged for the next chunk
+    }
+    if (sweep == 0) {
+      lr_block_sum(L, acc, 5);
+      if (threadIdx.x == 0) { int a, b; lr_sgr_solve(L.tot[0], L.tot[1], L.tot[2], L.tot[3], L.tot[4], r0, r1, &a, &b); L.xq[0] = a; L.xq[1] = b; }
+      __syncthreads();
+      xq0 = L.xq[0]; xq1 = L.xq[1];
+    } else {
+      // the unit's mean activity scale (Q14) over the 8x8 cells it covers scales every distortion of the unit
+      const int ux0 = uc * 64, ux1 = uc == ucols - 1 ? f->w : ux0 + 64, uy0 = imax_(0, ur * 64 - 8), uy1 = ur == urows - 1 ? f->h : ur * 64 + 56;
+      const int cx0 = ux0 >> 3, cx1 = (ux1 - 1) >> 3, cy0 = uy0 >> 3, cy1 = (uy1 - 1) >> 3, ncx = cx1 - cx0 + 1, cnt = ncx * (cy1 - cy0 + 1);
+      long long a = 0;
+      for (int i = threadIdx.x; i < cnt; i += 256) a += f->act[(cy0 + i / ncx) * (f->pw >> 3) + cx0 + i % ncx];
+      acc[4] = a;
+      lr_block_sum(L, acc + 4, 2);                             // tot[0] = activity sum, tot[1] = SSE
+      if (threadIdx.x == 0) {
+        const long long unit_act = (L.tot[0] + cnt / 2) / cnt;
+        uint32_t rate = f->lr_cost[2] + 4 * 512, bits;
+        if (r0) rate += 512u * (uint32_t)lr_subexp_code(xq0, -96, 32, -32, &bits);
+        if (r1) rate += 512u * (uint32_t)lr_subexp_code(xq1, -32, 96, 31, &bits);
+        LrCand cnd;
+        cnd.cost = ((((L.tot[1] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)rate * f->rdmult + 256) >> 9);
+        cnd.xq0 = xq0; cnd.xq1 = xq1;
+        ((LrCand *)f->lr_cand)[(size_t)(plane * ucols * urows + ui) * 16 + si] = cnd;
+      }
+    }
+  }
+}
+
+// RD choice between RESTORE_NONE and the searched sets (first minimum in set order), then the winner is applied.
 // grid = (units, planes, frames)
 __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
   const FrameDev *f = frames + blockIdx.z;
@@ -193,96 +328,63 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
   uint16_t *out = f->lrp[plane];
   __syncthreads();
   // RESTORE_NONE
-  long long acc[6];
+  long long acc[2];
   {
     int s = 0;
     for (int q = 0; q < nch; q++) {
-      const LrChunk &c = ch[q];
+      const LrChunk c = ch[q];
       for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) {
         const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
         const int d = (int)cdef[o] - (int)src[o]; s += d * d;
       }
     }
     acc[0] = s;
-    // the unit's mean activity scale (Q14) over the 8x8 cells it covers: every distortion of the unit is scaled by it
     const int ux0 = uc * 64, ux1 = uc == ucols - 1 ? f->w : ux0 + 64, uy0 = imax_(0, ur * 64 - 8), uy1 = ur == urows - 1 ? f->h : ur * 64 + 56;
     const int cx0 = ux0 >> 3, cx1 = (ux1 - 1) >> 3, cy0 = uy0 >> 3, cy1 = (uy1 - 1) >> 3, ncx = cx1 - cx0 + 1, cnt = ncx * (cy1 - cy0 + 1);
     long long a = 0;
     for (int i = threadIdx.x; i < cnt; i += 256) a += f->act[(cy0 + i / ncx) * (f->pw >> 3) + cx0 + i % ncx];
     acc[1] = a;
     lr_block_sum(L, acc, 2);
-    if (threadIdx.x == 0) L.xq[0] = (int)((L.tot[1] + cnt / 2) / cnt);
+    if (threadIdx.x == 0) {
+      const long long unit_act = (L.tot[1] + cnt / 2) / cnt;
+      long long best_cost = ((((L.tot[0] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)f->lr_cost[0] * f->rdmult + 256) >> 9);
+      int best_type = 0, best_set = 0, bx0 = 0, bx1 = 0;
+      const int nsets = f->sgr_full ? 16 : 4;
+      const int reduced[4] = { 1, 3, 6, 11 };
+      const LrCand *cn = (const LrCand *)f->lr_cand + (size_t)(plane * ucols * urows + ui) * 16;
+      for (int si = 0; si < nsets; si++) if (cn[si].cost < best_cost) { best_cost = cn[si].cost; best_type = 1; best_set = f->sgr_full ? si : reduced[si]; bx0 = cn[si].xq0; bx1 = cn[si].xq1; }
+      const int n = ucols * urows;
+      f->lr_type[plane * n + ui] = (uint8_t)best_type; f->lr_set[plane * n + ui] = (uint8_t)best_set;
+      f->lr_xqd[(plane * n + ui) * 2] = (int8_t)bx0; f->lr_xqd[(plane * n + ui) * 2 + 1] = (int8_t)bx1;
+      L.xq[0] = bx0; L.xq[1] = bx1; L.red[0][0] = best_type; L.red[0][1] = best_set;
+    }
     __syncthreads();
   }
-  const long long unit_act = L.xq[0];
-  long long best_cost = ((((L.tot[0] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)f->lr_cost[0] * f->rdmult + 256) >> 9);
+  const int best_type = (int)L.red[0][0], best_set = (int)L.red[0][1], xq0 = L.xq[0], xq1 = L.xq[1];
   __syncthreads();
-  int best_type = 0, best_set = 0, best_x0 = 0, best_x1 = 0;
-  const int nsets = f->sgr_full ? 16 : 4;
-  int flt0[16], flt1[16];
-  for (int si = 0; si <= nsets; si++) {
-    const bool apply = si == nsets;                            // last round: apply the winner
-    if (apply && !best_type) break;
-    const int reduced[4] = { 1, 3, 6, 11 };
-    const int set = apply ? best_set : (f->sgr_full ? si : reduced[si & 3]);
-    int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
-    int xq0 = best_x0, xq1 = best_x1;
-    // sweep 0: normal equations; sweep 1: SSE with the solved weights (search) / output (apply)
-    for (int sweep = apply ? 1 : 0; sweep < 2; sweep++) {
-      for (int i = 0; i < 6; i++) acc[i] = 0;
-      for (int q = 0; q < nch; q++) {
-        const LrChunk &c = ch[q];
-        if (sweep == 0 || nch > 1 || apply) {
-          lr_load_window(L, f, plane, c);
-          if (r0) lr_box_filter(L, c, r0, s0, 0, bd, flt0);
-          if (r1) lr_box_filter(L, c, r1, s1, 1, bd, flt1);
-        }
-        const int npx = c.w * c.h;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int idx = threadIdx.x + 256 * k;
-          if (idx < npx) {
-            const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
-            const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
-            if (sweep == 0) {
-              const int u = cd << 4, e = (sv << 4) - u;
-              const int f0 = r0 ? flt0[k] - u : 0, f1 = r1 ? flt1[k] - u : 0;
-              acc[0] += (long long)(f0 * f0); acc[1] += (long long)(f1 * f1); acc[2] += (long long)(f0 * f1); acc[3] += (long long)(f0 * e); acc[4] += (long long)(f1 * e);
-            } else {
-              const int v = lr_project(cd, flt0[k], flt1[k], r0, r1, xq0, xq1, mx);
-              if (apply) out[o] = (uint16_t)v;
-              else { const int d = v - sv; acc[5] += (long long)(d * d); }
-            }
-          }
-        }
-        if (nch > 1) __syncthreads();                          // the window is re-staged for the next chunk
-      }
-      if (apply) break;
-      if (sweep == 0) {
-        lr_block_sum(L, acc, 5);
-        if (threadIdx.x == 0) { int a, b; lr_sgr_solve(L.tot[0], L.tot[1], L.tot[2], L.tot[3], L.tot[4], r0, r1, &a, &b); L.xq[0] = a; L.xq[1] = b; }
-        __syncthreads();
-        xq0 = L.xq[0]; xq1 = L.xq[1];
-      } else {
-        lr_block_sum(L, acc + 5, 1);
-        uint32_t rate = f->lr_cost[2] + 4 * 512, bits;
-        if (r0) rate += 512u * (uint32_t)lr_subexp_code(xq0, -96, 32, -32, &bits);
-        if (r1) rate += 512u * (uint32_t)lr_subexp_code(xq1, -32, 96, 31, &bits);
-        const long long cost = ((((L.tot[0] * unit_act + 8192) >> 14) * f->wq[plane]) >> 5) + (((long long)rate * f->rdmult + 256) >> 9);
-        if (cost < best_cost) { best_cost = cost; best_type = 1; best_set = set; best_x0 = xq0; best_x1 = xq1; }
-        __syncthreads();
-      }
-    }
-  }
   if (!best_type) {
     for (int q = 0; q < nch; q++) {
-      const LrChunk &c = ch[q];
+      const LrChunk c = ch[q];
       for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) { const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px; out[o] = cdef[o]; }
     }
+    return;
   }
-  if (threadIdx.x == 0) {
-    const int n = ucols * urows;
-    f->lr_type[plane * n + ui] = (uint8_t)best_type; f->lr_set[plane * n + ui] = (uint8_t)best_set;
-    f->lr_xqd[(plane * n + ui) * 2] = (int8_t)best_x0; f->lr_xqd[(plane * n + ui) * 2 + 1] = (int8_t)best_x1;
+  int r0, s0, r1, s1; sgr_param(best_set, &r0, &s0, &r1, &s1);
+  int flt0[16], flt1[16];
+  for (int q = 0; q < nch; q++) {
+    const LrChunk c = ch[q];
+    lr_load_window(L, f, plane, c);
+    if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt0); }
+    if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt1); }
+    const int npx = c.w * c.h;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int idx = threadIdx.x + 256 * k;
+      if (idx < npx) {
+        const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+        out[o] = (uint16_t)lr_project(L.win[(py + 3) * LR_WP + px + 3], flt0[k], flt1[k], r0, r1, xq0, xq1, mx);
+      }
+    }
+    if (nch > 1) __syncthreads();
   }
 }

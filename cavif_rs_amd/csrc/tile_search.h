@@ -372,7 +372,10 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
-  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx;        // one-level-smaller luma transforms are tried after the mode decision
+#ifndef TRIALDBG
+#define TRIALDBG 0
+#endif
+  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx && !(TRIALDBG == 1 && BS == 1) && !(TRIALDBG == 2 && BS == 2) && TRIALDBG != 3;        // one-level-smaller luma transforms are tried after the mode decision
   LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;
   LDS uint16_t *split_rec = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->split_rec;
   LDS uint16_t *spred = SH->spred;
@@ -542,6 +545,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int sflag = SH->sflag;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
+        // costs only grow: once the split can neither beat the undivided transform nor stay below the caller's budget
+        // (then the undivided transform is above the budget too and the caller discards this block) the rest is skipped
+        if (j_split >= budget && luma_j >= budget) return luma_j;   // wave-uniform
         if (!(j_split < luma_j)) break;
         const int sx = x + (q & 1) * hn, sy = y + (q >> 1) * hn;
         const int sU = availU || (q >> 1), sL = availL || (q & 1);

@@ -285,16 +285,23 @@ void av1o_setup_tiles(Av1oFrame *f) {
  *  Integer restatement (Q14), bit-identical on CPU and GPU:
  *    boost(sv, dv) = 4033/16384 * (sv + dv + 16384) / sqrt(4033^2 + sv * dv)      variances = 64 x per-sample variance, 8-bit scale
  *  4x4 blocks use their own 16-sample variance scaled to the 8x8 equivalent. */
-static uint64_t isqrt64(uint64_t n) {
-  uint64_t x = (uint64_t)sqrt((double)n);
-  while (x * x > n) x--;
-  while ((x + 1) * (x + 1) <= n) x++;
+/* floor(sqrt(n)), n < 2^46: a float guess made exact by integer correction (the same two steps run on the GPU, so the result
+ * does not depend on how either side rounds its floating point) */
+static uint32_t isqrt46(uint64_t n) {
+  uint32_t x = (uint32_t)sqrtf((float)n);
+  while ((uint64_t)x * x > n) x--;
+  while ((uint64_t)(x + 1) * (x + 1) <= n) x++;
   return x;
 }
 uint32_t av1o_psy_boost_q14(uint32_t svar, uint32_t dvar) {
+  /* Q14: 16384 * (4033 / 16384) * (sv + dv + 16384) / sqrt(4033^2 + sv * dv) = 4033 * (sv + dv + 16384) / sqrt(...) */
   const uint64_t num = 4033ull * ((uint64_t)svar + dvar + 16384);
-  const uint64_t den = isqrt64((16265089ull + (uint64_t)svar * dvar) << 16);     /* sqrt in Q8 */
-  return (uint32_t)(((num << 8) + den / 2) / den);
+  const uint32_t den = isqrt46(16265089ull + (uint64_t)svar * dvar);
+  const uint64_t t = num + den / 2;
+  uint32_t q = (uint32_t)((float)t / (float)den);              /* guess, then exact */
+  while ((uint64_t)q * den > t) q--;
+  while ((uint64_t)(q + 1) * den <= t) q++;
+  return q;
 }
 /* variance of a w x w cell (w = 8 or 4) as 64 x per-sample variance on the 8-bit scale */
 uint32_t av1o_cell_var(int64_t sum, int64_t sum2, int w, int bd) {

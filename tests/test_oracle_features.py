@@ -94,7 +94,7 @@ def test_psy_boost_known_answers(oracle):
     assert L.av1o_psy_boost_q14(0, 0) == 16384                       # flat source and reconstruction: no boost
     for sv, dv in ((4033, 4033), (100000, 100000), (4161600, 4161600), (0, 500000), (1234, 987654)):
         want = 16384.0 * (4033.0 / 16384.0) * (sv + dv + 16384.0) / np.sqrt(16265089.0 + float(sv) * dv)
-        assert abs(L.av1o_psy_boost_q14(sv, dv) - want) <= 1.0
+        assert abs(L.av1o_psy_boost_q14(sv, dv) - want) <= 1.0 + want / 2000.0          # the root is an integer floor (>= 4033)
     assert L.av1o_psy_boost_q14(4161600, 4161600) < 16384 * 0.5     # busy cells are discounted towards (x/2)^(-1/3)-like 0.49
 
 
