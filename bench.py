@@ -137,10 +137,10 @@ def end_to_end(n_files, w, h, speed, quality, depth):
         files = sorted(os.path.join(d, 'in', f) for f in os.listdir(os.path.join(d, 'in')))
         cmd = [cli, '-s', str(speed), '-Q', '%g' % quality, '--depth', str(depth), '-f', '-q', '-o', os.path.join(d, 'out')] + files
         t = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True)
+        r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, CAVIF_MI_TIMING='1'))
         dt = time.perf_counter() - t
         n_out = len(os.listdir(os.path.join(d, 'out')))
-    return {"files": n_files, "ok": r.returncode == 0 and n_out == n_files, "seconds": round(dt, 3), "MPix_per_s": round(n_files * w * h / 1e6 / dt, 2),
+    return {"files": n_files, "ok": r.returncode == 0 and n_out == n_files, "phases": [l for l in r.stderr.decode().splitlines() if l.startswith('[timing]')], "seconds": round(dt, 3), "MPix_per_s": round(n_files * w * h / 1e6 / dt, 2),
             "what": "cavif_mi -s%d -Q%g --depth %d -o out/ in/*.png: PNG decode on the host cores + RGBA8 upload + encode + file writes, process start included" % (speed, quality, depth)}
 
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,7 +50,10 @@ int usage(const char *msg) {
 
 }  // namespace
 
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
+  const double t_start = now_s(); const bool timing = getenv("CAVIF_MI_TIMING") != nullptr;
   float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0;
   bool overwrite = false, quiet = false, dirty_alpha = false, have_output = false, output_stdio = false;
   std::string output; std::vector<std::string> images; std::vector<int> devices;
@@ -137,26 +142,37 @@ int main(int argc, char **argv) {
     else j.out_path = use_dir ? output + "/" + with_extension_avif(file_name(in.path)) : output;
     if (j.error.empty() && !j.out_stdio && !overwrite && exists(j.out_path)) j.error = j.out_path + " already exists; skipping";
   };
-  {
-    const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(threads > 0 ? (unsigned)threads : 64u, std::thread::hardware_concurrency())));
-    std::atomic<size_t> next{ 0 };
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < nw; t++) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < files.size();) load(i); });
-    for (auto &t : pool) t.join();
-  }
-  // encode everything that is still alive, across the selected devices
-  std::vector<mi_image_desc> desc; std::vector<size_t> who;
-  for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].error.empty()) { mi_image_desc d; d.pixels = jobs[i].rgba; d.width = jobs[i].w; d.height = jobs[i].h; d.stride_px = jobs[i].w; d.channels = 4; desc.push_back(d); who.push_back(i); }
-  std::vector<mi_encoded_image> enc_out(desc.size()); std::vector<int> status(desc.size(), MI_OK);
-  if (!desc.empty()) {
-    const int rc = mi_ravif_encode_batch(&enc, desc.size(), desc.data(), enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
-    if (rc == MI_NO_DEVICE) for (int &s : status) s = MI_NO_DEVICE;
-  }
+  // loaders (host cores) and the encoder (GPUs) run concurrently: the encoder pulls image i through fetch(), which waits for
+  // loader i -- the reference gets the same overlap from rayon's work stealing over process() (src/main.rs:179-223)
+  std::mutex mu; std::condition_variable cv; std::vector<char> loaded(files.size(), 0);
+  const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(threads > 0 ? (unsigned)threads : 64u, std::thread::hardware_concurrency())));
+  std::atomic<size_t> next{ 0 };
+  std::vector<std::thread> pool;
+  for (size_t t = 0; t < nw; t++) pool.emplace_back([&] {
+    for (size_t i; (i = next.fetch_add(1)) < files.size();) { load(i); { std::lock_guard<std::mutex> lk(mu); loaded[i] = 1; } cv.notify_all(); }
+  });
+  struct Ctx { std::vector<Job> *jobs; std::mutex *mu; std::condition_variable *cv; std::vector<char> *loaded; } ctx{ &jobs, &mu, &cv, &loaded };
+  auto fetch = [](void *user, size_t i, mi_image_desc *d) -> int {
+    Ctx *c = (Ctx *)user;
+    { std::unique_lock<std::mutex> lk(*c->mu); c->cv->wait(lk, [&] { return (*c->loaded)[i] != 0; }); }
+    const Job &j = (*c->jobs)[i];
+    if (!j.error.empty()) return MI_INVALID_ARGUMENT;           // reported from the job's own message below
+    d->pixels = j.rgba; d->width = j.w; d->height = j.h; d->stride_px = j.w; d->channels = 4;
+    return MI_OK;
+  };
+  std::vector<mi_encoded_image> enc_out(jobs.size()); std::vector<int> status(jobs.size(), MI_OK);
+  if (timing) { fprintf(stderr, "[timing] setup %.3f s\n", now_s() - t_start); mi_device_count(); fprintf(stderr, "[timing] HIP runtime up %.3f s\n", now_s() - t_start); }
+  const int rc_all = mi_ravif_encode_stream(&enc, jobs.size(), fetch, &ctx, enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
+  for (auto &t : pool) t.join();
+  if (timing) fprintf(stderr, "[timing] encoded %.3f s\n", now_s() - t_start);
+  if (rc_all == MI_NO_DEVICE) for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].error.empty()) status[i] = MI_NO_DEVICE;
+  std::vector<size_t> who;
+  for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].error.empty()) who.push_back(i);
   for (size_t k = 0; k < who.size(); k++) {
-    Job &j = jobs[who[k]]; const mi_encoded_image &im = enc_out[k];
-    if (status[k] != MI_OK) {
+    Job &j = jobs[who[k]]; const mi_encoded_image &im = enc_out[who[k]];
+    if (status[who[k]] != MI_OK) {
       static const char *names[] = { "ok", "TooFewPixels", "Unsupported", "EncodingError", "invalid argument", "no HIP device (this encoder has no CPU fallback)" };
-      j.error = names[status[k] >= 0 && status[k] <= 5 ? status[k] : 3];
+      j.error = names[status[who[k]] >= 0 && status[who[k]] <= 5 ? status[who[k]] : 3];
       continue;
     }
     if (j.out_stdio) { if (fwrite(im.avif_file, 1, im.avif_len, stdout) != im.avif_len) j.error = "Unable to write output image: stdout"; }
@@ -169,6 +185,7 @@ int main(int argc, char **argv) {
     }
     mi_free(im.avif_file);
   }
+  if (timing) fprintf(stderr, "[timing] written %.3f s\n", now_s() - t_start);
   int failures = 0;
   for (Job &j : jobs) {
     if (j.rgba) mi_free(j.rgba);

@@ -604,8 +604,11 @@ int mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_t
 // The reference's files.into_par_iter() (src/main.rs:223) over the GPUs of one node: images are independent, so a host
 // thread per device pulls runs of equally-shaped images from a shared cursor and pushes each run through one resident
 // batch (no collective, no cross-device traffic).  status[i] receives the per-image result; returns the first failure.
-int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev) {
-  if (!e || (n && (!in || !out))) return MI_INVALID_ARGUMENT;
+// Streaming form of the fan-out: image i is obtained through `fetch(user, i, &desc)` when a worker is about to stage it (the
+// call may block until the pixels exist -- e.g. until a loader thread has decoded the file), so loading, upload, encoding and
+// assembly of consecutive runs overlap.  fetch returns MI_OK or a status that becomes the image's status.
+int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev) {
+  if (!e || !fetch || (n && !out)) return MI_INVALID_ARGUMENT;
   const int have = mi_device_count();
   std::vector<int> devs;
   if (devices && ndev > 0) devs.assign(devices, devices + ndev); else for (int d = 0; d < have; d++) devs.push_back(d);
@@ -620,51 +623,59 @@ int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_de
   // entropy coding and the host-side assembly of consecutive runs overlap (the same rotation bench.py drives).
   auto worker = [&](int dev) {
     mi_ravif_encoder enc = *e; enc.device = dev;
-    struct Slot { mi_batch *b = nullptr; size_t i0 = 0, i1 = 0; bool busy = false; };
+    struct Slot { mi_batch *b = nullptr; std::vector<size_t> idx; bool busy = false; };
     struct Shape { uint32_t w, h; int ch; Slot slot[2]; int next = 0; };
-    std::vector<Shape> shapes;
+    std::vector<std::unique_ptr<Shape>> shapes;
     auto collect = [&](Slot &sl) {
       if (!sl.busy) return;
       const int rc = mi_batch_wait(sl.b);
-      for (size_t i = sl.i0; i < sl.i1; i++) st[i] = rc == MI_OK ? mi_batch_get(sl.b, (int)(i - sl.i0), &out[i]) : rc;
+      for (size_t k = 0; k < sl.idx.size(); k++) st[sl.idx[k]] = rc == MI_OK ? mi_batch_get(sl.b, (int)k, &out[sl.idx[k]]) : rc;
       sl.busy = false;
     };
     for (;;) {
-      // claim a run [i0, i1) of images with the same shape
-      size_t i0 = cursor.load(), i1;
-      bool done = false;
-      do {
-        if (i0 >= n) { done = true; break; }
-        i1 = i0 + 1;
-        while (i1 < n && i1 - i0 < max_run && in[i1].width == in[i0].width && in[i1].height == in[i0].height && in[i1].channels == in[i0].channels) i1++;
-      } while (!cursor.compare_exchange_weak(i0, i1));
-      if (done) break;
-      const mi_image_desc &d0 = in[i0];
-      bool ok = d0.pixels && d0.width && d0.height && (d0.channels == 3 || d0.channels == 4);
-      for (size_t i = i0; i < i1 && ok; i++) ok = in[i].pixels != nullptr;
-      if (!ok) { for (size_t i = i0; i < i1; i++) st[i] = MI_INVALID_ARGUMENT; continue; }
-      Shape *sh = nullptr;
-      for (Shape &c : shapes) if (c.w == d0.width && c.h == d0.height && c.ch == d0.channels) sh = &c;
-      if (!sh) { shapes.push_back(Shape{ d0.width, d0.height, d0.channels, {}, 0 }); sh = &shapes.back(); }
-      Slot &sl = sh->slot[sh->next]; sh->next ^= 1;
-      collect(sl);                                           // the slot's previous run, if any
-      if (!sl.b) sl.b = mi_batch_create(&enc, (int)max_run, d0.width, d0.height, d0.channels);
-      int rc = sl.b ? mi_batch_set_count(sl.b, (int)(i1 - i0)) : MI_ENCODING_ERROR;
-      if (rc == MI_OK) {
-        const size_t row = (size_t)d0.width * d0.channels;
-        for (size_t i = i0; i < i1; i++) {
-          uint8_t *dst = mi_batch_input(sl.b, (int)(i - i0));
-          const size_t sp = in[i].stride_px ? in[i].stride_px : in[i].width;
-          if (sp == in[i].width) memcpy(dst, in[i].pixels, row * d0.height);
-          else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, in[i].pixels + (size_t)y * sp * d0.channels, row);
-        }
-        rc = mi_batch_upload_async(sl.b, 0, (int)(i1 - i0));
+      const size_t i0 = cursor.fetch_add(max_run);             // claim the index range [i0, i1)
+      if (i0 >= n) break;
+      const size_t i1 = std::min(n, i0 + max_run);
+      std::vector<mi_image_desc> d(i1 - i0);
+      std::vector<char> pending(i1 - i0, 0);
+      for (size_t i = i0; i < i1; i++) {
+        const int rc = fetch(user, i, &d[i - i0]);
+        const mi_image_desc &x = d[i - i0];
+        if (rc != MI_OK) st[i] = rc;
+        else if (!x.pixels || !x.width || !x.height || (x.channels != 3 && x.channels != 4)) st[i] = MI_INVALID_ARGUMENT;
+        else pending[i - i0] = 1;
       }
-      if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
-      if (rc != MI_OK) { for (size_t i = i0; i < i1; i++) st[i] = rc; continue; }
-      sl.i0 = i0; sl.i1 = i1; sl.busy = true;
+      // sub-runs of equal shape inside the range
+      for (size_t a = 0; a < d.size(); a++) {
+        if (!pending[a]) continue;
+        std::vector<size_t> run;
+        for (size_t k = a; k < d.size(); k++) if (pending[k] && d[k].width == d[a].width && d[k].height == d[a].height && d[k].channels == d[a].channels) { run.push_back(k); pending[k] = 0; }
+        const mi_image_desc &d0 = d[a];
+        Shape *sh = nullptr;
+        for (auto &c : shapes) if (c->w == d0.width && c->h == d0.height && c->ch == d0.channels) sh = c.get();
+        if (!sh) { shapes.emplace_back(new Shape{ d0.width, d0.height, d0.channels, {}, 0 }); sh = shapes.back().get(); }
+        Slot &sl = sh->slot[sh->next]; sh->next ^= 1;
+        collect(sl);                                           // the slot's previous run, if any
+        if (!sl.b) sl.b = mi_batch_create(&enc, (int)max_run, d0.width, d0.height, d0.channels);
+        int rc = sl.b ? mi_batch_set_count(sl.b, (int)run.size()) : MI_ENCODING_ERROR;
+        if (rc == MI_OK) {
+          const size_t row = (size_t)d0.width * d0.channels;
+          for (size_t k = 0; k < run.size(); k++) {
+            const mi_image_desc &x = d[run[k]];
+            uint8_t *dst = mi_batch_input(sl.b, (int)k);
+            const size_t sp = x.stride_px ? x.stride_px : x.width;
+            if (sp == x.width) memcpy(dst, x.pixels, row * d0.height);
+            else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, x.pixels + (size_t)y * sp * d0.channels, row);
+          }
+          rc = mi_batch_upload_async(sl.b, 0, (int)run.size());
+        }
+        if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
+        if (rc != MI_OK) { for (size_t k : run) st[i0 + k] = rc; continue; }
+        sl.idx.clear(); for (size_t k : run) sl.idx.push_back(i0 + k);
+        sl.busy = true;
+      }
     }
-    for (Shape &c : shapes) for (Slot &sl : c.slot) { collect(sl); if (sl.b) mi_batch_destroy(sl.b); }
+    for (auto &c : shapes) for (Slot &sl : c->slot) { collect(sl); if (sl.b) mi_batch_destroy(sl.b); }
   };
   std::vector<std::thread> th;
   for (int d : devs) th.emplace_back(worker, d);
@@ -672,6 +683,12 @@ int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_de
   int first = MI_OK;
   for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (first == MI_OK && st[i] != MI_OK) first = st[i]; }
   return first;
+}
+// The reference's files.into_par_iter() (src/main.rs:223) over the GPUs of one node with every image already in host memory.
+static int fetch_from_array(void *user, size_t i, mi_image_desc *d) { *d = ((const mi_image_desc *)user)[i]; return MI_OK; }
+int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev) {
+  if (!e || (n && (!in || !out))) return MI_INVALID_ARGUMENT;
+  return mi_ravif_encode_stream(e, n, fetch_from_array, (void *)in, out, status, devices, ndev);
 }
 int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgb, 3, w, h, stride_px, out); }
 

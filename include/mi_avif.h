@@ -86,6 +86,11 @@ int  mi_ravif_encode_raw_planes_10(const mi_ravif_encoder *e, uint32_t w, uint32
  * the return value is the first failure.  out[i].avif_file is malloc'd (mi_free). */
 typedef struct mi_image_desc { const uint8_t *pixels; uint32_t width, height; size_t stride_px /* 0 = width */; int channels /* 3 RGB8 | 4 RGBA8 */; } mi_image_desc;
 int  mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev);
+/* streaming form: image i is pulled through `fetch` right before it is staged (the callback may block until a loader has produced
+ * the pixels; they must stay valid until the call returns), so file loading overlaps the GPU work -- what rayon's work stealing gives
+ * the reference when load and encode sit in one par_iter body (src/main.rs:179-223).  fetch returns MI_OK or the image's status. */
+typedef int (*mi_fetch_fn)(void *user, size_t index, mi_image_desc *desc);
+int  mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev);
 
 /* PNG -> RGBA8 as cavif's load_rgba does (src/main.rs:265-283: RGB gets alpha 255, 16-bit samples keep their high byte, gray is
  * replicated); all colour types, bit depths, tRNS and Adam7.  Host code over zlib.  *rgba is malloc'd (mi_free), w*h*4 bytes. */
