@@ -269,7 +269,7 @@ __device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int
 // grid.x = sb index, grid.y = frame; 256 threads = 4 waves, wave w handles 8x8 blocks w, w+4, ...
 // Every strength index >= 1 of the fixed list has a non-zero primary strength, so the filter direction of a block is
 // its luma direction for all candidates and the 12 tap samples per pixel and plane are loaded once.
-__global__ __launch_bounds__(256) void cdef_kernel(const FrameDev *frames, int write_final) {
+__global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *frames, int write_final) {
   const FrameDev *f = frames + blockIdx.y;
   const int sbi = blockIdx.x;
   if (sbi >= f->sb_rows * f->sb_cols) return;

@@ -92,7 +92,7 @@ __device__ inline void lr_load_window(LrLds &L, const FrameDev *f, int plane, co
   const uint16_t *cdef = f->fin[plane], *dbk = f->rec[plane];
   const int ww = c.w + 6, wh = c.h + 6;
   for (int i = threadIdx.x; i < ww * wh; i += 256) {
-    const int wy = i / ww, wx = i - wy * ww;
+    const int wy = ww == 70 ? i / 70 : i / ww, wx = i - wy * ww;
     const int x = iclamp_(c.x0 - 3 + wx, 0, ex); int y = iclamp_(c.y0 - 3 + wy, 0, ey);
     int v;
     if (y < c.stripe_start) { y = imax_(c.stripe_start - 2, y); v = dbk[(size_t)y * st + x]; }
@@ -113,7 +113,7 @@ template <int R> __device__ __forceinline__ bool lr_pos(const LrChunk &c, int k,
   const int nrows = R == 2 ? (ah - (c.y0 & 1) + 1) >> 1 : ah;
   const int pos = threadIdx.x + 256 * k;
   if (pos >= nrows * aw) return false;
-  const int row = pos / aw;
+  const int row = c.w == 64 ? pos / 66 : pos / aw;             // the usual chunk is 64 wide: division by a constant
   *pj = pos - row * aw; *pi = R == 2 ? (c.y0 & 1) + 2 * row : row;           // pi = i + 1, pj = j + 1
   return true;
 }
@@ -180,7 +180,7 @@ __device__ inline void lr_box_F(LrLds &L, const LrChunk &c, int pass, int flt[16
     const int idx = threadIdx.x + 256 * k;
     int out = 0;
     if (idx < npx) {
-      const int py = idx / c.w, px = idx - py * c.w, yabs = c.y0 + py;
+      const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w, yabs = c.y0 + py;
       const int o = (py + 1) * LR_AP + px + 1;
       int a, b, shift;
       if (pass == 0) {
@@ -231,7 +231,10 @@ __device__ __forceinline__ int lr_chunks(const FrameDev *f, int ur, int uc, int 
 // One candidate of the search: (unit, plane, parameter set) -> least-squares weights, activity-scaled SSE, RD cost.
 // grid = (units, planes * nsets, frames).  Results go to f->lr_cand[(plane * units + unit) * 16 + set index].
 struct LrCand { long long cost; int xq0, xq1; };
-__global__ __launch_bounds__(256) void lr_search_kernel(const FrameDev *frames) {
+#ifndef LR_WG_PER_CU
+#define LR_WG_PER_CU 4
+#endif
+__global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const FrameDev *frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int nsets = f->sgr_full ? 16 : 4;
   const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void lr_search_kernel(const FrameDev *frames) 
       for (int k = 0; k < 16; k++) {
         const int idx = threadIdx.x + 256 * k;
         if (idx < npx) {
-          const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+          const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
           const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
           if (sweep == 0) {
             const int u = cd << 4, e = (sv << 4) - u;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
     for (int q = 0; q < nch; q++) {
       const LrChunk c = ch[q];
       for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) {
-        const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+        const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
         const int d = (int)cdef[o] - (int)src[o]; s += d * d;
       }
     }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
   if (!best_type) {
     for (int q = 0; q < nch; q++) {
       const LrChunk c = ch[q];
-      for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) { const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px; out[o] = cdef[o]; }
+      for (int idx = threadIdx.x; idx < c.w * c.h; idx += 256) { const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px; out[o] = cdef[o]; }
     }
     return;
   }
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
     for (int k = 0; k < 16; k++) {
       const int idx = threadIdx.x + 256 * k;
       if (idx < npx) {
-        const int py = idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+        const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
         out[o] = (uint16_t)lr_project(L.win[(py + 3) * LR_WP + px + 3], flt0[k], flt1[k], r0, r1, xq0, xq1, mx);
       }
     }

@@ -12,6 +12,8 @@
  * structure as recalled and are documented in DESIGN.md.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this directory.
+ * NOT RE-ENTRANT: the search keeps its block scratch in function-local statics (av1o_search.c try_block / eval_tx, av1o_entropy.c);
+ * one encode at a time per process (the tests and bench.py fan out over processes, never threads).
  */
 #ifndef ORACLE_AV1O_H
 #define ORACLE_AV1O_H
