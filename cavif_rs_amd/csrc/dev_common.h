@@ -36,7 +36,7 @@ struct FrameDev {
   uint32_t dc_recip[3], ac_recip[3];          // floor((2^32 - 1) / q): quantisation divides by multiply-high + one fix-up
   long long rdmult, wq[3];
   // tools
-  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, tx_mode_select;
+  int part_min, part_max, complex_modes, fine_directional, rdo_tx, reduced_tx_set, tx_mode_select, bottomup;
   int tile_cols;
   // Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent)
   const uint32_t *act, *svar8, *svar4; int tune_psnr;

@@ -111,7 +111,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     d.lr_type = take(nlr); d.lr_set = take(nlr); d.lr_xqd = (int8_t *)take(nlr * 2);
     d.lr_cand = p.cfg.lrf ? take(nlr * 16 * sizeof(LrCand)) : nullptr;
   }
-  d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES(4 << p.maxbs));
+  d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES_ALL(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
@@ -136,6 +136,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
   for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
+  d.bottomup = c.encode_bottomup;
   d.tx_mode_select = c.rdo_tx_decision || c.inter_tx_split;    // rav1e FrameInvariants.tx_mode_select (recall)
   d.rdo_tx = c.rdo_tx_decision; d.reduced_tx_set = c.reduced_tx_set; d.enable_cdef = c.cdef; d.fast_deblock = c.fast_deblock;
   d.enable_restoration = c.lrf; d.sgr_full = c.sgr_full; d.tune_psnr = c.tune_psnr;
@@ -162,11 +163,11 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
-template <int MAXBS, int NW> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
   const size_t lds = k1_lds_bytes<MAXBS, NW>();
-  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW>), dim3(njobs), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs);
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(njobs), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs);
   return hipGetLastError();
 }
 // jobs must all belong to frames of the same block-size class
@@ -177,13 +178,21 @@ static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const Tile
   else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(64), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
   return hipGetLastError();
 }
-static hipError_t launch_search(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+// every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch
+static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  if (maxbs <= 2) return launch_search_t<2, 4>(d_frames, d_jobs, njobs, s);
-  if (maxbs == 3) return launch_search_t<3, 4>(d_frames, d_jobs, njobs, s);
-  return launch_search_t<4, 1>(d_frames, d_jobs, njobs, s);     // 64x64 blocks: alpha (4:0:0) frames only
+  if (bottomup) {
+    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, njobs, s);
+    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, njobs, s);
+    return launch_search_t<4, 1, true>(d_frames, d_jobs, njobs, s);
+  }
+  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, njobs, s);
+  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, njobs, s);
+  return launch_search_t<4, 1, false>(d_frames, d_jobs, njobs, s);     // 64x64 blocks: alpha (4:0:0) frames only
 }
 
+}  // namespace mi
+namespace mi {
 // The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
 // points: K2a deblock level search -> level pick -> K2 deblock (vertical, horizontal edges) -> K3 CDEF.
 static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, int max_lr_units, int max_lr_sets, hipStream_t s, hipEvent_t ev_cdef) {
@@ -474,7 +483,7 @@ int mi_batch_encode_async(mi_batch *b) {
   { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
     hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
   HIP_OK(hipEventRecord(b->ev[1], s));
-  for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
+  for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
   HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
@@ -734,7 +743,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
   hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
-  HIP_OK(launch_search(p.maxbs, d_frame, d_jobs, njobs, s));
+  HIP_OK(launch_search(p.maxbs, p.cfg.encode_bottomup != 0, d_frame, d_jobs, njobs, s));
   HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   HIP_OK(hipGetLastError());

@@ -1095,12 +1095,61 @@ template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
   }
 };
 
+// encode_partition_bottomup (SpeedTweaks.encode_bottomup, speed <= 2, ravif av1encoder.rs:575; oracle rd_partition_bottomup): every
+// child is searched recursively first, the undivided block competes with the children's own best partitions.  One snapshot
+// per level (the levels are live at the same time); returns the node's RD cost including its partition symbol.
+template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(int bs, int maxbs) {
+  size_t o = 0;
+  for (int b = maxbs; b > bs; b--) o += MI_SNAP_BYTES(4 << b);
+  return o;
+}
+#define MI_SNAP_BYTES_ALL(n) (2 * MI_SNAP_BYTES(n))           /* sum over the levels < 4/3 of the largest */
+template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
+  static __device__ MI_K1_INLINE long long run(Ctx<MAXN> &k, int r, int c) {
+    const LDS FrameDev *f = k.f;
+    if (r >= f->mi_rows || c >= f->mi_cols) return 0;
+    constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
+    const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
+    const int must_split = px > f->part_max || !has_rows || !has_cols;
+    const int can_split = px > f->part_min || must_split;
+    set_decoded_wg<NW>(f, r, c, n4, 0);
+    long long j_none = J_INF;
+    if constexpr (BS <= MAXBS) {
+      if (!must_split) {
+        j_none = try_block<MAXN, BS, NW>(k, r, c);
+        j_none += ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9;
+        if (!can_split) return j_none;
+        area_copy_dev<BS, NW>(f, k.snap + snap_level_off<MAXN>(BS, MAXBS), r, c, 1);
+        set_decoded_wg<NW>(f, r, c, n4, 0);
+      }
+    }
+    long long j_split = must_split ? 0 : ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+      if (!must_split && j_split >= j_none) break;
+      j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half);
+    }
+    if (must_split || j_split < j_none) return j_split;
+    if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
+    return j_none;
+  }
+};
+template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
+  static __device__ MI_K1_INLINE long long run(Ctx<MAXN> &k, int r, int c) {
+    const LDS FrameDev *f = k.f;
+    if (r >= f->mi_rows || c >= f->mi_cols) return 0;
+    set_decoded_wg<NW>(f, r, c, 1, 0);
+    return try_block<MAXN, 0, NW>(k, r, c);
+  }
+};
+
 template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
   return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2 +
          ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + (size_t)FRAMEDEV_K1_BYTES;
 }
 
-template <int MAXBS, int NW>
+// BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
+template <int MAXBS, int NW, bool BU>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -1126,7 +1175,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   const LDS FrameDev *f = lf;
   k.t.mi_row_start = gf->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   k.t.mi_col_start = gf->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES(MAXN);
+  k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES_ALL(MAXN);
 #if MI_PROFILE
   if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
 #endif
@@ -1134,8 +1183,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   if (DBG_IS(f, 1)) return;
   const unsigned long long clk0 = wall_clock64();
   for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
-    for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16)
-      RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
+    for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16) {
+      if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
+    }
   if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 #if MI_PROFILE
   WG_SYNC();

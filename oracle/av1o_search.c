@@ -378,6 +378,37 @@ static int rd_partition(Search *s, int r, int c, int bs, int64_t known_j) {
   return 0;
 }
 
+/* encode_partition_bottomup (rav1e; SpeedTweaks.encode_bottomup, speed <= 2, ravif av1encoder.rs:575): every child is searched
+ * recursively FIRST, so the undivided block competes with the children's own best partitions instead of their undivided forms.
+ * Returns the RD cost of the node including its partition symbol; the winner's data is left in the frame. */
+static int64_t rd_partition_bottomup(Search *s, int r, int c, int bs) {
+  Av1oFrame *f = s->f;
+  if (r >= f->mi_rows || c >= f->mi_cols) return 0;
+  const int half = (1 << bs) >> 1, px = 4 << bs;
+  const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
+  const int must_split = bs > BS_4 && (px > f->cfg.part_max || !has_rows || !has_cols);
+  const int can_split = bs > BS_4 && (px > f->cfg.part_min || must_split);
+  static AreaSnap snap[5];
+  set_decoded(f, r, c, bs, 0);
+  int64_t j_none = INT64_MAX;
+  if (!must_split) {
+    j_none = try_block(s, r, c, bs);
+    if (bs >= BS_8) j_none += ((int64_t)partition_rate(s, r, c, bs, PARTITION_NONE) * f->rdmult[0] + 256) >> 9;
+    if (!can_split) return j_none;
+    area_copy(f, &snap[bs], r, c, bs, 1);
+    set_decoded(f, r, c, bs, 0);
+  }
+  int64_t j_split = must_split ? 0 : ((int64_t)partition_rate(s, r, c, bs, PARTITION_SPLIT) * f->rdmult[0] + 256) >> 9;
+  for (int k = 0; k < 4; k++) {
+    if (!must_split && j_split >= j_none) break;               /* costs only grow */
+    j_split += rd_partition_bottomup(s, r + (k >> 1) * half, c + (k & 1) * half, bs - 1);
+  }
+  if (must_split || j_split < j_none) return j_split;
+  area_copy(f, &snap[bs], r, c, bs, 0);
+  set_decoded(f, r, c, bs, 1);
+  return j_none;
+}
+
 void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
   Search s; s.f = f;
   s.t.mi_row_start = f->tile_row_start[tile_row] * SB_MI; s.t.mi_row_end = imin(f->tile_row_start[tile_row + 1] * SB_MI, f->mi_rows);
@@ -388,5 +419,5 @@ void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
   }
   for (int r = s.t.mi_row_start; r < s.t.mi_row_end; r += SB_MI)
     for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI)
-      rd_partition(&s, r, c, BS_64, -1);
+      if (f->cfg.bottomup) rd_partition_bottomup(&s, r, c, BS_64); else rd_partition(&s, r, c, BS_64, -1);
 }
