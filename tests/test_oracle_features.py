@@ -113,3 +113,29 @@ def test_premultiplied_pixel_map(oracle, avifdec):
     g, b, r = d['planes']                                                 # identity matrix: planes are G, B, R
     err = np.abs(np.stack([r, g, b], -1).astype(int) - want)
     assert np.median(err) <= 4 and np.all(np.stack([r, g, b], -1)[:16].astype(int).mean() < 8)   # the a in {0,255} rows are black
+
+
+def test_quality_plausibility_against_libaom(oracle):
+    """at a matched file size the encoder's PSNR stays within a plausibility band of libaom's (Pillow's bundled
+    libavif; a different, PSNR-tuned encoder) -- catches a broken RDO / mis-scaled distortion, proves nothing about parity."""
+    import io
+    PIL_Image = pytest.importorskip('PIL.Image')
+    import PIL._avif as _avif
+    if not _avif.encoder_codec_available('aom'):
+        pytest.skip('no aom encoder in Pillow')
+    sys.path.insert(0, ROOT)
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(384, 216, index=2)
+
+    def psnr(a, b):
+        return 10 * np.log10(255.0 ** 2 / np.mean((a.astype(float) - b.astype(float)) ** 2))
+    data, cs, _ = oracle.ravif_encode(img, quality=80, speed=4, depth=8)
+    ours = psnr(np.array(PIL_Image.open(io.BytesIO(data)).convert('RGB')), img)
+    best = None
+    for aq in range(40, 96, 5):
+        b = io.BytesIO(); PIL_Image.fromarray(img, 'RGB').save(b, format='AVIF', quality=aq, speed=8, codec='aom', subsampling='4:4:4')
+        if best is None or abs(b.tell() - len(data)) < abs(best[0] - len(data)):
+            best = (b.tell(), b.getvalue())
+    theirs = psnr(np.array(PIL_Image.open(io.BytesIO(best[1])).convert('RGB')), img)
+    assert 0.7 < best[0] / len(data) < 1.4
+    assert ours > theirs - 2.5 and ours > 30.0, (ours, theirs, len(data), best[0])
