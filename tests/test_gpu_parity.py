@@ -226,22 +226,8 @@ def test_config3_full_size_4096_rgba_properties(avifdec):
     b.close()
 
 
-def test_config5_8k_speed1_properties(avifdec):
-    """BASELINE config 5 at its full size (7680x4320, speed 1, 10-bit): conformance + reconstruction identity + tile plan."""
-    import cavif_rs_amd as m
-    from cavif_rs_amd.synth import synth_image
-    img = synth_image(7680, 4320, index=5)
-    e = m.Encoder().with_quality(80).with_speed(1).with_bit_depth(10)
-    b = m.BatchEncoder(e, 1, 7680, 4320, channels=3)
-    b.upload(0, img)
-    b.encode()
-    out = b.get(0)
-    assert b.num_tiles() == 8            # 2048-px minimum tile size at speed 1 (ravif/src/av1encoder.rs:598-604): 7680*4320 / 2048^2 = 7.9 -> 8
-    d = avifdec.decode(out.avif_file)
-    assert (d['width'], d['height'], d['depth']) == (7680, 4320, 10)
-    for a, r in zip(d['planes'], b.recon(0)):
-        assert np.array_equal(a, r)
-    b.close()
+# (BASELINE config 5 at full size -- conformance, reconstruction identity, tile plan and the oracle's sha256 -- is one test in
+#  tests/test_gpu_parity_cells.py::test_full_size_configs_equal_oracle_vectors: the 8K speed-1 bottom-up encode takes ~50 s.)
 
 
 @pytest.mark.parametrize('w,h', [(1, 1), (3, 2), (5, 7), (4, 64), (65, 3)])

@@ -102,7 +102,7 @@ G = os.path.join(ROOT, 'tests', 'golden', 'fullsize_golden.json')
 
 @pytest.mark.skipif(not os.path.exists(G), reason='tests/golden/fullsize_golden.json not generated yet (tests/golden/make_fullsize_golden.py)')
 @pytest.mark.parametrize('name', ['config3_4096x4096_rgba_s4_q80', 'config5_7680x4320_rgb_s1_q80'])
-def test_full_size_configs_equal_oracle_vectors(name):
+def test_full_size_configs_equal_oracle_vectors(avifdec, name):
     """BASELINE configs 3 and 5 at full size: the HIP path == the oracle's output, which was produced once on the host
     (minutes of scalar C) and committed as sha256 (tests/golden/make_fullsize_golden.py)."""
     import cavif_rs_amd as m
@@ -113,6 +113,21 @@ def test_full_size_configs_equal_oracle_vectors(name):
     g = allg[name]
     img = synth_image(g['w'], g['h'], index=g['index'], alpha=g['alpha'])
     e = m.Encoder().with_quality(g['quality']).with_alpha_quality(g['alpha_quality']).with_speed(g['speed']).with_bit_depth(g['depth'])
-    got = e.encode_rgba(img) if g['alpha'] else e.encode_rgb(img)
+    b = m.BatchEncoder(e, 1, g['w'], g['h'], channels=4 if g['alpha'] else 3)
+    b.upload(0, img)
+    b.encode()
+    got = b.get(0)
     assert got.color_byte_size == g['color_byte_size'] and got.alpha_byte_size == g['alpha_byte_size']
     assert len(got.avif_file) == g['avif_len'] and hashlib.sha256(got.avif_file).hexdigest() == g['avif_sha256']
+    # size-independent properties at the full size: tile plan, dav1d conformance, decoder output == the encoder's reconstruction
+    if name.startswith('config5'):
+        assert b.num_tiles() == 8        # 2048-px minimum tile size at speed 1 (ravif/src/av1encoder.rs:598-604): 7680*4320 / 2048^2 = 7.9 -> 8
+    else:
+        assert b.num_tiles() == 512      # 256-px minimum tile size at speed 4: 256 colour + 256 alpha tiles
+    d = avifdec.decode(got.avif_file)
+    assert (d['width'], d['height'], d['depth']) == (g['w'], g['h'], g['depth'])
+    for a, r in zip(d['planes'], b.recon(0)):
+        assert np.array_equal(a, r)
+    if g['alpha']:
+        assert np.array_equal(d['alpha'], b.recon(0, alpha=True)[0])
+    b.close()
