@@ -102,12 +102,12 @@ __device__ inline void lr_load_window(LrLds &L, const FrameDev *f, int plane, co
   }
   __syncthreads();
 }
-// Box filter process of a chunk (spec 7.17.3) in three steps, so that the search can reuse the first one across parameter sets:
-//   raw : per thread, the (sum of squares, sum) box sums of its positions of the (w + 2) x (h + 2) grid -- they depend on the
-//         radius only.  Radius 2 (pass 0) weights rows of odd parity only, so only those rows are computed.
-//   map : (a, b) -> (A, B) of one parameter set (its s), into LDS.
-//   F   : the 3x3 weighting of (A, B) -> filtered value of the thread's 16 samples (tid + 256 k, row-major over w x h).
-template <int R> struct LrRaw { static constexpr int NP = R == 2 ? 9 : 18; uint32_t a[NP], b[NP]; };
+// Box filter process of a chunk (spec 7.17.3) in two steps:
+//   AB : per thread, the (sum of squares, sum) box sums of its positions of the (w + 2) x (h + 2) grid -> (A, B) of one parameter
+//        set (its s), into LDS.  Radius 2 (pass 0) weights rows of odd parity only, so only those rows are computed.
+//   F  : the 3x3 weighting of (A, B) -> filtered value of the thread's 16 samples (tid + 256 k, row-major over w x h).
+// (Keeping the box sums in registers across the parameter sets of one unit was tried: 258 VGPRs, one wave per SIMD, no gain.)
+template <int R> struct LrRaw { static constexpr int NP = R == 2 ? 9 : 18; };
 template <int R> __device__ __forceinline__ bool lr_pos(const LrChunk &c, int k, int *pi, int *pj) {
   const int aw = c.w + 2, ah = c.h + 2;
   const int nrows = R == 2 ? (ah - (c.y0 & 1) + 1) >> 1 : ah;
@@ -116,38 +116,6 @@ template <int R> __device__ __forceinline__ bool lr_pos(const LrChunk &c, int k,
   const int row = c.w == 64 ? pos / 66 : pos / aw;             // the usual chunk is 64 wide: division by a constant
   *pj = pos - row * aw; *pi = R == 2 ? (c.y0 & 1) + 2 * row : row;           // pi = i + 1, pj = j + 1
   return true;
-}
-template <int R> __device__ inline void lr_box_raw(LrLds &L, const LrChunk &c, LrRaw<R> &raw) {
-#pragma unroll
-  for (int k = 0; k < LrRaw<R>::NP; k++) {
-    int pi, pj; uint32_t a = 0, b = 0;
-    if (lr_pos<R>(c, k, &pi, &pj)) {
-      const int wy = pi + 2, wx = pj + 2;                      // window coordinates of (i, j)
-#pragma unroll
-      for (int dy = -R; dy <= R; dy++)
-#pragma unroll
-        for (int dx = -R; dx <= R; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
-    }
-    raw.a[k] = a; raw.b[k] = b;
-  }
-}
-template <int R> __device__ inline void lr_box_map(LrLds &L, const LrChunk &c, const LrRaw<R> &raw, int sparam, int bd) {
-  constexpr int n = (2 * R + 1) * (2 * R + 1), one_by_n = ((1 << 12) + n / 2) / n;
-  const int s2 = 2 * (bd - 8), s1 = bd - 8;
-#pragma unroll
-  for (int k = 0; k < LrRaw<R>::NP; k++) {
-    int pi, pj;
-    if (lr_pos<R>(c, k, &pi, &pj)) {
-      const uint32_t a = raw.a[k], b = raw.b[k];
-      const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
-      const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
-      const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
-      const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
-      const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
-      L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
-    }
-  }
-  __syncthreads();
 }
 // raw + map fused (nothing kept between parameter sets): (A, B) of one (radius, s) straight into LDS
 template <int R> __device__ inline void lr_box_AB(LrLds &L, const LrChunk &c, int sparam, int bd) {

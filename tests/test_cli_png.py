@@ -138,3 +138,52 @@ def test_cli_skips_existing_output_and_fails_loudly_without_gpu(tmp_path):
         r = _run(['-f', str(p)])
         assert r.returncode == 1 and b'no HIP device' in r.stderr                      # no silent CPU path
         assert (tmp_path / 'a.avif').read_bytes() == b'existing'
+
+
+def test_png_reader_survives_corruption():
+    """Mutated / truncated PNGs: mi_png_decode_rgba returns a status, never crashes, never allocates a claimed canvas
+    that the compressed data cannot back."""
+    import ctypes as C, io, zlib, struct
+    import numpy as np
+    from PIL import Image
+    import cavif_rs_amd as m
+    L = m.load_library()
+    L.mi_png_decode_rgba.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(7)
+    seeds = []
+    for mode, shape in (('RGB', (23, 31, 3)), ('RGBA', (16, 16, 4)), ('L', (9, 40)), ('P', (12, 12))):
+        arr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        im = Image.fromarray(arr if mode != 'P' else arr % 7, mode)
+        if mode == 'P':
+            im.putpalette([int(x) for x in rng.integers(0, 256, size=21)])
+        b = io.BytesIO(); im.save(b, format='PNG', interlace=bool(len(seeds) & 1)); seeds.append(b.getvalue())
+
+    def run(data):
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b'\\0')
+        out = C.POINTER(C.c_uint8)(); w = C.c_uint32(); h = C.c_uint32()
+        st = L.mi_png_decode_rgba(buf, len(data), C.byref(out), C.byref(w), C.byref(h))
+        if st == 0:
+            assert 0 < w.value <= 65536 and 0 < h.value <= 65536
+            L.mi_free(out)
+        return st
+    ok = 0
+    for s in seeds:
+        assert run(s) == 0
+        for _ in range(120):
+            d = bytearray(s)
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                d = d[:int(rng.integers(0, len(d)))]
+            elif kind == 1:
+                for _ in range(int(rng.integers(1, 6))):
+                    d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+            elif kind == 2:
+                p = int(rng.integers(8, len(d))); d[p:p] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+            else:
+                struct.pack_into('>II', d, 16, int(rng.integers(1, 1 << 16)), int(rng.integers(1, 1 << 16)))     # lie about the canvas
+            ok += run(bytes(d)) == 0
+    # a 100-byte file that claims 65536 x 65536 must be refused without allocating 17 GB
+    ihdr = struct.pack('>IIBBBBB', 65536, 65536, 8, 6, 0, 0, 0)
+    def chunk(t, dd): return struct.pack('>I', len(dd)) + t + dd + struct.pack('>I', zlib.crc32(t + dd) & 0xffffffff)
+    bomb = b'\\x89PNG\\r\\n\\x1a\\n' + chunk(b'IHDR', ihdr) + chunk(b'IDAT', zlib.compress(b'\\0' * 64)) + chunk(b'IEND', b'')
+    assert run(bomb) != 0

@@ -87,3 +87,28 @@ def test_cli_output_directory_stdio_and_dirty_alpha(tmp_path):
     im = Image.open(io.BytesIO((tmp_path / 'named.avif').read_bytes()))
     assert im.size == (64, 48)
 
+
+
+def test_cli_keeps_going_past_a_bad_file(tmp_path):
+    """One unreadable input among many: the reference reports it, carries on with the rest and exits 1 (src/main.rs:158-186).
+    The streamed path must hand every other image its own file (no slot mix-up after the gap)."""
+    from cavif_rs_amd.synth import synth_image
+    e = _cli_encoder()
+    names = []
+    for i in range(7):
+        p = tmp_path / ('im%d.png' % i)
+        if i in (2, 5):
+            p.write_bytes(b'\x89PNG\r\n\x1a\n' + b'garbage' * 9 if i == 2 else b'')
+        else:
+            Image.fromarray(synth_image(96 + 32 * (i & 1), 64, index=i), 'RGB').save(p)
+        names.append(str(p))
+    r = subprocess.run([CLI] + names, capture_output=True)
+    assert r.returncode == 1
+    assert r.stderr.count(b'error') >= 2 and b'im2.png' in r.stderr and b'im5.png' in r.stderr
+    for i in range(7):
+        out = tmp_path / ('im%d.avif' % i)
+        if i in (2, 5):
+            assert not out.exists()
+        else:
+            im = synth_image(96 + 32 * (i & 1), 64, index=i)
+            assert out.read_bytes() == e.encode_rgba(np.dstack([im, np.full(im.shape[:2], 255, np.uint8)])).avif_file
