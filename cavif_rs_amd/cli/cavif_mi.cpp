@@ -51,6 +51,7 @@ int usage(const char *msg) {
 }  // namespace
 
 #include <chrono>
+#include <unistd.h>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
   const double t_start = now_s(); const bool timing = getenv("CAVIF_MI_TIMING") != nullptr;
@@ -143,15 +144,24 @@ int main(int argc, char **argv) {
     if (j.error.empty() && !j.out_stdio && !overwrite && exists(j.out_path)) j.error = j.out_path + " already exists; skipping";
   };
   // loaders (host cores) and the encoder (GPUs) run concurrently: the encoder pulls image i through fetch(), which waits for
-  // loader i -- the reference gets the same overlap from rayon's work stealing over process() (src/main.rs:179-223)
+  // loader i -- the reference gets the same overlap from rayon's work stealing over process() (src/main.rs:179-223).  Loaders
+  // stay at most `window` images ahead of the images the encoder has released (pixels copied to its staging and freed here), so
+  // host memory is bounded for any number of files.
   std::mutex mu; std::condition_variable cv; std::vector<char> loaded(files.size(), 0);
   const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(threads > 0 ? (unsigned)threads : 64u, std::thread::hardware_concurrency())));
+  std::atomic<size_t> window{ 4 * 32 + nw };                        // widened below once the device count is known (loaders start first)
+  size_t released = 0;                                              // guarded by mu: images the encoder is done reading (or that failed to load)
   std::atomic<size_t> next{ 0 };
   std::vector<std::thread> pool;
   for (size_t t = 0; t < nw; t++) pool.emplace_back([&] {
-    for (size_t i; (i = next.fetch_add(1)) < files.size();) { load(i); { std::lock_guard<std::mutex> lk(mu); loaded[i] = 1; } cv.notify_all(); }
+    for (size_t i; (i = next.fetch_add(1)) < files.size();) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return i < released + window; }); }
+      load(i);
+      { std::lock_guard<std::mutex> lk(mu); loaded[i] = 1; if (!jobs[i].error.empty()) released++; }
+      cv.notify_all();
+    }
   });
-  struct Ctx { std::vector<Job> *jobs; std::mutex *mu; std::condition_variable *cv; std::vector<char> *loaded; } ctx{ &jobs, &mu, &cv, &loaded };
+  struct Ctx { std::vector<Job> *jobs; std::mutex *mu; std::condition_variable *cv; std::vector<char> *loaded; size_t *released; } ctx{ &jobs, &mu, &cv, &loaded, &released };
   auto fetch = [](void *user, size_t i, mi_image_desc *d) -> int {
     Ctx *c = (Ctx *)user;
     { std::unique_lock<std::mutex> lk(*c->mu); c->cv->wait(lk, [&] { return (*c->loaded)[i] != 0; }); }
@@ -160,9 +170,20 @@ int main(int argc, char **argv) {
     d->pixels = j.rgba; d->width = j.w; d->height = j.h; d->stride_px = j.w; d->channels = 4;
     return MI_OK;
   };
+  auto release = [](void *user, size_t i) {
+    Ctx *c = (Ctx *)user;
+    Job &j = (*c->jobs)[i];
+    mi_free(j.rgba); j.rgba = nullptr;
+    { std::lock_guard<std::mutex> lk(*c->mu); (*c->released)++; }
+    c->cv->notify_all();
+  };
   std::vector<mi_encoded_image> enc_out(jobs.size()); std::vector<int> status(jobs.size(), MI_OK);
-  if (timing) { fprintf(stderr, "[timing] setup %.3f s\n", now_s() - t_start); mi_device_count(); fprintf(stderr, "[timing] HIP runtime up %.3f s\n", now_s() - t_start); }
-  const int rc_all = mi_ravif_encode_stream(&enc, jobs.size(), fetch, &ctx, enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
+  if (timing) fprintf(stderr, "[timing] setup %.3f s\n", now_s() - t_start);
+  const size_t ndev_used = devices.empty() ? (size_t)std::max(1, mi_device_count()) : devices.size();      // brings the HIP runtime up while the loaders run
+  { std::lock_guard<std::mutex> lk(mu); window = 4 * 32 * ndev_used + nw; }
+  cv.notify_all();
+  if (timing) fprintf(stderr, "[timing] HIP runtime up %.3f s\n", now_s() - t_start);
+  const int rc_all = mi_ravif_encode_stream(&enc, jobs.size(), fetch, release, &ctx, enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
   for (auto &t : pool) t.join();
   if (timing) fprintf(stderr, "[timing] encoded %.3f s\n", now_s() - t_start);
   if (rc_all == MI_NO_DEVICE) for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].error.empty()) status[i] = MI_NO_DEVICE;
@@ -191,5 +212,7 @@ int main(int argc, char **argv) {
     if (j.rgba) mi_free(j.rgba);
     if (!j.error.empty()) { failures++; if (!quiet) fprintf(stderr, "error: %s: error: %s\n", j.in_name.c_str(), j.error.c_str()); }
   }
-  return failures ? 1 : 0;
+  // every output is on disk: leave without the HIP runtime's teardown (freeing pinned staging and contexts costs ~0.3 s)
+  fflush(stdout); fflush(stderr);
+  _exit(failures ? 1 : 0);
 }

@@ -67,7 +67,12 @@ struct FrameDev {
   uint32_t *tile_len;        // per tile
   uint32_t tile_out_cap;
   int tile_base;             // index of this frame's first tile in the launch-wide tile list
+  // Alpha frames of an RGBA batch are planned before the front end has reported whether the image uses its alpha channel
+  // (ravif/src/av1encoder.rs:246): `active` points at the image's flag, and every stage of an unused alpha frame returns at
+  // once (no host round trip between the front end and the tile search).  nullptr: always active.
+  const int *active;
 };
+__device__ __forceinline__ bool frame_idle(const FrameDev *f) { return f->active != nullptr && *f->active == 0; }
 #define FRAMEDEV_K1_BYTES ((int)(offsetof(FrameDev, fin) + 15) & ~15)
 
 struct TileJob { int frame; int tile_row, tile_col; };

@@ -90,7 +90,7 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
 __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *frames, int nframes) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y >> 1, pass = blockIdx.y & 1;
-  if (plane >= f->np || f->fast_deblock) return;
+  if (plane >= f->np || f->fast_deblock || frame_idle(f)) return;
   __shared__ long long ldiff[65];
   if (threadIdx.x < 65) ldiff[threadIdx.x] = 0;
   __syncthreads();
@@ -138,6 +138,7 @@ __global__ void deblock_pick_kernel(FrameDev *frames, int nframes) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nframes) return;
   FrameDev *f = frames + k;
+  if (frame_idle(f)) return;
   if (!f->fast_deblock) {
     int lv[4] = { 0, 0, 0, 0 };
     for (int pass = 0; pass < 2; pass++) {
@@ -160,7 +161,7 @@ __global__ void deblock_pick_kernel(FrameDev *frames, int nframes) {
 __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *frames, int nframes, int pass) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y;
-  if (plane >= f->np) return;
+  if (plane >= f->np || frame_idle(f)) return;
   const int L = plane == 0 ? f->lf_level[pass] : f->lf_level[plane + 1];
   if (!L) return;
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,7 +273,7 @@ __device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int
 __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *frames, int write_final) {
   const FrameDev *f = frames + blockIdx.y;
   const int sbi = blockIdx.x;
-  if (sbi >= f->sb_rows * f->sb_cols) return;
+  if (sbi >= f->sb_rows * f->sb_cols || frame_idle(f)) return;
   __shared__ unsigned long long costs[8];
   __shared__ int any_blocks, best_idx;
   __shared__ int part_s[4][128];
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *frames, in
 __global__ __launch_bounds__(256) void activity_kernel(const FrameDev *frames) {
   const FrameDev *f = frames + blockIdx.y;
   const int cw = f->pw >> 3, chh = f->ph >> 3, cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= cw * chh) return;
+  if (cell >= cw * chh || frame_idle(f)) return;
   const int cy = cell / cw, cx = cell - cy * cw;
   uint32_t s8 = 0, q8 = 0;
   for (int k = 0; k < 4; k++) {

@@ -9,6 +9,8 @@
 #include <memory>
 #include <thread>
 #include <atomic>
+#include <future>
+#include <chrono>
 #include <exception>
 #include "host_av1.h"
 #include "png_reader.h"
@@ -38,6 +40,9 @@ struct DeviceTables { uint16_t *cost[4] = { 0, 0, 0, 0 }; uint16_t *cdf0[4] = { 
 static std::mutex g_tab_mu;
 #define MI_MAX_DEVICES 64
 static DeviceTables g_tabs[MI_MAX_DEVICES];
+// First launch of anything from this library makes the runtime load the gfx950 code object (~2 MB, 0.1-0.2 s): ensure_tables
+// does it once per device with an empty kernel, so callers can overlap it with their allocations (mi_ravif_encode_stream does).
+__global__ void module_warm_kernel() {}
 static int ensure_tables(int dev) {
   std::lock_guard<std::mutex> lk(g_tab_mu);
   if (dev < 0 || dev >= MI_MAX_DEVICES) { fprintf(stderr, "mi_avif: HIP ordinal %d outside the supported 0..%d\n", dev, MI_MAX_DEVICES - 1); return MI_INVALID_ARGUMENT; }
@@ -49,6 +54,8 @@ static int ensure_tables(int dev) {
     HIP_OK(hipMemcpy(t.cost[q], cost.data(), CDF_TOTAL * 2, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(t.cdf0[q], av1_default_cdfs + (size_t)q * CDF_TOTAL, CDF_TOTAL * 2, hipMemcpyHostToDevice));
   }
+  hipLaunchKernelGGL(module_warm_kernel, dim3(1), dim3(64), 0, 0);
+  HIP_OK(hipDeviceSynchronize());
   t.ready = true;
   return MI_OK;
 }
@@ -226,16 +233,18 @@ struct mi_batch {
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
   uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
-  uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0; unsigned long long *d_prof = nullptr;
+  uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0, packed_max = 0; unsigned long long *d_prof = nullptr;
+  int *h_alpha = nullptr; FrameDev *h_frames = nullptr; TileJob *h_jobs = nullptr;   // pinned: alpha flags (D2H), frame descriptors and tile jobs (H2D sources)
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
-  std::vector<TileJob> jobs; std::vector<FrameDev> hframes;
+  std::vector<TileJob> jobs;
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
   hipEvent_t ev[8]{}; double stage_ms[8]{};
   bool planned = false, in_flight = false;
 };
 
 static int batch_plan(mi_batch *b, bool with_alpha_frames) {
-  // (re)build frame plans: colour for every image, alpha for flagged images
+  // (re)build frame plans: colour for every image [0, n), then (RGBA input) one alpha frame per image [n, 2n) -- whether an alpha
+  // frame is used is decided on the device (FrameDev::active)
   b->frames.clear(); b->jobs.clear();
   const int quantizer = quality_to_quantizer(b->enc.quality), aquant = quality_to_quantizer(b->enc.alpha_quality);
   auto make = [&](int image, bool alpha) {
@@ -249,34 +258,31 @@ static int batch_plan(mi_batch *b, bool with_alpha_frames) {
     return p;
   };
   for (int i = 0; i < b->n; i++) b->frames.push_back(make(i, false));
-  if (with_alpha_frames) for (int i = 0; i < b->n; i++) if (b->alpha_flags[i]) b->frames.push_back(make(i, true));
+  if (with_alpha_frames) for (int i = 0; i < b->n; i++) b->frames.push_back(make(i, true));
   return MI_OK;
 }
 
 static void batch_free_device(mi_batch *b) {
-  if (b->d_arena) hipFree(b->d_arena); b->d_arena = nullptr;
-  if (b->d_frames) hipFree(b->d_frames); b->d_frames = nullptr;
-  if (b->d_jobs) hipFree(b->d_jobs); b->d_jobs = nullptr;
-  if (b->d_precarry) hipFree(b->d_precarry); b->d_precarry = nullptr;
-  if (b->d_offsets) hipFree(b->d_offsets); b->d_offsets = nullptr;
-  if (b->d_prof) hipFree(b->d_prof); b->d_prof = nullptr;
-  if (b->d_packed) hipFree(b->d_packed); b->d_packed = nullptr;
-  if (b->h_packed) hipHostFree(b->h_packed); b->h_packed = nullptr;
-  if (b->h_lens) hipHostFree(b->h_lens); b->h_lens = nullptr;
-  if (b->h_lf) hipHostFree(b->h_lf); b->h_lf = nullptr;
+  if (b->d_arena) (void)hipFree(b->d_arena); b->d_arena = nullptr;
+  if (b->d_frames) (void)hipFree(b->d_frames); b->d_frames = nullptr;
+  if (b->d_jobs) (void)hipFree(b->d_jobs); b->d_jobs = nullptr;
+  if (b->d_precarry) (void)hipFree(b->d_precarry); b->d_precarry = nullptr;
+  if (b->d_offsets) (void)hipFree(b->d_offsets); b->d_offsets = nullptr;
+  if (b->d_prof) (void)hipFree(b->d_prof); b->d_prof = nullptr;
+  if (b->d_packed) (void)hipFree(b->d_packed); b->d_packed = nullptr;
+  if (b->h_packed) (void)hipHostFree(b->h_packed); b->h_packed = nullptr;
+  if (b->h_lens) (void)hipHostFree(b->h_lens); b->h_lens = nullptr;
+  if (b->h_lf) (void)hipHostFree(b->h_lf); b->h_lf = nullptr;
+  if (b->h_alpha) (void)hipHostFree(b->h_alpha); b->h_alpha = nullptr;
+  if (b->h_frames) (void)hipHostFree(b->h_frames); b->h_frames = nullptr;
+  if (b->h_jobs) (void)hipHostFree(b->h_jobs); b->h_jobs = nullptr;
 }
 
 // allocate arena for the worst case: every image has an alpha frame when channels == 4
 static int batch_alloc(mi_batch *b) {
   const DeviceTables &tab = g_tabs[b->device];
-  std::vector<FramePlan> worst;
-  {
-    std::vector<int> save = b->alpha_flags;
-    if (b->channels == 4) std::fill(b->alpha_flags.begin(), b->alpha_flags.end(), 1);
-    batch_plan(b, b->channels == 4);
-    worst = b->frames;
-    b->alpha_flags = save;
-  }
+  batch_plan(b, b->channels == 4);
+  std::vector<FramePlan> worst = b->frames;
   size_t total = 0, max_tiles = 0; uint32_t max_cap = 0; size_t packed = 0;
   for (auto &p : worst) {
     const uint32_t cap = tile_capacity(p);
@@ -292,11 +298,17 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * max_cap * 2));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
   HIP_OK(hipMalloc(&b->d_prof, max_tiles * 128 * 8));
-  b->packed_cap = std::min<size_t>(packed, (size_t)1 << 31);
+  // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
+  // usual case a few per cent of it: start at 1/16 and let mi_batch_wait grow the pair when a run needs more.
+  b->packed_max = std::min<size_t>(packed, (size_t)1 << 31);
+  b->packed_cap = std::min(b->packed_max, align_up(std::max<size_t>(packed / 16, (size_t)1 << 20), 4096));
   HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_lens, max_tiles * 4));
   HIP_OK(hipHostMalloc(&b->h_lf, worst.size() * 4 * sizeof(int)));
+  HIP_OK(hipHostMalloc(&b->h_alpha, sizeof(int) * b->cap));
+  HIP_OK(hipHostMalloc(&b->h_frames, sizeof(FrameDev) * worst.size()));
+  HIP_OK(hipHostMalloc(&b->h_jobs, sizeof(TileJob) * max_tiles));
   return MI_OK;
 }
 
@@ -326,7 +338,9 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   if (e->speed < 1 || e->speed > 10 || !(e->quality >= 1.f && e->quality <= 100.f) || !(e->alpha_quality >= 1.f && e->alpha_quality <= 100.f)) return nullptr;
   if (mi_device_count() <= e->device) { fprintf(stderr, "mi_avif: no HIP device %d (the HIP path is mandatory; there is no CPU fallback)\n", e->device); return nullptr; }
   if (hipSetDevice(e->device) != hipSuccess) return nullptr;
-  if (ensure_tables(e->device) != MI_OK) return nullptr;
+  const bool timing = getenv("MI_AVIF_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3; };
   mi_batch *b = new mi_batch();
   b->enc = *e; b->n = b->cap = n_images; b->w = w; b->h = h; b->channels = channels; b->device = e->device; b->depth = e->depth == 8 ? 8 : 10;
   if (e->exif && e->exif_len) b->exif.assign(e->exif, e->exif + e->exif_len);
@@ -340,7 +354,11 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
          hipMalloc(&b->d_alpha_acc, sizeof(unsigned long long) * 4 * n_images) == hipSuccess;
   if (ok && channels == 4 && e->alpha_mode == 2) ok = hipMalloc(&b->d_clean, b->pixel_bytes) == hipSuccess;   // premultiplied pixels
   for (int i = 0; i < 8 && ok; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  const double t_px = since();
   if (ok) ok = batch_alloc(b) == MI_OK;
+  const double t_arena = since();
+  if (ok) ok = ensure_tables(e->device) == MI_OK;              // last: a caller may be warming the device up on another thread meanwhile
+  if (timing) fprintf(stderr, "[mi_avif] batch_create %d x %ux%u: pixels + pinned staging %.1f ms, arena (%.2f GB) %.1f ms, tables %.1f ms\n", n_images, w, h, t_px, b->arena_bytes / 1e9, t_arena - t_px, since() - t_arena);
   if (!ok) { mi_batch_destroy(b); return nullptr; }
   b->files.resize(n_images); b->color_sz.assign(n_images, 0); b->alpha_sz.assign(n_images, 0);
   return b;
@@ -359,7 +377,7 @@ int mi_batch_set_count(mi_batch *b, int n_images) {
 // enqueue the H2D of images [first, first + count) from the pinned staging on the batch's stream; returns at once
 int mi_batch_upload_async(mi_batch *b, int first, int count) {
   if (!b || first < 0 || count < 1 || first + count > b->cap) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   const size_t img = (size_t)b->w * b->h * b->channels;
   HIP_OK(hipMemcpyAsync(b->d_pixels + first * img, b->h_pixels + first * img, count * img, hipMemcpyHostToDevice, b->stream));
   return MI_OK;
@@ -377,7 +395,7 @@ int mi_batch_upload(mi_batch *b, int index, const uint8_t *pixels, size_t stride
 // debug/profiling: per-tile [K1 start, K1 end, K4 start, K4 end] ticks of the last encode; out must hold 4*num_tiles values
 int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
   if (!b || !out) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   size_t o = 0;
   for (auto &p : b->frames) { HIP_OK(hipMemcpy(out + (size_t)p.dev.tile_base * 4, p.dev.tile_clk, (size_t)p.ntiles * 32, hipMemcpyDeviceToHost)); o += (size_t)p.ntiles * 4; }
   return MI_OK;
@@ -385,7 +403,7 @@ int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
 // profiling builds (MI_PROFILE=1): K1 phase cycle counters, 64 values per tile job of the last encode
 int mi_batch_phase_profile(mi_batch *b, unsigned long long *out) {
   if (!b || !out || !b->d_prof) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   HIP_OK(hipMemcpy(out, b->d_prof, b->jobs.size() * 128 * 8, hipMemcpyDeviceToHost));
   return MI_OK;
 }
@@ -396,11 +414,11 @@ double mi_batch_stage_ms(const mi_batch *b, int stage) { return (b && stage >= 0
 int mi_batch_encode_async(mi_batch *b) {
   if (!b) return MI_INVALID_ARGUMENT;
   if (b->in_flight) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   const DeviceTables &tab = g_tabs[b->device];
   hipStream_t s = b->stream;
-  // ---- plan colour frames (alpha frames are added once the front end has reported the flags)
-  batch_plan(b, false);
+  // ---- plan colour frames and, for RGBA input, an alpha frame per image (idle on the device unless the front end flags the image)
+  batch_plan(b, b->channels == 4);
   size_t off = 0;
   auto place = [&](FramePlan &p) { const uint32_t cap = tile_capacity(p); p.arena = b->d_arena + off; p.arena_bytes = carve(p, p.arena, cap); off += align_up(p.arena_bytes, 4096); fill_dev(p, tab); };
   for (auto &p : b->frames) place(p);
@@ -436,20 +454,10 @@ int mi_batch_encode_async(mi_batch *b) {
   }
   HIP_OK(hipGetLastError());
   if (b->channels == 4) {
-    HIP_OK(hipMemcpyAsync(b->alpha_flags.data(), b->d_alpha_flags, sizeof(int) * b->n, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    const size_t ncolor = b->frames.size();
-    const int quantizer_a = quality_to_quantizer(b->enc.alpha_quality);
-    for (int i = 0; i < b->n; i++) if (b->alpha_flags[i]) {
-      FramePlan p; p.image = i; p.is_alpha = true; mi_av1_config &c = p.cfg;
-      c = b->frames[i].cfg; c.quantizer = (uint8_t)quantizer_a; c.chroma = 1; c.has_color_desc = 0; c.pixel_range = 1;
-      tweaks_from_preset(b->enc.speed, c.quantizer, &c);
-      plan_geometry(p);
-      b->frames.push_back(p);
-    }
-    for (size_t k = ncolor; k < b->frames.size(); k++) {
-      place(b->frames[k]);
+    HIP_OK(hipMemcpyAsync(b->h_alpha, b->d_alpha_flags, sizeof(int) * b->n, hipMemcpyDeviceToHost, s));    // read in mi_batch_wait
+    for (size_t k = b->n; k < b->frames.size(); k++) {
       FramePlan &a = b->frames[k], &col = b->frames[a.image];
+      a.dev.active = b->d_alpha_flags + a.image;
       HIP_OK(hipMemcpyAsync(a.dev.src[0], col.dev.fin[0], (size_t)a.pw * a.ph * 2, hipMemcpyDeviceToDevice, s));
     }
   }
@@ -475,9 +483,10 @@ int mi_batch_encode_async(mi_batch *b) {
     // clear the state the kernels rely on being zero
     HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   }
-  b->hframes.clear(); for (auto &p : b->frames) b->hframes.push_back(p.dev);     // must outlive the async copy
-  HIP_OK(hipMemcpyAsync(b->d_frames, b->hframes.data(), sizeof(FrameDev) * b->hframes.size(), hipMemcpyHostToDevice, s));
-  HIP_OK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
+  for (size_t k = 0; k < b->frames.size(); k++) b->h_frames[k] = b->frames[k].dev;          // pinned: the copies below never block the host
+  memcpy(b->h_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size());
+  HIP_OK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(FrameDev) * b->frames.size(), hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
   // ---- activity mask (Tune::Psychovisual), then K1 tile search
   { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
@@ -503,18 +512,26 @@ int mi_batch_encode_async(mi_batch *b) {
 // Waits for the enqueued work, compacts + downloads the tile payloads (one D2H) and assembles OBUs and containers.
 int mi_batch_wait(mi_batch *b) {
   if (!b || !b->in_flight) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   hipStream_t s = b->stream;
   b->in_flight = false;
   const int njobs = (int)b->jobs.size();
   std::vector<uint32_t> offsets(njobs);
   HIP_OK(hipStreamSynchronize(s));
+  if (b->channels == 4) for (int i = 0; i < b->n; i++) b->alpha_flags[i] = b->h_alpha[i];
+  auto idle = [&](const FramePlan &p) { return p.is_alpha && !b->alpha_flags[p.image]; };
   size_t total = 0;
   for (int j = 0; j < njobs; j++) {
     if (b->h_lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer\n", j); return MI_ENCODING_ERROR; }
     offsets[j] = (uint32_t)total; total += b->h_lens[j];
   }
-  if (total > b->packed_cap) return MI_ENCODING_ERROR;
+  if (total > b->packed_max) return MI_ENCODING_ERROR;
+  if (total > b->packed_cap) {                                 // rare (near-lossless settings): grow the packed pair, keep it
+    (void)hipFree(b->d_packed); (void)hipHostFree(b->h_packed); b->d_packed = nullptr; b->h_packed = nullptr;
+    b->packed_cap = std::min(b->packed_max, align_up(total + total / 2, 4096));
+    HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
+    HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
+  }
   HIP_OK(hipMemcpyAsync(b->d_offsets, offsets.data(), (size_t)njobs * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(pack_tiles_kernel, dim3(njobs), dim3(256), 0, s, b->d_frames, b->d_jobs, njobs, b->d_offsets, b->d_packed);
   HIP_OK(hipMemcpyAsync(b->h_packed, b->d_packed, total, hipMemcpyDeviceToHost, s));
@@ -523,6 +540,7 @@ int mi_batch_wait(mi_batch *b) {
   // ---- host assembly
   for (size_t k = 0; k < b->frames.size(); k++) {
     FramePlan &p = b->frames[k];
+    if (idle(p)) { p.obu.clear(); continue; }
     std::vector<std::pair<const uint8_t *, size_t>> tl;
     for (int t = 0; t < p.ntiles; t++) { const int j = p.dev.tile_base + t; tl.push_back({ b->h_packed + offsets[j], (size_t)b->h_lens[j] }); }
     for (int i = 0; i < 4; i++) p.hdr.lf_level[i] = b->h_lf[4 * k + i];
@@ -530,7 +548,7 @@ int mi_batch_wait(mi_batch *b) {
   }
   for (int i = 0; i < b->n; i++) {
     const FramePlan *alpha = nullptr;
-    for (size_t k = b->n; k < b->frames.size(); k++) if (b->frames[k].image == i) alpha = &b->frames[k];
+    if (b->channels == 4 && b->alpha_flags[i]) alpha = &b->frames[b->n + i];
     const FramePlan &col = b->frames[i];
     b->files[i] = avif_container(col.obu.data(), col.obu.size(), alpha ? alpha->obu.data() : nullptr, alpha ? alpha->obu.size() : 0,
                                  b->w, b->h, b->depth, col.cfg.matrix, b->enc.alpha_mode == 2, b->enc.exif, b->enc.exif_len);
@@ -538,7 +556,7 @@ int mi_batch_wait(mi_batch *b) {
   }
   HIP_OK(hipEventRecord(b->ev[7], s));
   HIP_OK(hipEventSynchronize(b->ev[7]));
-  for (int i = 0; i < 7; i++) { float ms = 0; hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]); b->stage_ms[i] = ms; }
+  for (int i = 0; i < 7; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]); b->stage_ms[i] = ms; }
   return MI_OK;
 }
 
@@ -557,9 +575,9 @@ int mi_batch_get(mi_batch *b, int index, mi_encoded_image *out) {
 
 int mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]) {
   if (!b || index < 0 || index >= b->n) return MI_INVALID_ARGUMENT;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   const FramePlan *p = nullptr;
-  if (!alpha) p = &b->frames[index]; else for (size_t k = b->n; k < b->frames.size(); k++) if (b->frames[k].image == index) p = &b->frames[k];
+  if (!alpha) p = &b->frames[index]; else if (b->channels == 4 && b->alpha_flags[index]) p = &b->frames[b->n + index];
   if (!p) return MI_INVALID_ARGUMENT;
   for (int i = 0; i < 3; i++) planes[i] = nullptr;
   for (int i = 0; i < p->np; i++) {
@@ -571,27 +589,80 @@ int mi_batch_get_recon(mi_batch *b, int index, int alpha, uint16_t *planes[3]) {
 
 void mi_batch_destroy(mi_batch *b) {
   if (!b) return;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   batch_free_device(b);
-  if (b->d_pixels) hipFree(b->d_pixels);
-  if (b->h_pixels) hipHostFree(b->h_pixels);
-  if (b->d_alpha_flags) hipFree(b->d_alpha_flags);
-  if (b->d_clean) hipFree(b->d_clean);
-  if (b->d_clean_tmp) hipFree(b->d_clean_tmp);
-  if (b->d_alpha_acc) hipFree(b->d_alpha_acc);
-  for (int i = 0; i < 8; i++) if (b->ev[i]) hipEventDestroy(b->ev[i]);
-  if (b->stream) hipStreamDestroy(b->stream);
+  if (b->d_pixels) (void)hipFree(b->d_pixels);
+  if (b->h_pixels) (void)hipHostFree(b->h_pixels);
+  if (b->d_alpha_flags) (void)hipFree(b->d_alpha_flags);
+  if (b->d_clean) (void)hipFree(b->d_clean);
+  if (b->d_clean_tmp) (void)hipFree(b->d_clean_tmp);
+  if (b->d_alpha_acc) (void)hipFree(b->d_alpha_acc);
+  for (int i = 0; i < 8; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
+}
+
+// ---- batch objects behind the one-call entry points are pooled ----
+// Creating a batch (hipMalloc of the arena, pinned staging: ~0.2 s for 32 x 1080p) and destroying it cost more than encoding a
+// small image, and a caller of ravif::Encoder::encode_rgba calls it in a loop with the same settings.  mi_ravif_encode_rgba/_rgb,
+// _batch and _stream therefore take their batch objects from a process-wide pool keyed by (device, capacity, shape, settings) and
+// hand them back afterwards; mi_release_cached() (or process exit) frees them.  Explicit mi_batch_create objects are not pooled.
+struct PoolKey {
+  int device, cap, channels; uint32_t w, h; float quality, alpha_quality; uint8_t speed, color_model, depth, alpha_mode; int32_t threads, tiles_override;
+  bool operator==(const PoolKey &o) const {
+    return device == o.device && cap == o.cap && channels == o.channels && w == o.w && h == o.h && quality == o.quality && alpha_quality == o.alpha_quality &&
+           speed == o.speed && color_model == o.color_model && depth == o.depth && alpha_mode == o.alpha_mode && threads == o.threads && tiles_override == o.tiles_override;
+  }
+};
+static PoolKey pool_key(const mi_ravif_encoder *e, int cap, uint32_t w, uint32_t h, int channels) {
+  return PoolKey{ e->device, cap, channels, w, h, e->quality, e->alpha_quality, e->speed, e->color_model, e->depth, e->alpha_mode, e->threads, e->tiles_override };
+}
+static std::mutex g_pool_mu;
+static std::vector<std::pair<PoolKey, mi_batch *>> g_pool;          // oldest first; never destroyed at process exit (the runtime may be gone by then)
+static size_t batch_footprint(const mi_batch *b) { return b->arena_bytes + 3 * b->pixel_bytes + b->packed_cap; }
+static constexpr size_t MI_POOL_MAX_ITEMS = 12, MI_POOL_MAX_BYTES = (size_t)96 << 30;
+
+static mi_batch *pool_acquire(const mi_ravif_encoder *e, int cap, uint32_t w, uint32_t h, int channels) {
+  const PoolKey key = pool_key(e, cap, w, h, channels);
+  mi_batch *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) if (g_pool[i].first == key) { b = g_pool[i].second; g_pool.erase(g_pool.begin() + i); break; }
+  }
+  if (!b) return mi_batch_create(e, cap, w, h, channels);
+  b->exif.clear();
+  if (e->exif && e->exif_len) b->exif.assign(e->exif, e->exif + e->exif_len);
+  b->enc.exif = b->exif.empty() ? nullptr : b->exif.data(); b->enc.exif_len = b->exif.size();
+  b->n = b->cap; b->alpha_flags.assign(b->cap, 0);
+  return b;
+}
+static void pool_release(mi_batch *b) {
+  if (!b) return;
+  if (b->in_flight) { mi_batch_destroy(b); return; }
+  const PoolKey key = pool_key(&b->enc, b->cap, b->w, b->h, b->channels);
+  std::vector<mi_batch *> evict;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back({ key, b });
+    size_t bytes = 0; for (auto &x : g_pool) bytes += batch_footprint(x.second);
+    while (g_pool.size() > MI_POOL_MAX_ITEMS || (bytes > MI_POOL_MAX_BYTES && g_pool.size() > 1)) { bytes -= batch_footprint(g_pool.front().second); evict.push_back(g_pool.front().second); g_pool.erase(g_pool.begin()); }
+  }
+  for (mi_batch *x : evict) mi_batch_destroy(x);
+}
+void mi_release_cached(void) {
+  std::vector<std::pair<PoolKey, mi_batch *>> all;
+  { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
+  for (auto &x : all) mi_batch_destroy(x.second);
 }
 
 static int encode_one(const mi_ravif_encoder *e, const uint8_t *px, int channels, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) {
   if (!e || !px || !out || w < 1 || h < 1) return MI_INVALID_ARGUMENT;
-  mi_batch *b = mi_batch_create(e, 1, w, h, channels);
+  mi_batch *b = pool_acquire(e, 1, w, h, channels);
   if (!b) return mi_device_count() > e->device ? MI_INVALID_ARGUMENT : MI_NO_DEVICE;
   int st = mi_batch_upload(b, 0, px, stride_px);
   if (st == MI_OK) st = mi_batch_encode(b);
   if (st == MI_OK) st = mi_batch_get(b, 0, out);
-  mi_batch_destroy(b);
+  pool_release(b);
   return st;
 }
 int mi_ravif_encode_rgba(const mi_ravif_encoder *e, const uint8_t *rgba, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgba, 4, w, h, stride_px, out); }
@@ -616,7 +687,7 @@ int mi_png_decode_rgba(const uint8_t *data, size_t len, uint8_t **rgba, uint32_t
 // Streaming form of the fan-out: image i is obtained through `fetch(user, i, &desc)` when a worker is about to stage it (the
 // call may block until the pixels exist -- e.g. until a loader thread has decoded the file), so loading, upload, encoding and
 // assembly of consecutive runs overlap.  fetch returns MI_OK or a status that becomes the image's status.
-int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev) {
+int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, mi_release_fn release, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev) {
   if (!e || !fetch || (n && !out)) return MI_INVALID_ARGUMENT;
   const int have = mi_device_count();
   std::vector<int> devs;
@@ -627,17 +698,37 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
   for (size_t i = 0; i < n; i++) { out[i].avif_file = nullptr; out[i].avif_len = out[i].color_byte_size = out[i].alpha_byte_size = 0; }
   std::atomic<size_t> cursor{ 0 };
   const size_t max_run = 32;
-  // Per device: two resident batch objects per image shape, created on first use and kept for the whole call.  While one
-  // batch encodes, the host fills the other one's pinned staging and enqueues its H2D + encode, so uploads, tile search,
-  // entropy coding and the host-side assembly of consecutive runs overlap (the same rotation bench.py drives).
+  const bool timing = getenv("MI_AVIF_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3; };
+  // Per device: up to three resident batch objects (from the pool) per image shape, kept for the whole call.  While one batch encodes, the host
+  // fills the next one's pinned staging and enqueues its H2D + encode, so uploads, tile search, entropy coding and the host-side
+  // assembly of consecutive runs overlap (the same rotation bench.py drives).  A batch object costs tens of milliseconds to create
+  // (hipMalloc of the arena, pinned staging), so the one a run will need is created in the background as soon as the first image
+  // of that shape has been fetched, and the following slot's while the current run is being filled.
+  const size_t cap = std::min(max_run, std::max<size_t>(n, 1));
   auto worker = [&](int dev) {
     mi_ravif_encoder enc = *e; enc.device = dev;
-    struct Slot { mi_batch *b = nullptr; std::vector<size_t> idx; bool busy = false; };
-    struct Shape { uint32_t w, h; int ch; Slot slot[2]; int next = 0; };
+    std::future<int> warm = std::async(std::launch::async, [dev]() { return hipSetDevice(dev) == hipSuccess ? ensure_tables(dev) : (int)MI_ENCODING_ERROR; });
+    constexpr int NSLOT = 3;
+    struct Slot { mi_batch *b = nullptr; std::future<mi_batch *> making; std::vector<size_t> idx; bool busy = false; };
+    struct Shape { uint32_t w, h; int ch; Slot slot[NSLOT]; int next = 0; };
     std::vector<std::unique_ptr<Shape>> shapes;
+    auto ensure_slot = [&](Shape *sh, int j) {
+      Slot &sl = sh->slot[j];
+      if (sl.b || sl.making.valid()) return;
+      const mi_ravif_encoder ec = enc; const uint32_t w = sh->w, h = sh->h; const int ch = sh->ch; const int c = (int)cap;
+      sl.making = std::async(std::launch::async, [ec, c, w, h, ch]() { return pool_acquire(&ec, c, w, h, ch); });
+    };
+    auto shape_for = [&](const mi_image_desc &x) {
+      for (auto &c : shapes) if (c->w == x.width && c->h == x.height && c->ch == x.channels) return c.get();
+      shapes.emplace_back(new Shape{ x.width, x.height, x.channels, {}, 0 });
+      return shapes.back().get();
+    };
     auto collect = [&](Slot &sl) {
       if (!sl.busy) return;
       const int rc = mi_batch_wait(sl.b);
+      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu done\n", since(), dev, sl.idx.size());
       for (size_t k = 0; k < sl.idx.size(); k++) st[sl.idx[k]] = rc == MI_OK ? mi_batch_get(sl.b, (int)k, &out[sl.idx[k]]) : rc;
       sl.busy = false;
     };
@@ -651,22 +742,24 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
         const int rc = fetch(user, i, &d[i - i0]);
         const mi_image_desc &x = d[i - i0];
         if (rc != MI_OK) st[i] = rc;
-        else if (!x.pixels || !x.width || !x.height || (x.channels != 3 && x.channels != 4)) st[i] = MI_INVALID_ARGUMENT;
-        else pending[i - i0] = 1;
+        else if (!x.pixels || !x.width || !x.height || (x.channels != 3 && x.channels != 4)) { st[i] = MI_INVALID_ARGUMENT; if (release) release(user, i); }
+        else { pending[i - i0] = 1; Shape *sh = shape_for(x); ensure_slot(sh, sh->next); }
       }
+      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: images %zu..%zu fetched\n", since(), dev, i0, i1);
       // sub-runs of equal shape inside the range
       for (size_t a = 0; a < d.size(); a++) {
         if (!pending[a]) continue;
         std::vector<size_t> run;
         for (size_t k = a; k < d.size(); k++) if (pending[k] && d[k].width == d[a].width && d[k].height == d[a].height && d[k].channels == d[a].channels) { run.push_back(k); pending[k] = 0; }
         const mi_image_desc &d0 = d[a];
-        Shape *sh = nullptr;
-        for (auto &c : shapes) if (c->w == d0.width && c->h == d0.height && c->ch == d0.channels) sh = c.get();
-        if (!sh) { shapes.emplace_back(new Shape{ d0.width, d0.height, d0.channels, {}, 0 }); sh = shapes.back().get(); }
-        Slot &sl = sh->slot[sh->next]; sh->next ^= 1;
+        Shape *sh = shape_for(d0);
+        const int j = sh->next; sh->next = (j + 1) % NSLOT;
+        Slot &sl = sh->slot[j];
         collect(sl);                                           // the slot's previous run, if any
-        if (!sl.b) sl.b = mi_batch_create(&enc, (int)max_run, d0.width, d0.height, d0.channels);
+        ensure_slot(sh, j);
+        if (sl.making.valid()) sl.b = sl.making.get();
         int rc = sl.b ? mi_batch_set_count(sl.b, (int)run.size()) : MI_ENCODING_ERROR;
+        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d ready\n", since(), dev, j);
         if (rc == MI_OK) {
           const size_t row = (size_t)d0.width * d0.channels;
           for (size_t k = 0; k < run.size(); k++) {
@@ -678,13 +771,24 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
           }
           rc = mi_batch_upload_async(sl.b, 0, (int)run.size());
         }
+        if (release) for (size_t k : run) release(user, i0 + k);   // staged (or failed): the caller's pixels are no longer read
         if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
+        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu enqueued on slot %d\n", since(), dev, run.size(), j);
         if (rc != MI_OK) { for (size_t k : run) st[i0 + k] = rc; continue; }
         sl.idx.clear(); for (size_t k : run) sl.idx.push_back(i0 + k);
         sl.busy = true;
+        // more ranges to come: have the next slot made while the GPU works on this run (not earlier: hipMalloc / hipHostMalloc
+        // on another thread hold runtime locks that stall this thread's copies and launches)
+        if (cursor.load() < n) ensure_slot(sh, sh->next);
       }
     }
-    for (auto &c : shapes) for (Slot &sl : c->slot) { collect(sl); if (sl.b) mi_batch_destroy(sl.b); }
+    for (auto &c : shapes) for (Slot &sl : c->slot) {
+      collect(sl);
+      if (sl.making.valid()) sl.b = sl.making.get();
+      pool_release(sl.b);                                      // back to the pool: the next call (or nobody, at process exit) gets them
+    }
+    warm.get();
+    if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: worker done\n", since(), dev);
   };
   std::vector<std::thread> th;
   for (int d : devs) th.emplace_back(worker, d);
@@ -697,7 +801,7 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
 static int fetch_from_array(void *user, size_t i, mi_image_desc *d) { *d = ((const mi_image_desc *)user)[i]; return MI_OK; }
 int mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev) {
   if (!e || (n && (!in || !out))) return MI_INVALID_ARGUMENT;
-  return mi_ravif_encode_stream(e, n, fetch_from_array, (void *)in, out, status, devices, ndev);
+  return mi_ravif_encode_stream(e, n, fetch_from_array, nullptr, (void *)in, out, status, devices, ndev);
 }
 int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t w, uint32_t h, size_t stride_px, mi_encoded_image *out) { return encode_one(e, rgb, 3, w, h, stride_px, out); }
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
   const FrameDev *f = frames + blockIdx.z;
   const int nsets = f->sgr_full ? 16 : 4;
   const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;
-  if (plane >= f->np || !f->enable_restoration) return;
+  if (plane >= f->np || !f->enable_restoration || frame_idle(f)) return;
   const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h);
   const int ui = blockIdx.x;
   if (ui >= ucols * urows) return;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
 __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y;
-  if (plane >= f->np || !f->enable_restoration) return;
+  if (plane >= f->np || !f->enable_restoration || frame_idle(f)) return;
   const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h);
   const int ui = blockIdx.x;
   if (ui >= ucols * urows) return;

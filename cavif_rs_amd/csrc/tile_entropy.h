@@ -331,6 +331,7 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
   const FrameDev *f = frames + tj.frame;
+  if (frame_idle(f)) { if (LANE == 0) f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = 0; return; }
   TileWriter w;
   w.f = f;
   w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);

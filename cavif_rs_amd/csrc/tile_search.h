@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
   const FrameDev *gf = frames + tj.frame;
+  if (frame_idle(gf)) return;
   Ctx<MAXN> k;
   constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
   constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;

@@ -87,10 +87,19 @@ int  mi_ravif_encode_raw_planes_10(const mi_ravif_encoder *e, uint32_t w, uint32
 typedef struct mi_image_desc { const uint8_t *pixels; uint32_t width, height; size_t stride_px /* 0 = width */; int channels /* 3 RGB8 | 4 RGBA8 */; } mi_image_desc;
 int  mi_ravif_encode_batch(const mi_ravif_encoder *e, size_t n, const mi_image_desc *in, mi_encoded_image *out, int *status, const int *devices, int ndev);
 /* streaming form: image i is pulled through `fetch` right before it is staged (the callback may block until a loader has produced
- * the pixels; they must stay valid until the call returns), so file loading overlaps the GPU work -- what rayon's work stealing gives
- * the reference when load and encode sit in one par_iter body (src/main.rs:179-223).  fetch returns MI_OK or the image's status. */
+ * the pixels), so file loading overlaps the GPU work -- what rayon's work stealing gives the reference when load and encode sit in
+ * one par_iter body (src/main.rs:179-223).  fetch returns MI_OK or the image's status.  `release` (nullable) is called once per
+ * successfully fetched image as soon as its pixels have been copied into the pinned staging: the caller may free them and let its
+ * loaders run further ahead (bounded host memory for any number of files).  Without it the pixels must stay valid until the call
+ * returns.  Indices are fetched in increasing order per device thread; both callbacks may be called from several threads. */
 typedef int (*mi_fetch_fn)(void *user, size_t index, mi_image_desc *desc);
-int  mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev);
+typedef void (*mi_release_fn)(void *user, size_t index);
+int  mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetch, mi_release_fn release, void *user, mi_encoded_image *out, int *status, const int *devices, int ndev);
+
+/* The one-call entry points above (mi_ravif_encode_rgba / _rgb / _batch / _stream) keep their device arenas and pinned staging in
+ * a process-wide pool keyed by (device, shape, settings), so a loop of calls with the same settings pays the allocation once
+ * (what a long-lived rav1e thread pool is to the reference).  At most 12 objects / 96 GB are retained; this frees them now. */
+void mi_release_cached(void);
 
 /* PNG -> RGBA8 as cavif's load_rgba does (src/main.rs:265-283: RGB gets alpha 255, 16-bit samples keep their high byte, gray is
  * replicated); all colour types, bit depths, tRNS and Adam7.  Host code over zlib.  *rgba is malloc'd (mi_free), w*h*4 bytes. */

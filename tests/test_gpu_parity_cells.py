@@ -131,3 +131,47 @@ def test_full_size_configs_equal_oracle_vectors(avifdec, name):
     if g['alpha']:
         assert np.array_equal(d['alpha'], b.recon(0, alpha=True)[0])
     b.close()
+
+
+def test_pooled_batch_objects_give_the_same_bytes(oracle):
+    """The one-call entry points reuse pooled batch objects (mi_avif.hip pool_acquire): a loop of encode_rgba calls with the same
+    settings, interleaved with another shape / other settings / Exif, must give the same files as fresh objects."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    L = m.load_library()
+    L.mi_release_cached.restype = None
+    e = m.Encoder().with_quality(72).with_speed(6)
+    a, b2, c = synth_image(160, 96, index=11, alpha=True), synth_image(160, 96, index=12, alpha=True), synth_image(96, 64, index=13)
+    opaque = np.dstack([c, np.full(c.shape[:2], 255, np.uint8)])
+    first = [e.encode_rgba(a).avif_file, e.encode_rgba(b2).avif_file, e.encode_rgba(opaque).avif_file]
+    for im, want in zip((a, b2), first):
+        ref, _, _ = oracle.ravif_encode(im, quality=72, alpha_quality=80, speed=6)
+        assert want == ref
+    # same shape again: opaque image through an object that last carried an alpha frame, and the other way round
+    opaque160 = a.copy(); opaque160[..., 3] = 255
+    got = e.encode_rgba(opaque160)
+    assert got.alpha_byte_size == 0
+    ref, _, _ = oracle.ravif_encode(opaque160, quality=72, alpha_quality=80, speed=6)
+    assert got.avif_file == ref
+    again = [e.encode_rgba(a).avif_file, e.encode_rgba(b2).avif_file, e.encode_rgba(opaque).avif_file]
+    assert again == first
+    with_exif = e.with_exif(b'Exif\x00\x00II*\x00\x08\x00\x00\x00\x00\x00').encode_rgba(a).avif_file
+    assert with_exif != first[0] and b'Exif' in with_exif
+    assert e.encode_rgba(a).avif_file == first[0]                      # the pooled object does not keep the Exif of its last user
+    L.mi_release_cached()
+    assert e.encode_rgba(a).avif_file == first[0]
+    L.mi_release_cached()
+
+
+def test_near_lossless_noise_grows_the_packed_buffers(oracle):
+    """quality 100 on noise: the payload exceeds the initial 1/16 share of the worst-case packed size (mi_batch_wait grows the
+    device / pinned pair); bytes still equal the oracle's."""
+    import cavif_rs_amd as m
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, size=(96, 160, 3), dtype=np.uint8)
+    e = m.Encoder().with_quality(100).with_speed(8).with_bit_depth(10)
+    got = e.encode_rgb(im)
+    assert got.color_byte_size > 96 * 160 * 3 * 2 // 16
+    ref, _, _ = oracle.ravif_encode(im, quality=100, speed=8, depth=10)
+    assert got.avif_file == ref
+    assert e.encode_rgb(im).avif_file == ref                     # the grown pair is kept (pooled object)
