@@ -42,9 +42,10 @@ struct FrameDev {
   const uint32_t *act, *svar8, *svar4; int tune_psnr;
   uint8_t *snap;             // area snapshots, per tile: MI_SNAP_BYTES
   int dbg;                   // debug bisect level (0 = off; probe builds only)
+  const uint16_t *cost;      // static rate table [CDF_TOTAL] (cost per symbol in 1/512 bit, same flat layout as the CDF context)
+  // ---- tail: frame-level stages and the entropy coder ----
   unsigned long long *prof_out;  // profiling builds: per launch-wide tile job, 4 waves x 16 phase cycle counters
   unsigned long long *tile_clk;  // per tile: [start, end] of K1 and of K4 in wall_clock64 ticks (100 MHz), 4 values
-  // ---- tail: frame-level stages and the entropy coder ----
   uint16_t *fin[3];                        // post-CDEF output
   uint16_t *lrp[3];                        // post-loop-restoration output (the final picture when enable_restoration)
   uint8_t *lr_type, *lr_set; int8_t *lr_xqd;   // per (plane, restoration unit): 0 none / 1 sgrproj, parameter set, xqd[2]
@@ -55,9 +56,7 @@ struct FrameDev {
   // tiles (SB units)
   int tile_rows, tile_cols_log2, tile_rows_log2;
   int tile_col_start[MI_MAX_TILE_COLS + 1], tile_row_start[MI_MAX_TILE_ROWS + 1];
-  // static rate table (cost per symbol in 1/512 bit, same flat layout as the CDF context) + initial CDFs
-  const uint16_t *cost;      // [CDF_TOTAL]
-  const uint16_t *cdf0;      // [CDF_TOTAL]
+  const uint16_t *cdf0;      // initial CDFs [CDF_TOTAL]
   // loop filter / cdef
   int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
   long long *lf_tally;       // deblock level search: [3 planes][2 passes][65] SSE-delta difference arrays (zeroed per encode)
@@ -86,6 +85,21 @@ __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int iclamp_(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs_(int a) { return a < 0 ? -a : a; }
 __device__ __forceinline__ int round2_(int x, int n) { return n == 0 ? x : (x + (1 << (n - 1))) >> n; }
+
+// run-time indexed small tables without a memory lookup: 4-bit / 8-bit entries packed into a 64-bit immediate
+__device__ __forceinline__ int lut4(unsigned long long tab, int i) { return (int)((tab >> (4 * i)) & 15); }
+__device__ __forceinline__ int lut8(unsigned long long tab, int i) { return (int)((tab >> (8 * i)) & 255); }
+// nominal prediction angle of the directional modes V, H, D45, D135, D113, D157, D203, D67 (mode 1..8; 0 for DC)
+__device__ __forceinline__ int mode_angle_of(int m) { return m == 8 ? 67 : lut8(0xcb9d71872db45a00ULL, m); }
+// above / left intra mode -> KF y-mode context (spec Intra_Mode_Context)
+__device__ __forceinline__ int intra_mode_ctx(int m) { return lut4(0x210344443210ULL, m); }
+
+// Wave-uniform values the compiler cannot prove uniform (results of calls, values loaded from memory): pin them to SGPRs.  What
+// stays live across a call to the (no-callee-saved-registers) block search is then kept by v_writelane instead of scratch.
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+  return (long long)(((unsigned long long)(uint32_t)uni32((int)((unsigned long long)v >> 32)) << 32) | (uint32_t)uni32((int)v));
+}
 
 // Wave-wide reductions on the DPP network (no LDS round trips): quad_perm, row_half_mirror, row_mirror,
 // row_bcast:15, row_bcast:31; the total lands in lane 63 and is broadcast through an SGPR.
@@ -152,8 +166,9 @@ __device__ __forceinline__ int tx_set_of(int txs, int reduced) { return txs >= 3
 __device__ __forceinline__ int tx_set_count(int set) { return set == 0 ? 1 : (set == 1 ? 7 : 5); }
 __device__ __forceinline__ int sym_to_txtype(int set, int s) {
   if (set == 0) return DCT_DCT;
-  if (set == 1) { const int t[7] = { IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST }; return t[s]; }
-  const int t2[5] = { IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST }; return t2[s];
+  // (tables as packed 4-bit constants: a const array indexed at run time becomes a global-memory lookup, ~1 us on the block search's critical path)
+  if (set == 1) return lut4(0x213ba09ULL, s);            // IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST
+  return lut4(0x21309ULL, s);                             // IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST
 }
 __device__ __forceinline__ int txtype_to_sym(int set, int t) {
   const int n = tx_set_count(set);
@@ -161,8 +176,8 @@ __device__ __forceinline__ int txtype_to_sym(int set, int t) {
   return -1;
 }
 __device__ __forceinline__ int mode_to_txtype(int m) {
-  const int t[14] = { DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT, ADST_ADST, ADST_DCT, DCT_ADST, ADST_ADST, DCT_DCT };
-  return t[m];
+  // DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT, ADST_ADST, ADST_DCT, DCT_ADST, ADST_ADST, DCT_DCT
+  return lut4(0x3213122130210ULL, m);
 }
 __device__ __forceinline__ int tx_class_of(int t) {
   if (t == V_DCT || t == V_ADST || t == V_FLIPADST) return TXC_VERT;

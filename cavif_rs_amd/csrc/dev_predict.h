@@ -60,23 +60,20 @@ __device__ inline void load_edges(const LDS FrameDev *f, int plane, int x, int y
   const uint16_t *rec = f->rec[plane];
   const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
   const int tot = 2 * n;
-  for (int i = LANE; i < tot; i += 64) {
-    uint16_t a, l;
-    if (!have_above && have_left) a = rec[y * rs + x - 1];
-    else if (!have_above && !have_left) a = (uint16_t)((1 << (bd - 1)) - 1);
-    else { const int lim = imin_(max_x, x + (have_ar ? 2 * n : n) - 1); a = rec[(y - 1) * rs + imin_(lim, x + i)]; }
-    if (!have_left && have_above) l = rec[(y - 1) * rs + x];
-    else if (!have_left && !have_above) l = (uint16_t)((1 << (bd - 1)) + 1);
-    else { const int lim = imin_(max_y, y + (have_bl ? 2 * n : n) - 1); l = rec[imin_(lim, y + i) * rs + x - 1]; }
-    above[i] = a; left[i] = l;
-  }
-  if (LANE == 0) {
-    uint16_t c;
-    if (have_above && have_left) c = rec[(y - 1) * rs + x - 1];
-    else if (have_above) c = rec[(y - 1) * rs + x];
-    else if (have_left) c = rec[y * rs + x - 1];
-    else c = (uint16_t)(1 << (bd - 1));
-    above[-1] = c; left[-1] = c;
+  // index tot is the corner; every sample comes from one unconditional load per edge (addresses selected, not the loads)
+  const int na = x + (have_ar ? 2 * n : n) - 1, nl = y + (have_bl ? 2 * n : n) - 1;
+  const int lim_a = imin_(max_x, na), lim_l = imin_(max_y, nl);
+  for (int i = LANE; i <= tot; i += 64) {
+    const bool corner = i == tot;
+    int ia, il;
+    if (have_above) ia = (y - 1) * rs + (corner ? (have_left ? x - 1 : x) : imin_(lim_a, x + i));
+    else ia = y * rs + (have_left ? x - 1 : x);                  // no row above: the left neighbour's sample (or, with no neighbour at all, any valid address)
+    if (have_left) il = imin_(lim_l, y + i) * rs + x - 1;
+    else il = (have_above ? y - 1 : y) * rs + x;
+    uint16_t a = rec[ia], l = rec[il];
+    if (!have_above && !have_left) { a = (uint16_t)(corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1); l = (uint16_t)((1 << (bd - 1)) + 1); }
+    if (corner) { above[-1] = a; left[-1] = a; }
+    else { above[i] = a; left[i] = l; }
   }
   WAVE_SYNC();
 }
@@ -152,8 +149,7 @@ __device__ inline void predict_block(const LDS FrameDev *f, int x, int y, int lo
       pred[idx] = (uint16_t)p;
     }
   } else {
-    const int mode_angle[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
-    const int pa = mode_angle[mode] + angle_delta * 3;
+    const int pa = mode_angle_of(mode) + angle_delta * 3;
     // working copies of the edges
     for (int i = LANE; i < 2 * n + 1; i += 64) { wa[i - 1] = ra[i - 1]; wl[i - 1] = rl[i - 1]; }
     WAVE_SYNC();

@@ -6,19 +6,17 @@
 #include "dev_common.h"
 
 // all_zero and dc_sign contexts from the level/dc maps left by the neighbours (inside the tile only)
-template <typename FP> __device__ inline void txb_ctx_dev(FP f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
+template <typename FP, typename TP> __device__ inline void txb_ctx_dev(FP f, TP t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
   const int w4 = 1 << txs, ms = f->mi_stride;
   int top = 0, left = 0, dcs = 0, any_a = 0, any_l = 0;
   const int k = LANE;
   if (k < w4) {
-    if (r4 - 1 >= t->mi_row_start && c4 + k < f->mi_cols) {
-      const int l = f->m_lvl[plane][(r4 - 1) * ms + c4 + k], d = f->m_dc[plane][(r4 - 1) * ms + c4 + k];
-      top = l; any_a = l | d; dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-    }
-    if (c4 - 1 >= t->mi_col_start && r4 + k < f->mi_rows) {
-      const int l = f->m_lvl[plane][(r4 + k) * ms + c4 - 1], d = f->m_dc[plane][(r4 + k) * ms + c4 - 1];
-      left = l; any_l = l | d; dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-    }
+    // both neighbours with unconditional loads (clamped to the block's own cell where there is none): one round trip, not two
+    const bool ha = r4 - 1 >= t->mi_row_start && c4 + k < f->mi_cols, hl = c4 - 1 >= t->mi_col_start && r4 + k < f->mi_rows;
+    const int ia = ha ? (r4 - 1) * ms + c4 + k : r4 * ms + c4, il = hl ? (r4 + k) * ms + c4 - 1 : r4 * ms + c4;
+    const int la = f->m_lvl[plane][ia], da = f->m_dc[plane][ia], ll = f->m_lvl[plane][il], dl = f->m_dc[plane][il];
+    if (ha) { top = la; any_a = la | da; dcs += da == 1 ? -1 : (da == 2 ? 1 : 0); }
+    if (hl) { left = ll; any_l = ll | dl; dcs += dl == 1 ? -1 : (dl == 2 ? 1 : 0); }
   }
   top = wave_max_i32(top); left = wave_max_i32(left); dcs = wave_sum_i32(dcs);
   any_a = wave_or_i32(any_a); any_l = wave_or_i32(any_l);
@@ -90,20 +88,27 @@ __device__ __forceinline__ int coef_cost_entries(int maxtxs) {
 }
 #define COEF_COST_MAX_ENTRIES(maxtxs) (((maxtxs) + 1) * (13 * 3 + 18 * 3 + 84 * 5 + 8 * 4) + 18 + ((maxtxs) < 3 ? (maxtxs) + 1 : 4) * 42 * 5 + 4 * (6 + 8 + 10 + 12))
 // all threads of the workgroup copy; returns the table pointers
-__device__ inline void load_coef_cost(CoefCost *cc, LDS uint16_t *dst, const uint16_t *cost, int maxtxs, int tid, int nthreads) {
+// Where each slice of the rate table sits behind `dst` (a pure function of dst and maxtxs: callers that know both at compile
+// time get constant LDS addresses, nothing is kept in registers or on the stack), and where it comes from in the flat table.
+__device__ __forceinline__ CoefCost coef_cost_layout(const LDS uint16_t *dst, int maxtxs, int *src_off = nullptr, int *count = nullptr) {
   const int t = maxtxs + 1, tb = imin_(maxtxs, 3) + 1;
+  const int src[10] = { CDF_TXB_SKIP, CDF_EOB_EXTRA, CDF_DC_SIGN, CDF_COEFF_BR, CDF_COEFF_BASE, CDF_COEFF_BASE_EOB, CDF_EOB_PT_16, CDF_EOB_PT_64, CDF_EOB_PT_256, CDF_EOB_PT_1024 };
+  const int cnt[10] = { t * 13 * CDF_TXB_SKIP_STRIDE, t * 18 * CDF_EOB_EXTRA_STRIDE, 6 * CDF_DC_SIGN_STRIDE, tb * 42 * CDF_COEFF_BR_STRIDE, t * 84 * CDF_COEFF_BASE_STRIDE,
+                        t * 8 * CDF_COEFF_BASE_EOB_STRIDE, 4 * CDF_EOB_PT_16_STRIDE, 4 * CDF_EOB_PT_64_STRIDE, 4 * CDF_EOB_PT_256_STRIDE, 4 * CDF_EOB_PT_1024_STRIDE };
+  int o[10]; int acc = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) { o[i] = acc; acc += cnt[i]; if (src_off) src_off[i] = src[i]; if (count) count[i] = cnt[i]; }
+  CoefCost cc;
+  cc.txb = dst + o[0]; cc.eobx = dst + o[1]; cc.dcs = dst + o[2]; cc.br = dst + o[3]; cc.base = dst + o[4]; cc.beob = dst + o[5];
+  cc.eobpt[0] = dst + o[6]; cc.eobpt[1] = dst + o[7]; cc.eobpt[2] = dst + o[8]; cc.eobpt[3] = dst + o[9];
+  return cc;
+}
+// all threads of the workgroup copy the slices
+__device__ inline void load_coef_cost(LDS uint16_t *dst, const uint16_t *cost, int maxtxs, int tid, int nthreads) {
+  int src[10], cnt[10];
+  coef_cost_layout(dst, maxtxs, src, cnt);
   int o = 0;
-  auto take = [&](int src_off, int count) { LDS uint16_t *p = dst + o; for (int i = tid; i < count; i += nthreads) p[i] = cost[src_off + i]; o += count; return (const LDS uint16_t *)p; };
-  cc->txb = take(CDF_TXB_SKIP, t * 13 * CDF_TXB_SKIP_STRIDE);
-  cc->eobx = take(CDF_EOB_EXTRA, t * 18 * CDF_EOB_EXTRA_STRIDE);
-  cc->dcs = take(CDF_DC_SIGN, 6 * CDF_DC_SIGN_STRIDE);
-  cc->br = take(CDF_COEFF_BR, tb * 42 * CDF_COEFF_BR_STRIDE);
-  cc->base = take(CDF_COEFF_BASE, t * 84 * CDF_COEFF_BASE_STRIDE);
-  cc->beob = take(CDF_COEFF_BASE_EOB, t * 8 * CDF_COEFF_BASE_EOB_STRIDE);
-  cc->eobpt[0] = take(CDF_EOB_PT_16, 4 * CDF_EOB_PT_16_STRIDE);
-  cc->eobpt[1] = take(CDF_EOB_PT_64, 4 * CDF_EOB_PT_64_STRIDE);
-  cc->eobpt[2] = take(CDF_EOB_PT_256, 4 * CDF_EOB_PT_256_STRIDE);
-  cc->eobpt[3] = take(CDF_EOB_PT_1024, 4 * CDF_EOB_PT_1024_STRIDE);
+  for (int k = 0; k < 10; k++) { for (int i = tid; i < cnt[k]; i += nthreads) dst[o + i] = cost[src[k] + i]; o += cnt[k]; }
 }
 
 template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(const CoefCost &cc, CostPtr cost, const LDS uint16_t *ls, const LDS int32_t *qc, int eob, int plane, int txs, int txtype,

@@ -159,8 +159,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     if (!skip && f->enable_cdef) {
       if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
-    const int *imc = intra_mode_ctx_tab();
-    const int am = imc[availU ? f->m_ymode[mi - ms] : DC_PRED], lm = imc[availL ? f->m_ymode[mi - 1] : DC_PRED];
+    const int am = intra_mode_ctx(availU ? f->m_ymode[mi - ms] : DC_PRED), lm = intra_mode_ctx(availL ? f->m_ymode[mi - 1] : DC_PRED);
     re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
     if (BS >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
       re_symbol_dev(e, f->m_angle_y[mi] + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);

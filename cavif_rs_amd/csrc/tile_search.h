@@ -17,6 +17,9 @@
 #include "dev_rate.h"
 #include "dev_group.h"
 
+#ifndef MI_K1_TRY_ATTR
+#define MI_K1_TRY_ATTR __attribute__((not_tail_called))
+#endif
 #ifndef MI_K1_INLINE
 #define MI_K1_INLINE
 #endif
@@ -81,6 +84,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint8_t nb_top[16][2], nb_left[16][2];
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
   uint16_t split_rec[N <= 16 ? 1 : N * N];
+  TileB tile; uint8_t *snap;                       // the tile's bounds (mi units) and its snapshot area (per-tile constants of Ctx)
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -88,12 +92,29 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
 
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
 
-template <int MAXN> struct Ctx {
-  const LDS FrameDev *f; TileB t; LDS WaveScratch<MAXN> *s; LDS SharedScratch<MAXN> *sh; uint8_t *snap;
-  const uint16_t *cost; const LDS uint16_t *ls; CoefCost cc;
+// What the block search needs to find its working set.  Everything lives in the workgroup's LDS block at offsets fixed by
+// (MAXN, NW) -- shared scratch, per-wave scratch, scan tables, coefficient cost slices, the frame descriptor head -- so the
+// context is two 32-bit LDS pointers passed BY VALUE (registers): the accessors fold into ds_read offsets.  (It used to be a
+// struct on the kernel's stack passed by reference: every use inside the non-inlined block search was a flat load from scratch,
+// ~40 per call, each holding both wait counters.)
+template <int MAXN, int NW> struct Ctx {
+  static constexpr int MAXBS = MAXN == 16 ? 2 : (MAXN == 32 ? 3 : 4);
+  static constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
+  static constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
+  static constexpr size_t LS_OFF = SH_BYTES + NW * WS_BYTES, CC_OFF = LS_OFF + SC_BYTES, F_OFF = CC_OFF + CC_BYTES;
+  LDS uint8_t *base;                  // the workgroup's LDS block (wave-uniform)
+  LDS WaveScratch<MAXN> *ws;          // this wave's scratch inside it
+  __device__ __forceinline__ LDS SharedScratch<MAXN> *sh() const { return (LDS SharedScratch<MAXN> *)base; }
+  __device__ __forceinline__ LDS WaveScratch<MAXN> *s() const { return ws; }
+  __device__ __forceinline__ const LDS uint16_t *ls() const { return (const LDS uint16_t *)(base + LS_OFF); }
+  __device__ __forceinline__ LDS uint16_t *cc_base() const { return (LDS uint16_t *)(base + CC_OFF); }
+  __device__ __forceinline__ CoefCost cc() const { return coef_cost_layout(cc_base(), MAXBS); }
+  __device__ __forceinline__ const LDS FrameDev *f() const { return (const LDS FrameDev *)(base + F_OFF); }
+  __device__ __forceinline__ const LDS TileB *t() const { return &sh()->tile; }
+  __device__ __forceinline__ uint8_t *snap() const { return sh()->snap; }
+  __device__ __forceinline__ const uint16_t *cost() const { return f()->cost; }
 };
 
-__device__ __forceinline__ const int *intra_mode_ctx_tab() { static __device__ const int t[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 }; return t; }
 #define IS_SMOOTH_(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
 #define J_INF 0x7fffffffffffffffLL
 
@@ -172,16 +193,35 @@ template <int n> __device__ inline long long psy_dist_wave(const LDS uint16_t *s
   return (long long)wave_sum_i32(dist);
 }
 
+// Rate of a candidate's mode symbols from the static table.  Every entry is fetched with an UNCONDITIONAL load (entry 0 of its table
+// where the symbol is not coded), so the loads leave as one batch; written as `if (coded) rate += cost[...]` each of them was a
+// separate round trip to L2 inside its own branch.
+__device__ __forceinline__ uint32_t y_mode_rate(const uint16_t *cost, const uint16_t *ycost, int m, bool angle_coded, int delta) {
+  const uint32_t r_mode = ycost[m], r_ang = cost[CDF_ANGLE + (angle_coded ? (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3 : 0)];
+  return r_mode + (angle_coded ? r_ang : 0u);
+}
+__device__ __forceinline__ uint32_t uv_mode_rate(const uint16_t *cost, const uint16_t *uvcost, int um, bool angle_coded, int delta, bool cfl, int alpha_u, int alpha_v, int *jsign) {
+  const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
+  const int js = cfl ? su * 3 + sv - 1 : 0;
+  const uint32_t r_mode = uvcost[um];
+  const uint32_t r_ang = cost[CDF_ANGLE + (angle_coded ? (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3 : 0)];
+  const uint32_t r_sign = cost[CDF_CFL_SIGN + js];
+  const uint32_t r_au = cost[CDF_CFL_ALPHA + ((cfl && su) ? ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_u) - 1 : 0)];
+  const uint32_t r_av = cost[CDF_CFL_ALPHA + ((cfl && sv) ? ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_v) - 1 : 0)];
+  *jsign = js;
+  return r_mode + (angle_coded ? r_ang : 0u) + (cfl ? r_sign + (su ? r_au : 0u) + (sv ? r_av : 0u) : 0u);
+}
+
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
-template <int MAXN, int BS>
-__device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+template <int MAXN, int BS, int NW>
+__device__ inline long long eval_tx(const Ctx<MAXN, NW> k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr,
                                     const LDS int *psv = nullptr, const LDS int *pact = nullptr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
-  const LDS FrameDev *f = k.f; LDS WaveScratch<MAXN> *S = k.s;
-  const LDS uint16_t *src = src_override ? src_override : k.sh->srcb[plane];
+  const LDS FrameDev *f = k.f(); LDS WaveScratch<MAXN> *S = k.s();
+  const LDS uint16_t *src = src_override ? src_override : k.sh()->srcb[plane];
 #if MI_PROFILE
-  LDS SharedScratch<MAXN> *SH = k.sh; const int W = WAVE_ID;
+  LDS SharedScratch<MAXN> *SH = k.sh(); const int W = WAVE_ID;
 #endif
   PH_BEGIN();
   for (int idx = LANE; idx < n * n; idx += 64) {
@@ -193,15 +233,15 @@ __device__ inline long long eval_tx(Ctx<MAXN> &k, int plane, int sctx, int dctx,
   PH(16);
   fwd_txfm2d_dev<n>(S->tbuf, S->cbuf, txtype);
   PH(17);
-  const int eob = quant_rate_dev<CS>(k.cc, k.cost, k.ls, S->cbuf, qc_out, S->lev, plane, BS, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane],
+  const int eob = quant_rate_dev<CS>(k.cc(), k.cost(), k.ls(), S->cbuf, qc_out, S->lev, plane, BS, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane],
                                      f->bd, sctx, dctx, tx_off, tx_sym, &tr->rate, &tr->cul, &tr->dcc);
   PH(19);
   if (eob > 0) inv_txfm2d_add_dev<n>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
   tr->eob = eob;
   PH(20);
   // distortion: luma = psychovisual cdef-dist per 8x8 cell x activity; chroma = SSE x the block's mean activity
-  if (plane == 0 && !f->tune_psnr) tr->sse = psy_dist_wave<n>(src, rec_out, psv ? psv : (const LDS int *)k.sh->psv, pact ? pact : (const LDS int *)k.sh->pact, f->bd);
-  else { const long long e = sse_dev(src, rec_out, n * n); tr->sse = plane == 0 ? e : (e * k.sh->cact + 8192) >> 14; }
+  if (plane == 0 && !f->tune_psnr) tr->sse = psy_dist_wave<n>(src, rec_out, psv ? psv : (const LDS int *)k.sh()->psv, pact ? pact : (const LDS int *)k.sh()->pact, f->bd);
+  else { const long long e = sse_dev(src, rec_out, n * n); tr->sse = plane == 0 ? e : (e * k.sh()->cact + 8192) >> 14; }
   PH(21);
   return ((tr->sse * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
 }
@@ -223,20 +263,31 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
 // undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
 // reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
 template <int MAXN, int BS, int NW>
-__device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long long budget = J_INF) {
+// not_tail_called: with every argument in registers the calls would be marked `tail`, and LLVM's interprocedural register
+// allocation then refuses its no-callee-saved-registers treatment for this function (TargetFrameLowering::isSafeForNoCSROpt):
+// the prologue / epilogue would spill and reload 46 VGPRs + 34 SGPRs per call.
+__device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
-  const LDS FrameDev *f = k.f; const TileB *t = &k.t; LDS WaveScratch<MAXN> *S = k.s; LDS SharedScratch<MAXN> *SH = k.sh;
+  const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
   const int ms = f->mi_stride, mi = r * ms + c, x = c * 4, y = r * 4;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int have_ar = availU && (c + n4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + n4];
-  const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
-  const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
-  const int *imc = intra_mode_ctx_tab();
-  const uint16_t *ycost = k.cost + CDF_KF_Y + (imc[amode] * 5 + imc[lmode]) * CDF_KF_Y_STRIDE;
-  const int ftype_y = (availU && IS_SMOOTH_(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH_(f->m_ymode[mi - 1]));
-  int ftype_uv = 0;
-  if (f->np > 1) ftype_uv = (availU && IS_SMOOTH_(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH_(f->m_uvmode[mi - 1]));
+  // Neighbour context of the block, fetched as ONE batch of unconditional loads: where a neighbour lies outside the tile the load
+  // goes to the block's own cell (always addressable) and the value is replaced afterwards.  Written as `cond ? map[i] : dflt` each
+  // load sat in its own branch with its own s_waitcnt -- a dozen serial round trips to L2 at the head of every block evaluation.
+  const int can_ar = availU && (c + n4 < t->mi_col_end), can_bl = availL && (r + n4 < t->mi_row_end);
+  const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
+  const int v_ar = f->m_decoded[can_ar ? (r - 1) * ms + c + n4 : mi], v_bl = f->m_decoded[can_bl ? (r + n4) * ms + c - 1 : mi];
+  const int v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL];
+  const int v_uvU = f->np > 1 ? f->m_uvmode[iU] : 0, v_uvL = f->np > 1 ? f->m_uvmode[iL] : 0;
+  const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
+  const int have_ar = can_ar && uni32(v_ar), have_bl = can_bl && uni32(v_bl);
+  const int amode = availU ? uni32(v_ymU) : DC_PRED, lmode = availL ? uni32(v_ymL) : DC_PRED;
+  const int nb_skip = (availU ? uni32(v_skU) : 0) + (availL ? uni32(v_skL) : 0);                      // skip context
+  const int nb_txU = availU ? uni32(v_txU) : -1, nb_txL = availL ? uni32(v_txL) : -1;                   // tx-size context (-1: no neighbour)
+  const uint16_t *ycost = k.cost() + CDF_KF_Y + (intra_mode_ctx(amode) * 5 + intra_mode_ctx(lmode)) * CDF_KF_Y_STRIDE;
+  const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);                                           // DC_PRED (no neighbour) is not smooth
+  const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uni32(v_uvU))) || (availL && IS_SMOOTH_(uni32(v_uvL))));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
   PH_BEGIN();
 
@@ -271,7 +322,6 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
   constexpr bool SMALL_GROUPED = BS <= BS_8 && NW == 4 && MAXN <= 16;
-  const int mode_angle_t[9] = { 0, 90, 180, 45, 135, 113, 157, 203, 67 };
   if constexpr (SMALL_GROUPED) {
     // 4x4 / 8x8: the eight directional modes run four per wave (one prediction angle per 16-lane row, dev_group.h) on
     // waves 0 and 1 -- rows sorted so that a wave's rows mostly share the interpolation branch --, the five others
@@ -280,7 +330,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int g = GROUP_ID;
       const int m = W == 0 ? (g == 0 ? V_PRED : g == 1 ? H_PRED : g == 2 ? D45_PRED : D67_PRED) : D135_PRED + g;
       LDS GroupPredBuf *gp = &S->gpred[g];
-      predict_dir_group<n>(f, x, y, availL, availU, mode_angle_t[m], ftype_y, ra, rl, gp);
+      predict_dir_group<n>(f, x, y, availL, availU, mode_angle_of(m), ftype_y, ra, rl, gp);
       const int sd = satd_group<n>(SH->srcb[0], gp->pred);
       if (GROUP_LANE == 0) SH->satd[m] = (long long)sd;
     } else {
@@ -330,7 +380,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   PH(4);
   const int ncand = f->complex_modes ? 7 : 3;
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
-  const int dl[6] = { -1, 1, -2, 2, -3, 3 };
+  auto dl_of = [](int q) { const int a = (q >> 1) + 1; return (q & 1) ? a : -a; };        // -1, 1, -2, 2, -3, 3
   const int refine = BS >= BS_8 && f->fine_directional;
   bool refine_grouped = false;
   if constexpr (SMALL_GROUPED) refine_grouped = refine && ncand == 3;
@@ -346,7 +396,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int m1 = SH->order[W < 3 ? W : (pass == 0 ? 0 : 2)], m2 = SH->order[W == 3 && pass == 0 ? 1 : (W < 3 ? W : 2)];
       if ((m1 >= V_PRED && m1 <= D67_PRED) || (m2 >= V_PRED && m2 <= D67_PRED)) {          // wave-uniform: anything to do in this pass?
         LDS GroupPredBuf *gp = &S->gpred[g];
-        predict_dir_group<n>(f, x, y, availL, availU, live ? mode_angle_t[m] + 3 * dl[q] : 90, ftype_y, ra, rl, gp);
+        predict_dir_group<n>(f, x, y, availL, availU, live ? mode_angle_of(m) + 3 * dl_of(q) : 90, ftype_y, ra, rl, gp);
         const int sd = satd_group<n>(SH->srcb[0], gp->pred);
         if (live && GROUP_LANE == 0) SH->dsd[ci][q] = (long long)sd;
       }
@@ -359,7 +409,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     for (int u = W; u < ncand * 6; u += NW) {
       const int ci = u / 6, q = u - ci * 6, m = SH->order[ci];
       if (m >= V_PRED && m <= D67_PRED) {
-        predict_block(f, x, y, log2w, availL, availU, m, dl[q], ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+        predict_block(f, x, y, log2w, availL, availU, m, dl_of(q), ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
         const long long sd = satd_dev(SH->srcb[0], S->pred, n);
         if (LANE == 0) SH->dsd[ci][q] = sd;
       }
@@ -387,7 +437,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       int delta = 0;
       if (m >= V_PRED && m <= D67_PRED && refine) {
         long long bsd = SH->satd[m];
-        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
+        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl_of(q); } }
       }
       predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, SH->lpred + ci * nn);
       if (LANE == 0) SH->ldelta[ci] = delta;
@@ -414,15 +464,14 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
         const bool live = e >= 0 && e < total;
         const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
         const int delta = SH->ldelta[ci];
-        uint32_t mode_rate = ycost[m];
-        if (m >= V_PRED && m <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+        const uint32_t mode_rate = y_mode_rate(k.cost(), ycost, m, m >= V_PRED && m <= D67_PRED && BS >= BS_8, delta);
         int ns2, set2;
         const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
         int txtype;
         if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
         else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
         GroupRes gr;
-        eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
+        eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
                       tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, f->tune_psnr ? -1 : SH->psv[0], SH->pact[0], &gr);
         long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (!live) j = J_INF;
@@ -456,19 +505,18 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     else {
       if (directional && refine) {
         long long bsd = SH->satd[m];
-        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl[q]; } }
+        for (int q = 0; q < 6; q++) { const long long sd = SH->dsd[ci][q]; if (sd < bsd) { bsd = sd; delta = dl_of(q); } }
       }
       predict_block(f, x, y, log2w, availL, availU, m, delta, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
     }
-    uint32_t mode_rate = ycost[m];
-    if (directional && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+    const uint32_t mode_rate = y_mode_rate(k.cost(), ycost, m, directional && BS >= BS_8, delta);
     int ns2, set2;
     const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
     int txtype;
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
     TxRes tr;
-    long long j = eval_tx<MAXN, BS>(k, 0, sctx_p[0], dctx_p[0], lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
+    long long j = eval_tx<MAXN, BS, NW>(k, 0, sctx_p[0], dctx_p[0], lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
   }
@@ -510,8 +558,8 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   // of the sub-block are dealt to the waves (16-lane rows for 4x4 / 8x8 transforms) like the candidates of a block.
   if constexpr (BS > 0) if (f->tx_mode_select) {
     const int maxw = 4 << BS;
-    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
-    const uint16_t *dcost = k.cost + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
+    const int actx = nb_txU >= 0 && (4 << nb_txU) >= maxw, lctx = nb_txL >= 0 && (4 << nb_txL) >= maxw;
+    const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
     if (tx_trial) {
       constexpr int SBS = BS - 1, hn = n >> 1, half = n4 >> 1, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
@@ -528,16 +576,16 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       if (W == 0) {
         if (LANE < n4) {
           const int k2 = LANE;
-          int l = 0, d = 0;
-          if (availU && c + k2 < f->mi_cols) { l = f->m_lvl[0][(r - 1) * ms + c + k2]; d = f->m_dc[0][(r - 1) * ms + c + k2]; }
-          SH->nb_top[k2][0] = (uint8_t)l; SH->nb_top[k2][1] = (uint8_t)d;
-          l = 0; d = 0;
-          if (availL && r + k2 < f->mi_rows) { l = f->m_lvl[0][(r + k2) * ms + c - 1]; d = f->m_dc[0][(r + k2) * ms + c - 1]; }
-          SH->nb_left[k2][0] = (uint8_t)l; SH->nb_left[k2][1] = (uint8_t)d;
+          const bool ha = availU && c + k2 < f->mi_cols, hl = availL && r + k2 < f->mi_rows;         // unconditional loads, one batch
+          const int ia = ha ? (r - 1) * ms + c + k2 : mi, il = hl ? (r + k2) * ms + c - 1 : mi;
+          const int la = f->m_lvl[0][ia], da = f->m_dc[0][ia], ll = f->m_lvl[0][il], dl2 = f->m_dc[0][il];
+          SH->nb_top[k2][0] = (uint8_t)(ha ? la : 0); SH->nb_top[k2][1] = (uint8_t)(ha ? da : 0);
+          SH->nb_left[k2][0] = (uint8_t)(hl ? ll : 0); SH->nb_left[k2][1] = (uint8_t)(hl ? dl2 : 0);
         }
         if (LANE == 0) {
-          const int ar3 = (c + n4 < t->mi_col_end) && f->m_decoded[(r + half - 1) * ms + c + n4];
-          const int bl3 = (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c + half - 1];
+          const bool ca = c + n4 < t->mi_col_end, cb = r + n4 < t->mi_row_end;
+          const int va = f->m_decoded[ca ? (r + half - 1) * ms + c + n4 : mi], vb = f->m_decoded[cb ? (r + n4) * ms + c + half - 1 : mi];
+          const int ar3 = ca && va, bl3 = cb && vb;
           SH->sflag = ar3 | (bl3 << 1);
         }
       }
@@ -615,7 +663,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             GroupRes gr;
-            eval_group<hn>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
+            eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
                            f->tune_psnr ? -1 : psv_q, pact_q, &gr);
             long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
             if (!live) j = J_INF;
@@ -636,7 +684,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
             if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
             else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
             TxRes tr;
-            const long long j = eval_tx<MAXN, SBS>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
+            const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
                                                    SH->ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
             if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
           }
@@ -690,7 +738,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   bool cgrouped = false;
   if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) cgrouped = f->np > 1 && !f->complex_modes;
   if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (cgrouped) {
-    const uint16_t *uvcost = k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
+    const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, f->reduced_tx_set);
     const int bdelta = (best_mode >= V_PRED && best_mode <= D67_PRED && BS >= BS_8) ? best_delta : 0;
     const int mx = (1 << f->bd) - 1;
@@ -766,7 +814,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      eval_group<n>(k.cc, k.cost, k.ls, f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, -1, SH->cact, &gr);
+      eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, -1, SH->cact, &gr);
       const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }
@@ -778,16 +826,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     for (int cnd = 0; cnd < 3; cnd++) {
       if (cnd < nc) {
         const int is_cfl = cnd == nc - 1, um = is_cfl ? UV_CFL_PRED : (cnd == 0 ? DC_PRED : best_mode);
-        uint32_t mode_rate = uvcost[um];
         int jsign = 0;
-        if (!is_cfl && cnd == 1 && um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + bdelta + 3];
-        if (is_cfl && cfl_ok) {
-          const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
-          jsign = su * 3 + sv - 1;
-          mode_rate += k.cost[CDF_CFL_SIGN + jsign];
-          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_u) - 1];
-          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_v) - 1];
-        }
+        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, !is_cfl && cnd == 1 && um >= V_PRED && um <= D67_PRED && BS >= BS_8, bdelta,
+                                                is_cfl && cfl_ok, alpha_u, alpha_v, &jsign);
         if (!is_cfl || cfl_ok) {
           const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
           if (j < best_uv) { best_uv = j; bc = cnd; b_sign = jsign; }
@@ -820,7 +861,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
   // ---- chroma: candidate ci2 by wave pair (ci2 & 1), plane (W & 1) + 1 within the pair ----
   if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
     const int cfl_allowed = BS <= BS_32;
-    const uint16_t *uvcost = cfl_allowed ? k.cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
+    const uint16_t *uvcost = cfl_allowed ? k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost() + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
     cands[nc++] = DC_PRED;
     if (best_mode != DC_PRED) cands[nc++] = best_mode;
@@ -895,8 +936,6 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
       WG_SYNC();                                            // (A) alphas of both planes visible
       PH(2);
       int alpha_u = 0, alpha_v = 0, jsign = 0, ok = valid;
-      uint32_t mode_rate = uvcost[um];
-      if (um >= V_PRED && um <= D67_PRED && BS >= BS_8) mode_rate += k.cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
       if (valid && um == UV_CFL_PRED) {
 #pragma unroll
         for (int pp = 0; pp < 2; pp++) {
@@ -905,14 +944,9 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
           if (pp == 0) alpha_u = al; else alpha_v = al;
         }
         if (alpha_u == 0 && alpha_v == 0) ok = 0;
-        else {
-          const int su = alpha_u == 0 ? 0 : (alpha_u < 0 ? 1 : 2), sv = alpha_v == 0 ? 0 : (alpha_v < 0 ? 1 : 2);
-          jsign = su * 3 + sv - 1;
-          mode_rate += k.cost[CDF_CFL_SIGN + jsign];
-          if (su) mode_rate += k.cost[CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_u) - 1];
-          if (sv) mode_rate += k.cost[CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE + iabs_(alpha_v) - 1];
-        }
       }
+      const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, um >= V_PRED && um <= D67_PRED && BS >= BS_8, delta,
+                                              valid && um == UV_CFL_PRED && ok, alpha_u, alpha_v, &jsign);
       TxRes trp = { 0, 0, 0, 0, 0 };
       if (ok) {
         {
@@ -936,7 +970,7 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
           } else {
             predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
           }
-          const long long jp = eval_tx<MAXN, BS>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &trp);
+          const long long jp = eval_tx<MAXN, BS, NW>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &trp);
           if (LANE == 0) SH->cj[ci2][p - 1] = jp;
         }
       }
@@ -983,8 +1017,8 @@ __device__ MI_K1_INLINE long long try_block(Ctx<MAXN> &k, int r, int c, long lon
     if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
     fill_map_dev(f->m_decoded, ms, r, c, n4, 1);
   }
-  const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
-  total_j += ((long long)k.cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
+  const int sctx = nb_skip;
+  total_j += ((long long)k.cost()[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
   PH(11);
   WG_SYNC();
   PH(2);
@@ -1028,7 +1062,7 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 
-__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const TileB *t, int r, int c, int bs, int part) {
+__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
@@ -1039,8 +1073,8 @@ __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS Fr
 // PARTITION_NONE, and the frame buffers still hold that result -- try_block() would reproduce it bit for bit, so
 // its cost is taken from the trial (oracle/av1o_search.c rd_partition does the same).  Returns 1 when split.
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
-  static __device__ MI_K1_INLINE int run(Ctx<MAXN> &k, int r, int c, long long known_j) {
-    const LDS FrameDev *f = k.f;
+  static __device__ MI_K1_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+    const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
@@ -1055,22 +1089,22 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
     long long sub_j[4] = { -1, -1, -1, -1 };
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        const long long j_blk = known_j >= 0 ? known_j : try_block<MAXN, BS, NW>(k, r, c);
-        const long long j_none = j_blk + (((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9);
-        area_copy_dev<BS, NW>(f, k.snap, r, c, 1);
+        const long long j_blk = known_j >= 0 ? known_j : uni64(try_block<MAXN, BS, NW>(k, r, c));
+        const long long j_none = uni64(j_blk + (((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9));
+        area_copy_dev<BS, NW>(f, k.snap(), r, c, 1);
         set_decoded_wg<NW>(f, r, c, n4, 0);
-        long long j_split = ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
+        long long j_split = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 3) * f->rdmult + 256) >> 9);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (!(j_split < j_none) || DBG_IS(f, 7)) break;
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-          sub_j[q] = try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split);
+          sub_j[q] = uni64(try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split));
           j_split += sub_j[q];
-          if (BS - 1 >= BS_8) j_split += ((long long)partition_rate_dev(k.cost, f, &k.t, rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9;
+          if (BS - 1 >= BS_8) j_split += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9);
         }
         if (j_split < j_none && !DBG_IS(f, 7) && !DBG_IS(f, 8) && !(DBG_IS(f, 10) && BS == 1)) do_split = 1;
-        else { area_copy_dev<BS, NW>(f, k.snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
+        else { area_copy_dev<BS, NW>(f, k.snap(), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
       }
     }
     if (do_split) {
@@ -1085,8 +1119,8 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_INLINE int run(Ctx<MAXN> &k, int r, int c, long long known_j) {
-    const LDS FrameDev *f = k.f;
+  static __device__ MI_K1_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+    const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     if (known_j >= 0) { set_decoded_wg<NW>(f, r, c, 1, 1); return 0; }
     set_decoded_wg<NW>(f, r, c, 1, 0);
@@ -1105,8 +1139,8 @@ template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(i
 }
 #define MI_SNAP_BYTES_ALL(n) (2 * MI_SNAP_BYTES(n))           /* sum over the levels < 4/3 of the largest */
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
-  static __device__ MI_K1_INLINE long long run(Ctx<MAXN> &k, int r, int c) {
-    const LDS FrameDev *f = k.f;
+  static __device__ MI_K1_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+    const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
@@ -1116,30 +1150,30 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
     long long j_none = J_INF;
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        j_none = try_block<MAXN, BS, NW>(k, r, c);
-        j_none += ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 0) * f->rdmult + 256) >> 9;
+        j_none = uni64(try_block<MAXN, BS, NW>(k, r, c));
+        j_none += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9);
         if (!can_split) return j_none;
-        area_copy_dev<BS, NW>(f, k.snap + snap_level_off<MAXN>(BS, MAXBS), r, c, 1);
+        area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 1);
         set_decoded_wg<NW>(f, r, c, n4, 0);
       }
     }
-    long long j_split = must_split ? 0 : ((long long)partition_rate_dev(k.cost, f, &k.t, r, c, BS, 3) * f->rdmult + 256) >> 9;
+    long long j_split = must_split ? 0 : uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 3) * f->rdmult + 256) >> 9);
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
       if (!must_split && j_split >= j_none) break;
       j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half);
     }
     if (must_split || j_split < j_none) return j_split;
-    if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
+    if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
     return j_none;
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_INLINE long long run(Ctx<MAXN> &k, int r, int c) {
-    const LDS FrameDev *f = k.f;
+  static __device__ MI_K1_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+    const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     set_decoded_wg<NW>(f, r, c, 1, 0);
-    return try_block<MAXN, 0, NW>(k, r, c);
+    return uni64(try_block<MAXN, 0, NW>(k, r, c));
   }
 };
 
@@ -1147,6 +1181,8 @@ template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
   return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2 +
          ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + (size_t)FRAMEDEV_K1_BYTES;
 }
+
+static_assert(k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit four workgroups per CU (160 KB LDS)");
 
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU>
@@ -1158,38 +1194,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   const TileJob tj = jobs[job];
   const FrameDev *gf = frames + tj.frame;
   if (frame_idle(gf)) return;
-  Ctx<MAXN> k;
-  constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
-  constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
-  k.sh = (LDS SharedScratch<MAXN> *)smem;
-  k.s = (LDS WaveScratch<MAXN> *)(smem + SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * WS_BYTES);
-  LDS uint16_t *lsc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES);
-  LDS uint16_t *lcc = (LDS uint16_t *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES);
-  LDS FrameDev *lf = (LDS FrameDev *)(smem + SH_BYTES + NW * WS_BYTES + SC_BYTES + CC_BYTES);
+  using K = Ctx<MAXN, NW>;
+  K k;
+  k.base = (LDS uint8_t *)smem;
+  k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);
+  LDS uint16_t *lsc = (LDS uint16_t *)(smem + K::LS_OFF);
+  LDS FrameDev *lf = (LDS FrameDev *)(smem + K::F_OFF);
   // the frame descriptor, the scan tables and the coefficient slices of the rate table are staged in LDS once per tile
   for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];   // only the head: K1 never reads the tail through `lf`
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
-  for (int i = LANE; i < (int)sizeof(k.s->lev); i += 64) k.s->lev[i] = 0;        // level-map padding stays zero for the whole tile
-  load_coef_cost(&k.cc, lcc, gf->cost, MAXBS, threadIdx.x, 64 * NW);
-  k.f = lf; k.cost = gf->cost; k.ls = lsc;
+  for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;        // level-map padding stays zero for the whole tile
+  load_coef_cost(k.cc_base(), gf->cost, MAXBS, threadIdx.x, 64 * NW);
+  if (threadIdx.x == 0) {
+    LDS TileB *t = &k.sh()->tile;
+    t->mi_row_start = gf->tile_row_start[tj.tile_row] * 16; t->mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, gf->mi_rows);
+    t->mi_col_start = gf->tile_col_start[tj.tile_col] * 16; t->mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, gf->mi_cols);
+    k.sh()->snap = gf->snap + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * MI_SNAP_BYTES_ALL(MAXN);
+  }
   WG_SYNC();
   const LDS FrameDev *f = lf;
-  k.t.mi_row_start = gf->tile_row_start[tj.tile_row] * 16; k.t.mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
-  k.t.mi_col_start = gf->tile_col_start[tj.tile_col] * 16; k.t.mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  k.snap = f->snap + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * MI_SNAP_BYTES_ALL(MAXN);
 #if MI_PROFILE
-  if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh->prof)[threadIdx.x] = 0;
+  if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x] = 0;
 #endif
   WG_SYNC();
   if (DBG_IS(f, 1)) return;
   const unsigned long long clk0 = wall_clock64();
-  for (int r = k.t.mi_row_start; r < k.t.mi_row_end; r += 16)
-    for (int c = k.t.mi_col_start; c < k.t.mi_col_end; c += 16) {
+  const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
+  for (int r = row0; r < row1; r += 16)
+    for (int c = col0; c < col1; c += 16) {
       if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
     }
-  if (threadIdx.x == 0) { unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
+  if (threadIdx.x == 0) { unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 #if MI_PROFILE
   WG_SYNC();
-  if (f->prof_out && threadIdx.x < 128) f->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh->prof)[threadIdx.x];
+  if (gf->prof_out && threadIdx.x < 128) gf->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];
 #endif
 }
