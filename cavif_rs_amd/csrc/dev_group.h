@@ -37,6 +37,7 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   constexpr int P = N + 1, nc = N * N, IT = nc / 16, bwl = N == 4 ? 2 : 3, st = N + 4;
   const int gl = GROUP_LANE;
   const int bd = f->bd;
+  const uint32_t tx_cost = cost[tx_off >= 0 ? tx_off + tx_sym : 0];     // the one global-memory operand of the evaluation: issued first, consumed after the transforms
   // ---- residual, reconstruction seed, level-map reset
 #pragma unroll
   for (int k = 0; k < IT; k++) {
@@ -120,7 +121,7 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
   int bits = 0, cul = 0, dcc = 0;
   if (eob > 0) {
-    if (tx_off >= 0) head += cost[tx_off + tx_sym];
+    if (tx_off >= 0) head += tx_cost;
     const int eob_pt = eob_to_pt(eob);
     head += cc.eobpt[N == 4 ? 0 : 1][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * (N == 4 ? CDF_EOB_PT_16_STRIDE : CDF_EOB_PT_64_STRIDE) + eob_pt - 1];
     if (eob_pt >= 3) {

@@ -121,9 +121,9 @@ template <typename CostPtr> __device__ inline uint32_t coef_rate_dev(const CoefC
   if (tx_off >= 0) head += cost[tx_off + tx_sym];
   const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
   {
-    const int strs[4] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_1024_STRIDE };
+    static_assert(CDF_EOB_PT_16_STRIDE == 6 && CDF_EOB_PT_64_STRIDE == 8 && CDF_EOB_PT_256_STRIDE == 10 && CDF_EOB_PT_1024_STRIDE == 12, "stride = 6 + 2 sq");
     const int sq = eob_multi >> 1;                        // square transforms: 16 / 64 / 256 / 1024 coefficients
-    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * strs[sq] + eob_pt - 1];
+    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * (6 + 2 * sq) + eob_pt - 1];
   }
   if (eob_pt >= 3) {
     const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
@@ -181,6 +181,7 @@ __device__ inline int quant_rate_dev(const CoefCost &cc, CostPtr cost, const LDS
                                      int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint32_t *rate_out, int *cul_out, int *dc_cat) {
   constexpr int n = CS, nc = CS * CS, IT = nc < 64 ? 1 : nc / 64, bwl = CS == 4 ? 2 : CS == 8 ? 3 : CS == 16 ? 4 : 5, st = CS + 4;
   LDS uint8_t *lev = levbase + LEV_OFF(CS);
+  const uint32_t tx_cost = cost[tx_off >= 0 ? tx_off + tx_sym : 0];     // the only global-memory operand: issued first, consumed after the quantiser
   const int cls = tx_class_of(txtype), pt = plane > 0, txs_ctx = txs;
   const int lsh = txs == 3 ? 1 : (txs == 4 ? 2 : 0);
   const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
@@ -237,12 +238,12 @@ __device__ inline int quant_rate_dev(const CoefCost &cc, CostPtr cost, const LDS
   *cul_out = 0; *dc_cat = 0;
   uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
   if (eob == 0) { *rate_out = head; return 0; }
-  if (tx_off >= 0) head += cost[tx_off + tx_sym];
+  if (tx_off >= 0) head += tx_cost;
   const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
   {
-    const int strs[4] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_1024_STRIDE };
+    static_assert(CDF_EOB_PT_16_STRIDE == 6 && CDF_EOB_PT_64_STRIDE == 8 && CDF_EOB_PT_256_STRIDE == 10 && CDF_EOB_PT_1024_STRIDE == 12, "stride = 6 + 2 sq");
     const int sq = eob_multi >> 1;
-    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * strs[sq] + eob_pt - 1];
+    head += cc.eobpt[sq][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * (6 + 2 * sq) + eob_pt - 1];
   }
   if (eob_pt >= 3) {
     const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;

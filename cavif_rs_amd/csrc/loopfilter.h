@@ -87,7 +87,7 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
 // line is off below the smallest level Lmin that passes the masks and can only change where L >> 4 changes, so a line adds at
 // most four (level range, SSE delta) pairs to the (plane, pass) difference array -- LDS first, then one global atomic per
 // non-zero entry and workgroup.  grid = (line chunks, plane * 2 + pass, frame).
-__global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *frames, int nframes) {
+__global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__restrict__ frames, int nframes) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y >> 1, pass = blockIdx.y & 1;
   if (plane >= f->np || f->fast_deblock || frame_idle(f)) return;
@@ -158,7 +158,7 @@ __global__ void deblock_pick_kernel(FrameDev *frames, int nframes) {
 }
 
 // pass 0: vertical edges (filter along x), pass 1: horizontal edges.  One thread per (plane, line, mi col).
-__global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *frames, int nframes, int pass) {
+__global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *__restrict__ frames, int nframes, int pass) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y;
   if (plane >= f->np || frame_idle(f)) return;
@@ -270,7 +270,7 @@ __device__ __forceinline__ void cdef_strengths(const FrameDev *f, int plane, int
 // grid.x = sb index, grid.y = frame; 256 threads = 4 waves, wave w handles 8x8 blocks w, w+4, ...
 // Every strength index >= 1 of the fixed list has a non-zero primary strength, so the filter direction of a block is
 // its luma direction for all candidates and the 12 tap samples per pixel and plane are loaded once.
-__global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *frames, int write_final) {
+__global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict__ frames, int write_final) {
   const FrameDev *f = frames + blockIdx.y;
   const int sbi = blockIdx.x;
   if (sbi >= f->sb_rows * f->sb_cols || frame_idle(f)) return;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *frames, in
 // ---------------------------------------------------------------- activity mask (Tune::Psychovisual)
 // One thread per 8x8 luma cell of the padded source: the four 4x4 variances (8x8-equivalent), the 8x8 variance and the cell's
 // activity scale = boost(var, var) (rav1e activity.rs ActivityMask::fill_scales; oracle av1o_activity).  grid = (cells / 256, frames)
-__global__ __launch_bounds__(256) void activity_kernel(const FrameDev *frames) {
+__global__ __launch_bounds__(256) void activity_kernel(const FrameDev *__restrict__ frames) {
   const FrameDev *f = frames + blockIdx.y;
   const int cw = f->pw >> 3, chh = f->ph >> 3, cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= cw * chh || frame_idle(f)) return;

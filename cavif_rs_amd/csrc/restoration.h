@@ -202,7 +202,7 @@ struct LrCand { long long cost; int xq0, xq1; };
 #ifndef LR_WG_PER_CU
 #define LR_WG_PER_CU 4
 #endif
-__global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const FrameDev *frames) {
+__global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const FrameDev *__restrict__ frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int nsets = f->sgr_full ? 16 : 4;
   const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
 
 // RD choice between RESTORE_NONE and the searched sets (first minimum in set order), then the winner is applied.
 // grid = (units, planes, frames)
-__global__ __launch_bounds__(256) void lr_kernel(const FrameDev *frames) {
+__global__ __launch_bounds__(256) void lr_kernel(const FrameDev *__restrict__ frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y;
   if (plane >= f->np || !f->enable_restoration || frame_idle(f)) return;

@@ -150,39 +150,44 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int pl
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int skip = f->m_skip[mi], ymode = f->m_ymode[mi];
-  int uvmode = 0;
+  // The block's mode info and its neighbours' in ONE batch of unconditional loads (a neighbour outside the tile reads the block's
+  // own cell and is replaced by its default afterwards): as `avail ? map[..] : dflt` at the point of use each of them was a
+  // separate round trip to L2 on the single wave that codes the tile.
+  const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
+  const int skip = f->m_skip[mi], ymode = f->m_ymode[mi], txs_y = f->m_txsize[mi];
+  const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
+  const int v_ay = f->m_angle_y[mi], v_cdef = f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)];
+  int uvmode = 0, v_auv = 0, v_js = 0, v_au = 0, v_av = 0;
+  if (f->np > 1) { uvmode = f->m_uvmode[mi]; v_auv = f->m_angle_uv[mi]; v_js = f->m_cfl_sign[mi]; v_au = f->m_cfl_au[mi]; v_av = f->m_cfl_av[mi]; }
   {
     RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
-    const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
+    const int sctx = (availU ? v_skU : 0) + (availL ? v_skL : 0);
     re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
     if (!skip && f->enable_cdef) {
-      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)], f->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
+      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, f->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
-    const int am = intra_mode_ctx(availU ? f->m_ymode[mi - ms] : DC_PRED), lm = intra_mode_ctx(availL ? f->m_ymode[mi - 1] : DC_PRED);
+    const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
     re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
     if (BS >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
-      re_symbol_dev(e, f->m_angle_y[mi] + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
+      re_symbol_dev(e, v_ay + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
     if (f->np > 1) {
-      const int um = f->m_uvmode[mi];
+      const int um = uvmode;
       if (BS <= BS_32) re_symbol_dev(e, um, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
       else re_symbol_dev(e, um, cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
       if (um == UV_CFL_PRED) {
-        const int js = f->m_cfl_sign[mi], su = (js + 1) / 3, sv = (js + 1) % 3;
+        const int js = v_js, su = (js + 1) / 3, sv = (js + 1) % 3;
         re_symbol_dev(e, js, cdf + CDF_CFL_SIGN, 8);
-        if (su) re_symbol_dev(e, f->m_cfl_au[mi], cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
-        if (sv) re_symbol_dev(e, f->m_cfl_av[mi], cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
+        if (su) re_symbol_dev(e, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
+        if (sv) re_symbol_dev(e, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
       }
       if (BS >= BS_8 && um >= V_PRED && um <= D67_PRED)
-        re_symbol_dev(e, f->m_angle_uv[mi] + 3, cdf + CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE, 7);
+        re_symbol_dev(e, v_auv + 3, cdf + CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE, 7);
     }
   }
-  if (f->np > 1) uvmode = f->m_uvmode[mi];
   // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
-  const int txs_y = f->m_txsize[mi];
   if (BS > 0 && f->tx_mode_select) {
     const int maxw = 4 << BS;
-    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
+    const int actx = availU && (4 << v_txU) >= maxw, lctx = availL && (4 << v_txL) >= maxw;
     re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   if (skip) return;                                    // wave-uniform
@@ -192,7 +197,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     for (int bi = 0; bi < nblk * nblk; bi++) {
       const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step, tmi = rr * ms + cc;
       if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-      const int eob = f->m_eob[p][tmi];
+      const int eob = f->m_eob[p][tmi], v_txt = f->m_txtype[tmi];        // issued with the coefficient loads below
       const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
       WAVE_SYNC();
       for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx >> l2n) * f->stride + (idx & (n - 1))];
@@ -200,7 +205,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
       build_level_map(w->qc, w->lev, n);
       int txtype, off = -1, sym = 0, ns = 0, set;
       if (p == 0) {
-        txtype = f->m_txtype[tmi];
+        txtype = v_txt;
         off = intra_tx_cdf(f, txs, ymode, &ns, &set);
         if (off >= 0) sym = txtype_to_sym(set, txtype);
       } else {
@@ -322,7 +327,7 @@ template <int CS> struct EntropyLds {
 };
 
 template <int MAXBS>
-__global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *frames, const TileJob *jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
+__global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
   constexpr int CS = MAXBS <= 2 ? 16 : 32;
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
   EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;

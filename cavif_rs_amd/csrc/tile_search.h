@@ -316,8 +316,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   WG_SYNC();
   PH(2);
   if (DBG_IS(f, 3)) return 0;
-  int sctx_p[3], dctx_p[3];
-  for (int p = 0; p < 3; p++) { sctx_p[p] = SH->sctx[p]; dctx_p[p] = SH->dctx[p]; }
+  const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];        // (chroma reads SH->sctx[p] in place: a private array indexed by p lives in scratch)
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
@@ -471,7 +470,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
         if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
         else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
         GroupRes gr;
-        eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_p[0], dctx_p[0], tx_off,
+        eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_y, dctx_y, tx_off,
                       tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, f->tune_psnr ? -1 : SH->psv[0], SH->pact[0], &gr);
         long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (!live) j = J_INF;
@@ -516,7 +515,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
     TxRes tr;
-    long long j = eval_tx<MAXN, BS, NW>(k, 0, sctx_p[0], dctx_p[0], lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
+    long long j = eval_tx<MAXN, BS, NW>(k, 0, sctx_y, dctx_y, lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
   }
@@ -814,7 +813,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, sctx_p[p], dctx_p[p], -1, 0, -1, SH->cact, &gr);
+      eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, SH->sctx[p], SH->dctx[p], -1, 0, -1, SH->cact, &gr);
       const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }
@@ -862,11 +861,13 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
     const int cfl_allowed = BS <= BS_32;
     const uint16_t *uvcost = cfl_allowed ? k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost() + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
-    int cands[16], nc = 0;
-    cands[nc++] = DC_PRED;
-    if (best_mode != DC_PRED) cands[nc++] = best_mode;
-    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) cands[nc++] = m;
-    if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
+    // candidate list: up to 14 modes of 4 bits packed into one 64-bit value (a private array indexed at run time lives in scratch)
+    unsigned long long cand_pack = 0; int nc = 0;
+    auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
+    push(DC_PRED);
+    if (best_mode != DC_PRED) push(best_mode);
+    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (cfl_allowed) push(UV_CFL_PRED);
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
     constexpr int NPAIR = 2;
     const int pair = ((W >> 1) & 1) ^ 1, active = W < 4;      // pair 0 (two plain candidates) = waves 2, 3: they have the lighter luma share
@@ -875,7 +876,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     // below only looks at (cost, candidate index), so the dealing order does not change the decision.
     int mine[16], nmine = 0, nother = 0;
     for (int i = 0; i < nc; i++) {
-      const int pr = (cands[i] == UV_CFL_PRED) ? 1 : (i == 0 || (i & 1)) ? 0 : 1;
+      const int pr = (lut4(cand_pack, i) == UV_CFL_PRED) ? 1 : (i == 0 || (i & 1)) ? 0 : 1;
       if (pr == pair) mine[nmine++] = i; else nother++;
     }
     const int rounds = imax_(nmine, nother);
@@ -883,7 +884,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       const int valid = active && rd < nmine;
       int ci2 = 0;
       for (int q = 0; q < 16; q++) if (q == rd && valid) ci2 = mine[q];
-      const int um = valid ? cands[ci2] : DC_PRED;
+      const int um = valid ? lut4(cand_pack, ci2) : DC_PRED;
       const int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && BS >= BS_8) ? best_delta : 0;
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
@@ -970,7 +971,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           } else {
             predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
           }
-          const long long jp = eval_tx<MAXN, BS, NW>(k, p, sctx_p[p], dctx_p[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &trp);
+          const long long jp = eval_tx<MAXN, BS, NW>(k, p, SH->sctx[p], SH->dctx[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &trp);
           if (LANE == 0) SH->cj[ci2][p - 1] = jp;
         }
       }
@@ -994,7 +995,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       commit_plane<BS>(f, p, r, c, S->rec[b], S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
       if (LANE == 0) SH->ceob[p - 1] = pb_tr.eob;
       if (p == 1) {
-        const int buv = cands[pb_c];
+        const int buv = lut4(cand_pack, pb_c);
         fill_map_dev(f->m_uvmode, ms, r, c, n4, buv);
         fill_map_dev((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)pb_delta);
         fill_map_dev(f->m_cfl_sign, ms, r, c, n4, pb_sign);
@@ -1186,7 +1187,7 @@ static_assert(k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit four workgroups 
 
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *frames, const TileJob *jobs, int njobs) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
   const int job = blockIdx.x;
