@@ -126,7 +126,10 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 }
 // WAVE_SYNC: orders one wavefront's own LDS/global traffic between phases (no cross-wave rendezvous);
 // WG_SYNC: workgroup barrier, used where the waves of a tile exchange results.
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// Lanes of ONE wavefront exchanging data through LDS: the LDS unit executes a wave's instructions in issue order, so all that is needed is
+// that the compiler keeps the order (wavefront-scope fence + scheduling barrier).  A workgroup-scope fence here would drain every
+// outstanding global load and store of the wave (s_waitcnt vmcnt(0)) at each of the thousands of exchanges per block.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define WG_SYNC() __syncthreads()
 
 struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };

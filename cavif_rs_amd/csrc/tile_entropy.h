@@ -44,24 +44,29 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
   }
   re_normalize_dev(e, l, r);
 }
-// encode + adapt.  Executed by the whole wave with identical (wave-uniform) operands: the coder state lives in
-// registers on every lane, lane i adapts CDF entry i (spec 8.3.2 update rule, one step instead of a loop).
-__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s, LDS uint16_t *icdf, int nsyms) {
-  const uint32_t fl = s > 0 ? icdf[s - 1] : 32768u, fh = icdf[s];
-  const int cnt = icdf[nsyms];
-  re_encode_q15_dev(e, fl, fh, s, nsyms);
-  const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
+// encode + adapt.  The coder state (low, rng, cnt, offs) is wave-uniform and every operand that reaches it goes through
+// v_readfirstlane / v_readlane, so the compiler keeps it in SGPRs and the range arithmetic runs on the scalar unit.  The CDF row
+// is read ONCE, lane i holding entry i (entry nsyms = the adaptation counter): the symbol's two bounds and the counter come
+// out of that register by v_readlane, the same register feeds lane i's adaptation (spec 8.3.2 update rule, one step instead
+// of a loop) -- one LDS round trip per symbol instead of three dependent ones.
+__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s_in, LDS uint16_t *icdf, int nsyms_in) {
+  const int s = uni32(s_in), nsyms = uni32(nsyms_in);
   const int i = LANE;
-  if (i < nsyms - 1) {
-    const int v = icdf[i];
-    icdf[i] = (uint16_t)(i < s ? v + ((32768 - v) >> rate) : v - (v >> rate));
-  } else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
+  const int v = icdf[imin_(i, nsyms)];
+  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(v, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
+  const int cnt = __builtin_amdgcn_readlane(v, nsyms);
+  re_encode_q15_dev(e, s > 0 ? fl0 : 32768u, fh, s, nsyms);
+  const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
+  if (i < nsyms - 1) icdf[i] = (uint16_t)(i < s ? v + ((32768 - v) >> rate) : v - (v >> rate));
+  else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
   WAVE_SYNC();
 }
-__device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit, uint32_t icdf0) {
+__device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit_in, uint32_t icdf0) {
+  const int bit = uni32(bit_in);
   re_encode_q15_dev(e, bit ? icdf0 : 32768, bit ? 0 : icdf0, bit, 2);
 }
-__device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v, int nbits) {
+__device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, int nbits_in) {
+  const uint32_t v = (uint32_t)uni32((int)v_in); const int nbits = uni32(nbits_in);
   for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
 }
 // returns number of bytes; out must hold them.  (lane 0)
@@ -94,8 +99,9 @@ struct TileWriter {
 // Two phases: (P) every lane derives the CDF rows (contexts) of its own scan positions -- they depend only on the
 // level map, not on the coder state -- and leaves (cdf offset, level, sign) records in LDS; (S) the wave walks
 // the records in coding order and drives the adaptive range coder, wave-uniform.
-__device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
+__device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
                                                   int tx_off, int tx_sym, int tx_ns) {
+  const int eob = uni32(eob_in);
   RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
@@ -126,23 +132,32 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob, int pl
     re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
     if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
   }
-  for (int c = eob - 1; c >= 0; c--) {
-    const int level = (int)(w->rec_lv[c] >> 1);
-    LDS uint16_t *bc0 = cdf + w->rec_off[c];
-    if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, bc0, 3);
-    else re_symbol_dev(e, imin_(level, 3), bc0, 4);
-    if (level > 2) {
-      LDS uint16_t *bc = cdf + w->rec_br[c];
-      int rem = level - 3;
-      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
+  // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
+  for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
+    const int li = imin_(cb + LANE, eob - 1);
+    const uint32_t r_lv = w->rec_lv[li]; const int r_off = w->rec_off[li], r_br = w->rec_br[li];
+    for (int c = imin_(eob - 1, cb + 63); c >= cb; c--) {
+      const int j = c - cb;
+      const int level = (int)((uint32_t)__builtin_amdgcn_readlane((int)r_lv, j) >> 1);
+      LDS uint16_t *bc0 = cdf + __builtin_amdgcn_readlane(r_off, j);
+      if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, bc0, 3);
+      else re_symbol_dev(e, imin_(level, 3), bc0, 4);
+      if (level > 2) {
+        LDS uint16_t *bc = cdf + __builtin_amdgcn_readlane(r_br, j);
+        int rem = level - 3;
+        for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
+      }
     }
   }
-  for (int c = 0; c < eob; c++) {
-    const uint32_t m = w->rec_lv[c]; const int a = (int)(m >> 1), neg = (int)(m & 1);
-    if (a) {
-      if (c == 0) re_symbol_dev(e, neg, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
-      else re_bool_dev(e, neg, 16384);
-      if (a > 14) { const uint32_t xg = (uint32_t)(a - 14); const int len = 32 - __clz(xg); re_literal_dev(e, 0, len - 1); re_literal_dev(e, xg, len); }
+  for (int cb = 0; cb < eob; cb += 64) {
+    const uint32_t r_lv = w->rec_lv[imin_(cb + LANE, eob - 1)];
+    for (int c = cb; c < imin_(eob, cb + 64); c++) {
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)r_lv, c - cb); const int a = (int)(m >> 1), neg = (int)(m & 1);
+      if (a) {
+        if (c == 0) re_symbol_dev(e, neg, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
+        else re_bool_dev(e, neg, 16384);
+        if (a > 14) { const uint32_t xg = (uint32_t)(a - 14); const int len = 32 - __clz(xg); re_literal_dev(e, 0, len - 1); re_literal_dev(e, xg, len); }
+      }
     }
   }
 }
