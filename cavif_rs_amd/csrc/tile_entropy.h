@@ -11,13 +11,16 @@
 
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
-  uint32_t low; uint32_t rng; int cnt; int overflow;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
+  uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
 };
 
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
-  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->overflow = 0;
+  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9;
 }
-__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) { if (e->offs < e->cap) { if (LANE == 0) e->pre[e->offs] = v; } else e->overflow = 1; e->offs++; }
+__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) {
+  if (e->offs < e->cap && LANE == 0) e->pre[e->offs] = v;   // offs counts every unit, stored or not: overflow <=> offs > cap at the end (re_finish_dev)
+  e->offs++;
+}
 __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, uint32_t rng) {
   int c = e->cnt;
   const int d = 16 - (32 - __clz(rng));
@@ -77,10 +80,14 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
   s += c;
   if (s > 0) {
     unsigned long long n = (1ULL << (c + 16)) - 1;
-    do { re_put16(e, (uint16_t)(x >> (c + 16))); x &= n; s -= 8; c -= 8; n >>= 8; } while (s > 0);
+    do {
+      const uint16_t u16 = (uint16_t)(x >> (c + 16));
+      re_put16(e, u16);
+      x &= n; s -= 8; c -= 8; n >>= 8;
+    } while (s > 0);
   }
   const uint32_t nb = e->offs;
-  if (e->overflow || nb > out_cap) return 0xFFFFFFFFu;
+  if (nb > e->cap || nb > out_cap) return 0xFFFFFFFFu;
   uint32_t carry = 0;
   for (uint32_t i = nb; i-- > 0;) { carry = e->pre[i] + carry; out[i] = (uint8_t)carry; carry >>= 8; }
   return nb;
@@ -93,7 +100,35 @@ struct TileWriter {
   LDS uint16_t *lr_cdf; LDS int *lr_ref;                           // switchable restoration_type CDF (3 symbols + counter), RefSgrXqd[plane][2]
   int cdef_pending;                                                 // the 64x64 superblock being walked has not signalled its cdef_idx yet
   int sb_cols_tile;
+  // Frame scalars that steer the walk, pinned to SGPRs once per tile (MI_K4_UNIFORM): a value that reaches a branch through a vector
+  // load is "divergent" to the compiler, the coder state behind such a branch becomes a per-lane value and the range arithmetic moves
+  // to the vector unit under exec masks.  Every control value the walk loads (skip, modes, transform sizes, eob, block sizes,
+  // restoration types) goes through v_readfirstlane for the same reason.
+  int np, mi_rows, mi_cols, ms, tx_mode_select, enable_cdef, cdef_bits, enable_restoration, sb_cols, fw, fh;
+  struct TxCfg { int reduced_tx_set, base_q_idx; } txc;
+#if MI_PROFILE == 2
+  unsigned long long prof[16], pt;
+#endif
 };
+// K4 phase timers (probe builds, -DMI_PROFILE=2): cycles per phase and event counts, flushed into wave 3's slots of the tile's K1 record
+#ifndef MI_PROFILE
+#define MI_PROFILE 0
+#endif
+#if MI_PROFILE == 2
+#define K4PH(i) do { const unsigned long long n_ = clock64(); w->prof[i] += n_ - w->pt; w->pt = n_; } while (0)
+#define K4CNT(i, n) do { w->prof[i] += (unsigned long long)(n); } while (0)
+#else
+#define K4PH(i) do {} while (0)
+#define K4CNT(i, n) do {} while (0)
+#endif
+#ifndef MI_K4_UNIFORM
+#define MI_K4_UNIFORM 1
+#endif
+#if MI_K4_UNIFORM
+#define U_(v) uni32((int)(v))
+#else
+#define U_(v) ((int)(v))
+#endif
 
 // Code one transform block's coefficients (levels + padded level map already staged in LDS).
 // Two phases: (P) every lane derives the CDF rows (contexts) of its own scan positions -- they depend only on the
@@ -106,14 +141,15 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
   re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
-  if (eob == 0) return;
+  K4CNT(9, 1); K4CNT(10, eob == 0);
+  if (eob == 0) { K4PH(3); return; }
   // ---- (P) contexts, lane-parallel
   const int st = n + 4, area = n * n;
   for (int c = LANE; c < eob; c += 64) {
     const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
     const int v = qc[p], level = iabs_(v);
     const LDS uint8_t *L = lev + row * st + col;
-    int off;
+    int off;                                                 // last position: its base_eob CDF row; the others: the base context (0..41)
     if (c == eob - 1) {
       const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
       off = CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE;
@@ -123,6 +159,7 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
     w->rec_off[c] = (uint16_t)off; w->rec_br[c] = (uint16_t)boff; w->rec_lv[c] = ((uint32_t)level << 1) | (uint32_t)(v < 0);
   }
   WAVE_SYNC();
+  K4PH(3);
   // ---- (S) serial coding
   if (tx_off >= 0) re_symbol_dev(e, tx_sym, cdf + tx_off, tx_ns);
   const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
@@ -133,22 +170,27 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
     if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
   }
   // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
+  // The coeff_base (42 contexts) and coeff_br (21 contexts) rows of this (transform size, plane type) live in registers for the
+  // duration of the block: lane L < 42 owns base context L, lane 42 + k owns base-range context k (four-symbol alphabets: three
+  // CDF entries + the adaptation counter).  A symbol takes its bounds out of the owning lane by v_readlane and that lane adapts
+  // its row in place -- no LDS round trip and no fence per symbol; the rows return to the LDS copy after the last coefficient.
   for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
     const int li = imin_(cb + LANE, eob - 1);
     const uint32_t r_lv = w->rec_lv[li]; const int r_off = w->rec_off[li], r_br = w->rec_br[li];
     for (int c = imin_(eob - 1, cb + 63); c >= cb; c--) {
       const int j = c - cb;
       const int level = (int)((uint32_t)__builtin_amdgcn_readlane((int)r_lv, j) >> 1);
-      LDS uint16_t *bc0 = cdf + __builtin_amdgcn_readlane(r_off, j);
-      if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, bc0, 3);
-      else re_symbol_dev(e, imin_(level, 3), bc0, 4);
+      const int boff = __builtin_amdgcn_readlane(r_off, j);
+      if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, cdf + boff, 3);
+      else re_symbol_dev(e, imin_(level, 3), cdf + boff, 4);
       if (level > 2) {
-        LDS uint16_t *bc = cdf + __builtin_amdgcn_readlane(r_br, j);
+        const int bl = __builtin_amdgcn_readlane(r_br, j);
         int rem = level - 3;
-        for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, bc, 4); rem -= s; if (s < 3) break; }
+        for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, cdf + bl, 4); rem -= s; if (s < 3) break; }
       }
     }
   }
+  K4PH(4); K4CNT(11, eob);
   for (int cb = 0; cb < eob; cb += 64) {
     const uint32_t r_lv = w->rec_lv[imin_(cb + LANE, eob - 1)];
     for (int c = cb; c < imin_(eob, cb + 64); c++) {
@@ -160,32 +202,36 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
       }
     }
   }
+  K4PH(5);
 }
 
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
-  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride, mi = r * ms + c;
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   // The block's mode info and its neighbours' in ONE batch of unconditional loads (a neighbour outside the tile reads the block's
   // own cell and is replaced by its default afterwards): as `avail ? map[..] : dflt` at the point of use each of them was a
   // separate round trip to L2 on the single wave that codes the tile.
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
-  const int skip = f->m_skip[mi], ymode = f->m_ymode[mi], txs_y = f->m_txsize[mi];
-  const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
-  const int v_ay = f->m_angle_y[mi], v_cdef = f->cdef_idx[(r >> 4) * f->sb_cols + (c >> 4)];
-  int uvmode = 0, v_auv = 0, v_js = 0, v_au = 0, v_av = 0;
-  if (f->np > 1) { uvmode = f->m_uvmode[mi]; v_auv = f->m_angle_uv[mi]; v_js = f->m_cfl_sign[mi]; v_au = f->m_cfl_au[mi]; v_av = f->m_cfl_av[mi]; }
+  const int l_skip = f->m_skip[mi], l_ymode = f->m_ymode[mi], l_txs_y = f->m_txsize[mi];
+  const int l_skU = f->m_skip[iU], l_skL = f->m_skip[iL], l_ymU = f->m_ymode[iU], l_ymL = f->m_ymode[iL], l_txU = f->m_txsize[iU], l_txL = f->m_txsize[iL];
+  const int l_ay = f->m_angle_y[mi], l_cdef = f->cdef_idx[(r >> 4) * w->sb_cols + (c >> 4)];
+  int l_uvmode = 0, l_auv = 0, l_js = 0, l_au = 0, l_av = 0;
+  if (w->np > 1) { l_uvmode = f->m_uvmode[mi]; l_auv = f->m_angle_uv[mi]; l_js = f->m_cfl_sign[mi]; l_au = f->m_cfl_au[mi]; l_av = f->m_cfl_av[mi]; }
+  const int skip = U_(l_skip), ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
+  const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_ay = U_(l_ay), v_cdef = U_(l_cdef);
+  const int uvmode = U_(l_uvmode), v_auv = U_(l_auv), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
   {
     RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
     const int sctx = (availU ? v_skU : 0) + (availL ? v_skL : 0);
     re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
-    if (!skip && f->enable_cdef) {
-      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, f->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
+    if (!skip && w->enable_cdef) {
+      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, w->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
     const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
     re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
     if (BS >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
       re_symbol_dev(e, v_ay + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
-    if (f->np > 1) {
+    if (w->np > 1) {
       const int um = uvmode;
       if (BS <= BS_32) re_symbol_dev(e, um, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
       else re_symbol_dev(e, um, cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
@@ -200,36 +246,39 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     }
   }
   // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
-  if (BS > 0 && f->tx_mode_select) {
+  if (BS > 0 && w->tx_mode_select) {
     const int maxw = 4 << BS;
     const int actx = availU && (4 << v_txU) >= maxw, lctx = availL && (4 << v_txL) >= maxw;
     re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
+  K4PH(1); K4CNT(8, 1);
   if (skip) return;                                    // wave-uniform
   // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
-  for (int p = 0; p < f->np; p++) {
+  for (int p = 0; p < w->np; p++) {
     const int txs = p == 0 ? txs_y : BS, l2n = imin_(5, 2 + txs), n = 1 << l2n, step = 1 << txs, nblk = 1 << (BS - txs);
     for (int bi = 0; bi < nblk * nblk; bi++) {
       const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step, tmi = rr * ms + cc;
-      if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-      const int eob = f->m_eob[p][tmi], v_txt = f->m_txtype[tmi];        // issued with the coefficient loads below
+      if (rr >= w->mi_rows || cc >= w->mi_cols) continue;
+      const int l_eob = f->m_eob[p][tmi], l_txt = f->m_txtype[tmi];      // issued with the coefficient loads below
       const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
       WAVE_SYNC();
       for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx >> l2n) * f->stride + (idx & (n - 1))];
       WAVE_SYNC();
       build_level_map(w->qc, w->lev, n);
+      const int eob = U_(l_eob), v_txt = U_(l_txt);
       int txtype, off = -1, sym = 0, ns = 0, set;
       if (p == 0) {
         txtype = v_txt;
-        off = intra_tx_cdf(f, txs, ymode, &ns, &set);
+        off = intra_tx_cdf(&w->txc, txs, ymode, &ns, &set);
         if (off >= 0) sym = txtype_to_sym(set, txtype);
       } else {
-        set = tx_set_of(txs, f->reduced_tx_set);
+        set = tx_set_of(txs, w->txc.reduced_tx_set);
         txtype = mode_to_txtype(uvmode);
         if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
       }
       int sctx2, dctx;
       txb_ctx_dev(f, t, p, rr, cc, txs, BS, &sctx2, &dctx);
+      K4PH(2);
       code_coeffs_lane0(w, eob, p, txs, txtype, sctx2, dctx, off, sym, ns);
     }
   }
@@ -238,10 +287,10 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
 
 // Partition symbol of the node (r, c, bs >= 1); returns 0 (NONE) or 3 (SPLIT).  spec 5.11.4
 __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int c, int bs) {
-  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = f->mi_stride;
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms;
   const int half = (1 << bs) >> 1;
-  const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
-  const int actual = f->m_bsize[r * ms + c];
+  const int has_rows = (r + half) < w->mi_rows, has_cols = (c + half) < w->mi_cols;
+  const int actual = U_(f->m_bsize[r * ms + c]);
   int part = actual == bs ? 0 : 3;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
@@ -254,29 +303,30 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
     if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
     else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
 #undef PP_
-    re_bool_dev(&w->ec, 1, psum);
+    re_bool_dev(&w->ec, 1, (uint32_t)U_(psum));
   }
   if (!(has_rows && has_cols)) part = 3;
+  K4PH(0);
   return part;
 }
 
 // read_lr() of the superblock at (r, c) (spec 5.11.57 / 5.11.58): with 64x64 units at most one unit per plane
 __device__ __forceinline__ void write_lr_sb(TileWriter *w, int r, int c) {
   const FrameDev *f = w->f;
-  if (!f->enable_restoration) return;
-  const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h), n = ucols * urows;
+  if (!w->enable_restoration) return;
+  const int ucols = lr_units_of(w->fw), urows = lr_units_of(w->fh), n = ucols * urows;
   const int urs = (r * 4 + 63) / 64, ure = imin_(((r + 16) * 4 + 63) / 64, urows);
   const int ucs = (c * 4 + 63) / 64, uce = imin_(((c + 16) * 4 + 63) / 64, ucols);
-  for (int p = 0; p < f->np; p++) for (int ur = urs; ur < ure; ur++) for (int uc = ucs; uc < uce; uc++) {
+  for (int p = 0; p < w->np; p++) for (int ur = urs; ur < ure; ur++) for (int uc = ucs; uc < uce; uc++) {
     const int ui = p * n + ur * ucols + uc;
-    const int type = f->lr_type[ui];
+    const int type = U_(f->lr_type[ui]);
     re_symbol_dev(&w->ec, type ? 2 : 0, w->lr_cdf, 3);
     if (!type) continue;
-    const int set = f->lr_set[ui];
+    const int set = U_(f->lr_set[ui]);
     re_literal_dev(&w->ec, (uint32_t)set, 4);
     int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
     for (int i = 0; i < 2; i++) {
-      const int v = f->lr_xqd[ui * 2 + i];
+      const int v = U_(f->lr_xqd[ui * 2 + i]);
       if (i == 0 ? r0 : r1) {
         uint32_t bits; const int nb = lr_subexp_code(v, i == 0 ? -96 : -32, i == 0 ? 32 : 96, w->lr_ref[p * 2 + i], &bits);
         re_literal_dev(&w->ec, bits, nb);
@@ -293,7 +343,9 @@ __device__ __forceinline__ void write_lr_sb(TileWriter *w, int r, int c) {
 template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter *w, int r0, int c0) {
   const FrameDev *f = w->f;
   w->cdef_pending = 1;
+  K4PH(7);
   write_lr_sb(w, r0, c0);
+  K4PH(6);
   int sr[5], sc[5], sk[5];
   int sp = 0; sr[0] = r0; sc[0] = c0; sk[0] = 0;
   while (sp >= 0) {
@@ -302,7 +354,7 @@ template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter
 #pragma unroll
     for (int q = 0; q < 5; q++) if (q == sp) { r = sr[q]; c = sc[q]; kk = sk[q]; }
     if (kk == 0) {
-      if (r >= f->mi_rows || c >= f->mi_cols) { sp--; continue; }
+      if (r >= w->mi_rows || c >= w->mi_cols) { sp--; continue; }
       const int part = bs == 0 ? 0 : write_partition_symbol(w, r, c, bs);
       if (part == 0) {
         switch (bs) {
@@ -358,12 +410,19 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__rest
   w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
   w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
   w.lr_cdf = (LDS uint16_t *)L.lr_cdf; w.lr_ref = (LDS int *)L.lr_ref;
+  w.np = U_(f->np); w.mi_rows = U_(f->mi_rows); w.mi_cols = U_(f->mi_cols); w.ms = U_(f->mi_stride); w.tx_mode_select = U_(f->tx_mode_select);
+  w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
+  w.fw = U_(f->w); w.fh = U_(f->h); w.txc.reduced_tx_set = U_(f->reduced_tx_set); w.txc.base_q_idx = U_(f->base_q_idx);
   if (LANE < 4) L.lr_cdf[LANE] = (uint16_t)(LANE == 0 ? 32768 - 9413 : (LANE == 1 ? 32768 - 22581 : 0));   // libaom default_switchable_restore_cdf
   if (LANE < 6) L.lr_ref[LANE] = (LANE & 1) ? 31 : -32;                                                      // Sgrproj_Xqd_Mid
   load_scans_to_lds((LDS uint16_t *)L.scans, CS);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
+#if MI_PROFILE == 2
+  for (int i = 0; i < 16; i++) w.prof[i] = 0;
+  w.pt = clock64();
+#endif
   const unsigned long long clk0 = wall_clock64();
   WAVE_SYNC();
   for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
@@ -375,6 +434,9 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__rest
     (void)ti;
     uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
     f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
+#if MI_PROFILE == 2
+    { TileWriter *w_ = &w; TileWriter *w = w_; K4PH(7); if (f->prof_out) for (int i = 0; i < 16; i++) f->prof_out[(size_t)job * 128 + 96 + i] = w->prof[i]; }
+#endif
     unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[2] = clk0; tc[3] = wall_clock64();
   }
 }
