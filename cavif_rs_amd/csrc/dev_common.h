@@ -78,7 +78,9 @@ struct TileJob { int frame; int tile_row, tile_col; };
 
 #define LANE ((int)(threadIdx.x & 63))
 // Explicit LDS address space: pointers carrying it compile to ds_read/ds_write instead of flat_* accesses.
+#ifndef LDS                                      /* (the CPU test harness tests/emu/ predefines it empty) */
 #define LDS __attribute__((address_space(3)))
+#endif
 
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }

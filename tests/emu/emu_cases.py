@@ -1,0 +1,43 @@
+"""Runs inside a subprocess with MI_AVIF_LIB = the emulator build: the product's host engine + HIP kernels, executed lane by lane
+on the CPU, against the oracle.  Prints one JSON line per case.  (TEST INFRASTRUCTURE; see tests/emu/include/hip/hip_runtime.h.)"""
+import json
+import sys
+import time
+import numpy as np
+
+sys.path.insert(0, sys.argv[1])
+from tests.helpers import oracle                      # noqa: E402
+from tests.helpers.images import planes, rgba_noisy, rgba_gradient   # noqa: E402
+import cavif_rs_amd as m                              # noqa: E402
+
+from cavif_rs_amd import encoder as _enc
+assert 'emu' in _enc.library_path(), _enc.library_path()
+which = sys.argv[2] if len(sys.argv) > 2 else 'quick'
+oracle.build(); oracle.lib()
+
+PLANE_CASES = {
+    'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0)],
+    'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
+             (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),
+             (72, 136, 8, 8, 160, False, 2), (8, 8, 8, 4, 121, False, 0), (17, 9, 10, 4, 90, False, 0), (200, 120, 10, 2, 121, False, 0), (200, 120, 8, 3, 170, False, 0)],
+}[which]
+ok_all = True
+for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
+    pl = planes(h, w, seed=w + h, bd=bd, mono=mono)
+    r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, speed, tiles=tiles), pl)
+    t = time.time()
+    obu, rec = m.encode_planes(pl, bd, q, speed, mono, tiles=tiles)
+    ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
+    ok_all &= ok
+    print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d' % (w, h, bd, speed, q, int(mono), tiles), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
+
+# ravif level: RGBA with a used alpha channel, UnassociatedClean (dirty-alpha kernels + front end + colour and alpha frames + container)
+img = rgba_noisy()[:40, :56].copy()
+e = m.Encoder().with_quality(66).with_alpha_quality(88).with_speed(6).with_num_threads(1).with_alpha_color_mode('clean')
+t = time.time()
+got = e.encode_rgba(img)
+ref, color, alpha = oracle.ravif_encode(img, quality=66, alpha_quality=88, speed=6, depth=0, alpha_mode=1, threads=1)
+ok = got.avif_file == ref and (got.color_byte_size, got.alpha_byte_size) == (color, alpha)
+ok_all &= ok
+print(json.dumps({'case': 'ravif rgba clean 56x40 s6', 'ok': bool(ok), 'bytes': len(got.avif_file), 's': round(time.time() - t, 2)}), flush=True)
+sys.exit(0 if ok_all else 1)

@@ -1,0 +1,111 @@
+// hip_runtime.h (SIMT emulator shim) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Lets g++ compile cavif_rs_amd/csrc/mi_avif.hip -- the UNCHANGED product sources, host engine and HIP kernels -- into
+// tests/emu/_build/libmi_avif_emu.so, in which every GPU thread is a fiber on the CPU: a workgroup's threads run one after
+// another between the points where the GPU makes them meet (cross-lane operations: v_readlane / DPP / v_readfirstlane /
+// __shfl; the wavefront-scope WAVE_SYNC; __syncthreads), LDS is a per-workgroup array, HBM is host memory and the HIP runtime
+// calls are synchronous stand-ins.  Purpose: `-m "not gpu"` tests can run the very kernels that ship against the CPU oracle on
+// small images when no MI355X is attached, so that a kernel edit is checked for byte parity before it costs GPU time.
+// It is 10^3..10^4 times slower than one host core running the oracle; it is never linked into cavif_rs_amd/libmi_avif.so,
+// which still fails with MI_NO_DEVICE without a GPU.  Cross-lane semantics follow the CDNA3/4 ISA (DPP controls quad_perm,
+// row_shl/shr/ror, row_mirror, row_half_mirror, row_bcast15/31 with row / bank masks and bound_ctrl).
+// Lanes that skip a divergent region wait at the next cross-lane operation they reach; an operation is resolved for the lanes
+// standing at the same source-level site as soon as every lane they read from stands there too (the kernels keep whole quads /
+// rows active around partial-wave DPP), so a region's lanes catch up with the ones waiting behind it.
+// What it cannot show: timing, register pressure, and bugs that depend on true lockstep execution inside a wavefront.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <cmath>
+#include <functional>
+
+#define MI_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ thread_local          /* one workgroup at a time per OS thread: its fibers share the thread's statics */
+#define __align__(n) alignas(n)
+#define LDS                              /* dev_common.h: address_space(3) on the GPU */
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+namespace emu {
+struct Idx3 { unsigned x, y, z; };
+enum XKind { X_READLANE = 1, X_READFIRST, X_DPP, X_SHFL };
+int xlane(int kind, int val, int old, int p0, int rm, int bm, int bc, int site);
+void wave_barrier();
+void wg_barrier();
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
+unsigned long long ticks();
+}
+extern thread_local emu::Idx3 threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+// dynamic LDS of the two kernels that use it (tile_search.h `smem`, tile_entropy.h `k4_smem`)
+extern thread_local alignas(16) uint8_t smem[];
+extern thread_local alignas(16) uint8_t k4_smem[];
+
+// ---- device intrinsics ----
+#define __builtin_amdgcn_readlane(v, lane) emu::xlane(emu::X_READLANE, (int)(v), 0, (int)(lane), 0, 0, 0, __COUNTER__)
+#define __builtin_amdgcn_readfirstlane(v) emu::xlane(emu::X_READFIRST, (int)(v), 0, 0, 0, 0, 0, __COUNTER__)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::xlane(emu::X_DPP, (int)(src), (int)(old), (int)(ctrl), (int)(rm), (int)(bm), (int)(bc), __COUNTER__)
+#define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+inline int __shfl(int v, int src, int width = 64) { (void)width; return emu::xlane(emu::X_SHFL, v, 0, src, 0, 0, 0, -1); }
+inline void __syncthreads() { emu::wg_barrier(); }
+inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+inline int __clz(unsigned v) { return v == 0 ? 32 : __builtin_clz(v); }
+inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline unsigned long long clock64() { return emu::ticks(); }
+inline unsigned long long wall_clock64() { return emu::ticks(); }
+// global / LDS atomics: workgroups of one launch may run on several OS threads
+template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
+struct uchar4 { unsigned char x, y, z, w; };
+inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{ x, y, z, w }; }
+
+// ---- HIP runtime stand-ins: one "device", synchronous streams ----
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct emu_stream_ *hipStream_t;
+typedef struct emu_event_ { double t; } *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+void *emu_alloc(size_t n);
+void emu_free(void *p);
+template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)emu_alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)emu_alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void *p) { emu_free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void *p) { emu_free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind) {
+  for (size_t y = 0; y < h; y++) memmove((uint8_t *)d + y * dp, (const uint8_t *)s + y * sp, w);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
+inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+double emu_now_ms();
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event_{ 0.0 }; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = emu_now_ms(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); })

@@ -1,0 +1,40 @@
+"""The shipped HIP kernels + host engine, executed lane by lane on the CPU (tests/emu/: a SIMT emulator, test infrastructure),
+must produce the oracle's bytes.  This is what keeps a kernel edit honest when no MI355X is attached; the `-m gpu` tests remain the
+parity tests proper.  The emulated library is a separate build (tests/emu/_build/), never the product library."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def emu_env(oracle):
+    from tests import emu
+    return emu.env()
+
+
+def _run(emu_env, which, timeout):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'emu_cases.py'), ROOT, which], env=emu_env, capture_output=True, text=True, timeout=timeout)
+    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    return p, rows
+
+
+def test_emulated_kernels_equal_oracle(emu_env):
+    p, rows = _run(emu_env, 'quick', 900)
+    assert rows, p.stderr[-2000:]
+    bad = [r['case'] for r in rows if not r['ok']]
+    assert not bad and p.returncode == 0, 'emulated HIP path differs from the oracle: %s\n%s' % (bad, p.stderr[-2000:])
+    assert len(rows) >= 6
+
+
+def test_product_library_is_not_the_emulator():
+    """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd import encoder
+    assert 'emu' not in os.path.basename(encoder.library_path())
+    with open(encoder.library_path(), 'rb') as fh:
+        blob = fh.read()
+    assert b'emu_switch' not in blob and b'gfx950' in blob
