@@ -76,7 +76,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   // reconstructed into split_rec / split_qc (for MAXN <= 16 these alias lpred, which is dead after the mode decision) and only
   // reach the frame if the split wins.  ssrc = the four sub-sources, spred = the current sub-block's prediction, nb_* = the
   // (level, dc) contexts the block's outer neighbours left behind.
-  int sub_tx[4], sub_eob[4], sub_cul[4], sub_dcc[4], sflag; long long lm_mode_j;
+  long long lm_mode_j;   // (the trial's per-sub-block results alias dsd / satd, dead by then)
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
   // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
   int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
@@ -561,171 +561,186 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
     if (tx_trial) {
-      constexpr int SBS = BS - 1, hn = n >> 1, half = n4 >> 1, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
-      long long j_split = SH->lm_mode_j + (((long long)dcost[1] * f->rdmult + 256) >> 9);
-      int stx_ns = 0, stx_set = 0;
-      const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
-      const int sntx = stx_off >= 0 ? stx_ns : 1;
-      int sub_any = 0;
-      // ---- stage 0, all waves: the four sub-sources; wave 0: outer neighbour contexts + the two decoded flags that lie outside the block
-      for (int q = W; q < 4; q += NW) {
-        const int so = (q >> 1) * hn * n + (q & 1) * hn;
-        for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[q * hnn + idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
-      }
-      if (W == 0) {
-        if (LANE < n4) {
-          const int k2 = LANE;
-          const bool ha = availU && c + k2 < f->mi_cols, hl = availL && r + k2 < f->mi_rows;         // unconditional loads, one batch
-          const int ia = ha ? (r - 1) * ms + c + k2 : mi, il = hl ? (r + k2) * ms + c - 1 : mi;
-          const int la = f->m_lvl[0][ia], da = f->m_dc[0][ia], ll = f->m_lvl[0][il], dl2 = f->m_dc[0][il];
-          SH->nb_top[k2][0] = (uint8_t)(ha ? la : 0); SH->nb_top[k2][1] = (uint8_t)(ha ? da : 0);
-          SH->nb_left[k2][0] = (uint8_t)(hl ? ll : 0); SH->nb_left[k2][1] = (uint8_t)(hl ? dl2 : 0);
+      // The trial of one depth D (1: 2x2 transform blocks one level smaller, 2: 4x4 blocks two levels smaller, raster order), LDS-resident:
+      // returns true when the caller's budget is exhausted (try_block returns at once).  The frame always holds the best transform
+      // size found so far (depth 0 was committed above; a winning depth replaces it), so a deeper trial needs no snapshot.
+      LDS int *const sub_tx = (LDS int *)SH->dsd, *const sub_eob = sub_tx + 16, *const sub_cul = sub_tx + 32, *const sub_dcc = sub_tx + 48, *const psv16 = sub_tx + 64;   // dsd / satd are dead after the mode decision
+      LDS int *const sfl_r = (LDS int *)SH->satd, *const sfl_b = sfl_r + 4;
+      auto trial = [&](auto depth_c) -> bool {
+        constexpr int D = decltype(depth_c)::value;
+        constexpr int SBS = BS - D, G = 1 << D, hn = n >> D, half = n4 >> D, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
+        long long j_split = SH->lm_mode_j + (((long long)dcost[D] * f->rdmult + 256) >> 9);
+        int stx_ns = 0, stx_set = 0;
+        const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
+        const int sntx = stx_off >= 0 ? stx_ns : 1;
+        int sub_any = 0;
+        // ---- stage 0, all waves: the sub-sources; wave 0: outer neighbour contexts, the 4x4 source variances (depth 2 of a 16x16 block)
+        // and the decoded flags of the cells right of / below the block that a sub-block's above-right / below-left edge may reach
+        for (int q = W; q < G * G; q += NW) {
+          const int so = (q / G) * hn * n + (q % G) * hn;
+          for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[q * hnn + idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
         }
-        if (LANE == 0) {
-          const bool ca = c + n4 < t->mi_col_end, cb = r + n4 < t->mi_row_end;
-          const int va = f->m_decoded[ca ? (r + half - 1) * ms + c + n4 : mi], vb = f->m_decoded[cb ? (r + n4) * ms + c + half - 1 : mi];
-          const int ar3 = ca && va, bl3 = cb && vb;
-          SH->sflag = ar3 | (bl3 << 1);
-        }
-      }
-      WG_SYNC();
-      const int sflag = SH->sflag;
-#pragma unroll 1
-      for (int q = 0; q < 4; q++) {
-        // costs only grow: once the split can neither beat the undivided transform nor stay below the caller's budget
-        // (then the undivided transform is above the budget too and the caller discards this block) the rest is skipped
-        if (j_split >= budget && luma_j >= budget) return luma_j;   // wave-uniform
-        if (!(j_split < luma_j)) break;
-        const int sx = x + (q & 1) * hn, sy = y + (q >> 1) * hn;
-        const int sU = availU || (q >> 1), sL = availL || (q & 1);
         if (W == 0) {
-          // raw edges of the sub-block (spec 7.11.2 / load_edges) from the block's raw edges and the sub-blocks reconstructed so far
-          LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
-          const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride;
-          const uint16_t *grec = f->rec[0];
-          for (int i = LANE - 1; i < 2 * hn; i += 64) {
-            int a, l;
-            if (q == 0) { a = ra[i]; l = rl[i]; }
-            else if (q == 1) {
-              a = availU ? ra[hn + i] : split_rec[hn - 1];
-              l = i < 0 ? a : split_rec[imin_(i, hn - 1) * n + hn - 1];
-            } else if (q == 2) {
-              a = split_rec[(hn - 1) * n + imax_(i, 0)];
-              l = availL ? rl[hn + i] : split_rec[(hn - 1) * n];
-              if (i < 0) a = l;
-            } else {
-              a = i < hn ? split_rec[(hn - 1) * n + hn + i] : ((sflag & 1) ? (int)grec[(size_t)(sy - 1) * rs + imin_(max_x, sx + i)] : (int)split_rec[(hn - 1) * n + n - 1]);
-              l = i < hn ? split_rec[(hn + imax_(i, 0)) * n + hn - 1] : ((sflag & 2) ? (int)grec[(size_t)imin_(max_y, sy + i) * rs + sx - 1] : (int)split_rec[(n - 1) * n + hn - 1]);
-              if (i < 0) l = a;
-            }
-            A[i] = (uint16_t)a; Lf[i] = (uint16_t)l;
+          if (LANE < n4) {
+            const int k2 = LANE;
+            const bool ha = availU && c + k2 < f->mi_cols, hl = availL && r + k2 < f->mi_rows;         // unconditional loads, one batch
+            const int ia = ha ? (r - 1) * ms + c + k2 : mi, il = hl ? (r + k2) * ms + c - 1 : mi;
+            const int la = f->m_lvl[0][ia], da = f->m_dc[0][ia], ll = f->m_lvl[0][il], dl2 = f->m_dc[0][il];
+            SH->nb_top[k2][0] = (uint8_t)(ha ? la : 0); SH->nb_top[k2][1] = (uint8_t)(ha ? da : 0);
+            SH->nb_left[k2][0] = (uint8_t)(hl ? ll : 0); SH->nb_left[k2][1] = (uint8_t)(hl ? dl2 : 0);
           }
-          WAVE_SYNC();
-          predict_block(f, sx, sy, log2w - 1, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, spred);
+          if (hn == 4 && n == 16 && LANE < 16) psv16[LANE] = (int)f->svar4[(r + (LANE >> 2)) * ms + c + (LANE & 3)];
+          if (LANE >= 1 && LANE < G) {
+            const bool ca = c + n4 < t->mi_col_end, cb = r + n4 < t->mi_row_end;
+            const int va = f->m_decoded[ca ? (r + LANE * half - 1) * ms + c + n4 : mi], vb = f->m_decoded[cb ? (r + n4) * ms + c + LANE * half - 1 : mi];
+            sfl_r[LANE] = ca && va; sfl_b[LANE] = cb && vb;
+          }
         }
         WG_SYNC();
-        // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs) from the staged neighbour contexts
-        int ssc, sdc;
-        {
-          int top = 0, left = 0, dcs = 0;
-#pragma unroll
-          for (int k2 = 0; k2 < half; k2++) {
-            int l, d;
-            if ((q >> 1) == 0) { l = SH->nb_top[(q & 1) * half + k2][0]; d = SH->nb_top[(q & 1) * half + k2][1]; } else { l = SH->sub_cul[q - 2]; d = SH->sub_dcc[q - 2]; }
-            top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-            if ((q & 1) == 0) { l = SH->nb_left[(q >> 1) * half + k2][0]; d = SH->nb_left[(q >> 1) * half + k2][1]; } else { l = SH->sub_cul[q - 1]; d = SH->sub_dcc[q - 1]; }
-            left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+#pragma unroll 1
+        for (int q = 0; q < G * G; q++) {
+          // costs only grow: once the split can neither beat the best transform size so far nor stay below the caller's budget
+          // (then the best so far is above the budget too and the caller discards this block) the rest is skipped
+          if (j_split >= budget && luma_j >= budget) return true;   // wave-uniform
+          if (!(j_split < luma_j)) break;
+          const int bi = q / G, bj = q % G;
+          const int sx = x + bj * hn, sy = y + bi * hn;
+          const int sU = availU || bi, sL = availL || bj;
+          if (W == 0) {
+            // raw edges of the sub-block (spec 7.11.2; load_edges with the samples taken from the block's raw edges, the sub-blocks
+            // reconstructed so far, or -- beyond the block's right / bottom edge -- the frame)
+            const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
+            const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
+            LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+            const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+            const uint16_t *grec = f->rec[0];
+            const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
+            auto px = [&](int ax, int ay) -> int {                  // absolute sample position -> value
+              const int xr = ax - x, yr = ay - y;
+              if (xr >= 0 && xr < n && yr >= 0 && yr < n) return (int)split_rec[yr * n + xr];
+              if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
+              if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
+              return (int)grec[(size_t)ay * rs + ax];
+            };
+            for (int i = LANE; i <= 2 * hn; i += 64) {
+              const bool corner = i == 2 * hn;
+              int a, l;
+              if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+              if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+              if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+              if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+            }
+            WAVE_SYNC();
+            predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, spred);
           }
-          sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
-          if (top == 0 && left == 0) ssc = 1;
-          else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
-          else if (imax_(top, left) <= 3) ssc = 4;
-          else if (imin_(top, left) <= 3) ssc = 5;
-          else ssc = 6;
-        }
-        // psychovisual references of the sub-block
-        if (W == 0) {
-          constexpr int scp = hn >= 8 ? hn / 8 : 1, pcp = n / 8;
-          if (LANE < scp * scp) {
-            if constexpr (hn == 4) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; }
-            else { const int pc = ((q >> 1) * scp + LANE / scp) * pcp + (q & 1) * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
-          }
-        }
-        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
-        if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
-          const int g = GROUP_ID, e = W * 4 + g;
-          constexpr int pcp = n / 8;
-          const int psv_q = hn == 4 ? SH->psv4[q] : SH->psv[(q >> 1) * pcp + (q & 1)], pact_q = hn == 4 ? SH->pact[0] : SH->pact[(q >> 1) * pcp + (q & 1)];
-          if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
-            const bool live = e < sntx;
-            int txtype;
-            if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
-            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-            GroupRes gr;
-            eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
-                           f->tune_psnr ? -1 : psv_q, pact_q, &gr);
-            long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
-            if (!live) j = J_INF;
+          WG_SYNC();
+          // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs) from the staged neighbour contexts
+          int ssc, sdc;
+          {
+            int top = 0, left = 0, dcs = 0;
 #pragma unroll
-            for (int gg = 0; gg < 4; gg++) {
-              const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
-              const int eg = __builtin_amdgcn_readlane(e, gg * 16);
-              if (jg < sj || (jg == sj && eg < se)) {
-                sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
-                s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+            for (int k2 = 0; k2 < half; k2++) {
+              int l, d;
+              if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; }
+              top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+              if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; }
+              left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+            }
+            sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+            if (top == 0 && left == 0) ssc = 1;
+            else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+            else if (imax_(top, left) <= 3) ssc = 4;
+            else if (imin_(top, left) <= 3) ssc = 5;
+            else ssc = 6;
+          }
+          // psychovisual references of the sub-block: its own variance (4x4) or its 8x8 cells', and the activity of the 8x8 cells it lies in
+          constexpr int pcp = n >= 8 ? n / 8 : 1;
+          if (W == 0) {
+            constexpr int scp = hn >= 8 ? hn / 8 : 1;
+            if (LANE < scp * scp) {
+              if constexpr (hn == 4) { SH->spsv[0] = n == 8 ? SH->psv4[q] : psv16[q]; SH->spact[0] = SH->pact[(bi >> 1) * pcp + (bj >> 1)]; }
+              else { const int pc = (bi * scp + LANE / scp) * pcp + bj * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
+            }
+          }
+          long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
+          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
+            const int g = GROUP_ID, e = W * 4 + g;
+            const int psv_q = hn == 4 ? (n == 8 ? SH->psv4[q] : psv16[q]) : SH->psv[bi * pcp + bj];
+            const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
+            if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
+              const bool live = e < sntx;
+              int txtype;
+              if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
+              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+              GroupRes gr;
+              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
+                             f->tune_psnr ? -1 : psv_q, pact_q, &gr);
+              long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+              if (!live) j = J_INF;
+#pragma unroll
+              for (int gg = 0; gg < 4; gg++) {
+                const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+                const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+                if (jg < sj || (jg == sj && eg < se)) {
+                  sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
+                  s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+                }
               }
             }
+          } else {
+            WG_SYNC();                                           // spsv / spact staged by wave 0
+            for (int e = W; e < sntx; e += NW) {
+              int txtype;
+              if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
+              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+              TxRes tr;
+              const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
+                                                     SH->ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
+              if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
+            }
           }
-        } else {
-          WG_SYNC();                                           // spsv / spact staged by wave 0
-          for (int e = W; e < sntx; e += NW) {
-            int txtype;
-            if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
-            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-            TxRes tr;
-            const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
-                                                   SH->ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
-            if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
+          if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+          WG_SYNC();
+          int sw = 0;
+          for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
+          const long long sub_j = SH->wbest_j[sw];
+          if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
+            const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
+            if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
+            const int ro = bi * hn * n + bj * hn;
+            for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
+            for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
+            if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
+          }
+          WG_SYNC();
+          sub_any |= sub_eob[q] > 0;
+          j_split += sub_j;
+        }
+        if (j_split < luma_j) {
+          // this depth wins: its reconstruction, levels and contexts replace the best so far in the frame
+          luma_j = j_split; any_coef = sub_any;
+          const int tid = threadIdx.x, T = 64 * NW;
+          uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x;
+          int32_t *gc_ = f->coef[0] + (size_t)y * f->stride + x;
+          for (int i = tid; i < nn; i += T) { const uint16_t v = split_rec[i]; gr_[(i / n) * f->stride + (i % n)] = v; if (f->np > 1) SH->luma_rec[i] = v; }
+          for (int i = tid; i < G * G * sqn; i += T) { const int q = i / sqn, j2 = i - q * sqn; gc_[((q / G) * hn + j2 / SCS) * f->stride + (q % G) * hn + j2 % SCS] = split_qc[i]; }
+          if (W == 0) {
+            fill_map_dev(f->m_txsize, ms, r, c, n4, SBS);
+#pragma unroll 1
+            for (int q = 0; q < G * G; q++) {
+              const int rr = r + (q / G) * half, cc = c + (q % G) * half;
+              fill_map_dev(f->m_lvl[0], ms, rr, cc, half, sub_cul[q]);
+              fill_map_dev(f->m_dc[0], ms, rr, cc, half, sub_dcc[q]);
+              fill_map_dev(f->m_txtype, ms, rr, cc, half, sub_tx[q]);
+              if (LANE == 0) f->m_eob[0][rr * ms + cc] = (uint16_t)sub_eob[q];
+            }
           }
         }
-        if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
         WG_SYNC();
-        int sw = 0;
-        for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
-        const long long sub_j = SH->wbest_j[sw];
-        if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
-          const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
-          const int ro = (q >> 1) * hn * n + (q & 1) * hn;
-          for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
-          for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
-          if (LANE == 0) { SH->sub_eob[q] = s_eob; SH->sub_cul[q] = s_cul; SH->sub_dcc[q] = s_dcc; SH->sub_tx[q] = s_eob ? stx : DCT_DCT; }
-        }
-        WG_SYNC();
-        sub_any |= SH->sub_eob[q] > 0;
-        j_split += sub_j;
-      }
-      if (j_split < luma_j) {
-        // the split wins: its reconstruction, levels and contexts replace the undivided transform's in the frame
-        luma_j = j_split; any_coef = sub_any;
-        const int tid = threadIdx.x, T = 64 * NW;
-        uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x;
-        int32_t *gc_ = f->coef[0] + (size_t)y * f->stride + x;
-        for (int i = tid; i < nn; i += T) { const uint16_t v = split_rec[i]; gr_[(i / n) * f->stride + (i % n)] = v; if (f->np > 1) SH->luma_rec[i] = v; }
-        for (int i = tid; i < 4 * sqn; i += T) { const int q = i / sqn, j2 = i - q * sqn; gc_[((q >> 1) * hn + j2 / SCS) * f->stride + (q & 1) * hn + j2 % SCS] = split_qc[i]; }
-        if (W == 0) {
-          fill_map_dev(f->m_txsize, ms, r, c, n4, SBS);
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
-            fill_map_dev(f->m_lvl[0], ms, rr, cc, half, SH->sub_cul[q]);
-            fill_map_dev(f->m_dc[0], ms, rr, cc, half, SH->sub_dcc[q]);
-            fill_map_dev(f->m_txtype, ms, rr, cc, half, SH->sub_tx[q]);
-            if (LANE == 0) f->m_eob[0][rr * ms + cc] = (uint16_t)SH->sub_eob[q];
-          }
-        }
-      }
-      WG_SYNC();
+        return false;
+      };
+      if (trial(std::integral_constant<int, 1>{})) return luma_j;
+      if constexpr (BS >= BS_16 && MI_TX_DEPTH_MAX >= 2) if (trial(std::integral_constant<int, 2>{})) return luma_j;
     }
   }
   PH(13);

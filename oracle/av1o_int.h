@@ -6,6 +6,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* rav1e rdo_tx_size_type searches tx_depth 0..2 (rdo_tx_depth = 2) when rdo_tx_decision is on; 1 = one level only (round-2 behaviour) */
+#ifndef AV1O_TX_DEPTH_MAX
+#define AV1O_TX_DEPTH_MAX 2
+#endif
+
 #define MI 4
 #define SB 64
 #define SB_MI 16

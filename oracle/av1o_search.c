@@ -203,9 +203,11 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
       }
     }
   }
-  /* ---- luma transform size (rav1e rdo_tx_size_type; TX_MODE_SELECT): the largest transform against four transforms one
-   * level smaller, same prediction mode, each sub-block predicted from the reconstruction of the ones before it (spec
-   * transform_block) and free to pick its own tx type.  Depth 2 is not searched. */
+  /* ---- luma transform size (rav1e rdo_tx_size_type; TX_MODE_SELECT, rdo_tx_depth = 2): the largest transform against the
+   * transforms one and two levels smaller (tx_depth 1 and 2: 2x2 / 4x4 transform blocks in raster order), same prediction mode,
+   * each sub-block predicted from the reconstruction of the ones before it (spec transform_block) and free to pick its own tx
+   * type.  A depth is abandoned as soon as its running cost reaches the best so far; the frame buffers always hold the trial in
+   * progress, the best split so far waits in a snapshot of the block's area. */
   int txs_final = bs, any_coef = best_tr.eob > 0;
   if (f->tx_mode_select && bs > BS_4) {
     const int maxw = 4 << bs;
@@ -213,36 +215,44 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     const uint32_t *dcost = f->cost + CDF_TX_SIZE + ((bs - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     best_j += ((int64_t)dcost[0] * f->rdmult[0] + 256) >> 9;
     if (f->cfg.rdo_tx) {
-      const int half = n4 >> 1, hn = n >> 1, stx = bs - 1;
-      int64_t j_split = best_mode_j + (((int64_t)dcost[1] * f->rdmult[0] + 256) >> 9);
-      int sub_any = 0;
-      static uint16_t spred[32 * 32], srec[2][32 * 32]; static int32_t sqc[2][32 * 32];
-      int stx_ns, stx_set;
-      const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
-      const int sntx = stx_off >= 0 ? stx_ns : 1;
-      for (int k = 0; k < 4 && j_split < best_j; k++) {
-        const int rr = r + (k >> 1) * half, cc = c + (k & 1) * half;
-        const int sU = availU || (k >> 1), sL = availL || (k & 1);
-        const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
-        const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
-        av1o_predict_intra(f, t, 0, cc * 4, rr * 4, log2w - 1, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
-        int64_t bj = INT64_MAX; int btx = DCT_DCT, cur = 0; TxRes btr = { 0, 0, 0, 0, 0 };
-        for (int ti = 0; ti < sntx; ti++) {
-          int txtype;
-          if (sntx > 1) txtype = av1o_symbol_to_tx_type(stx_set, ti);
-          else { txtype = av1o_mode_to_txtype(best_mode); if (stx_off < 0 || !av1o_tx_type_in_set(stx_set, txtype)) txtype = DCT_DCT; }
-          TxRes tr;
-          const int64_t j = eval_tx(s, 0, rr, cc, stx, bs, spred, txtype, stx_off, stx_off >= 0 ? av1o_tx_type_to_symbol(stx_set, txtype) : 0, stx_ns, srec[cur], sqc[cur], &tr);
-          if (j < bj) { bj = j; btx = txtype; btr = tr; cur ^= 1; }
+      static AreaSnap split_snap;
+      const int max_depth = bs >= BS_16 ? AV1O_TX_DEPTH_MAX : 1;
+      for (int d = 1; d <= max_depth; d++) {
+        const int G = 1 << d, half = n4 >> d, hn = n >> d, stx = bs - d;
+        int64_t j_split = best_mode_j + (((int64_t)dcost[d] * f->rdmult[0] + 256) >> 9);
+        int sub_any = 0;
+        static uint16_t spred[32 * 32], srec[2][32 * 32]; static int32_t sqc[2][32 * 32];
+        int stx_ns, stx_set;
+        const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
+        const int sntx = stx_off >= 0 ? stx_ns : 1;
+        for (int k = 0; k < G * G && j_split < best_j; k++) {
+          const int bi = k / G, bj_ = k % G;
+          const int rr = r + bi * half, cc = c + bj_ * half;
+          const int sU = availU || bi, sL = availL || bj_;
+          const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
+          const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
+          av1o_predict_intra(f, t, 0, cc * 4, rr * 4, log2w - d, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
+          int64_t bj = INT64_MAX; int btx = DCT_DCT, cur = 0; TxRes btr = { 0, 0, 0, 0, 0 };
+          for (int ti = 0; ti < sntx; ti++) {
+            int txtype;
+            if (sntx > 1) txtype = av1o_symbol_to_tx_type(stx_set, ti);
+            else { txtype = av1o_mode_to_txtype(best_mode); if (stx_off < 0 || !av1o_tx_type_in_set(stx_set, txtype)) txtype = DCT_DCT; }
+            TxRes tr;
+            const int64_t j = eval_tx(s, 0, rr, cc, stx, bs, spred, txtype, stx_off, stx_off >= 0 ? av1o_tx_type_to_symbol(stx_set, txtype) : 0, stx_ns, srec[cur], sqc[cur], &tr);
+            if (j < bj) { bj = j; btx = txtype; btr = tr; cur ^= 1; }
+          }
+          commit_plane(f, 0, rr, cc, stx, srec[cur ^ 1], sqc[cur ^ 1], &btr);
+          fill_map(f->m_txtype, ms, rr, cc, half, btr.eob ? btx : DCT_DCT);
+          set_decoded(f, rr, cc, stx, 1);
+          sub_any |= btr.eob > 0;
+          j_split += bj;
         }
-        commit_plane(f, 0, rr, cc, stx, srec[cur ^ 1], sqc[cur ^ 1], &btr);
-        fill_map(f->m_txtype, ms, rr, cc, half, btr.eob ? btx : DCT_DCT);
-        set_decoded(f, rr, cc, stx, 1);
-        sub_any |= btr.eob > 0;
-        j_split += bj;
+        set_decoded(f, r, c, bs, 0);
+        if (j_split < best_j) {
+          best_j = j_split; txs_final = stx; any_coef = sub_any;
+          if (d < max_depth) area_copy(f, &split_snap, r, c, bs, 1);       /* a deeper trial is about to overwrite the area */
+        } else if (txs_final != bs && txs_final != stx) area_copy(f, &split_snap, r, c, bs, 0);   /* the shallower split stays */
       }
-      set_decoded(f, r, c, bs, 0);
-      if (j_split < best_j) { best_j = j_split; txs_final = stx; any_coef = sub_any; }
     }
   }
   if (txs_final == bs) {
