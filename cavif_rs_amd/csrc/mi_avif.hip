@@ -75,7 +75,16 @@ struct FramePlan;
 static size_t zeroed_bytes(const FramePlan &p);
 
 static int lr_units_host(uint32_t size) { const int n = ((int)size + 32) / 64; return n < 1 ? 1 : n; }
-static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + 6 * 65 * sizeof(long long); }
+static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + (size_t)p.sb_rows * p.tiles.cols * sizeof(int); }
+// Row workers per tile the tile search may use (tile_search.h): no more than the tile's superblock rows, nor than the two-superblock lag
+// lets run side by side, nor MI_K1_MAX_WORKERS; the frame's snapshot area is sized for it.
+#define MI_K1_MAX_WORKERS 16
+static int frame_max_workers(const FramePlan &p) {
+  int rows = 1, cols = 1;
+  for (int i = 0; i < p.tiles.rows; i++) rows = std::max(rows, std::min(p.tiles.row_start[i + 1], p.sb_rows) - p.tiles.row_start[i]);
+  for (int i = 0; i < p.tiles.cols; i++) cols = std::max(cols, std::min(p.tiles.col_start[i + 1], p.sb_cols) - p.tiles.col_start[i]);
+  return std::max(1, std::min(MI_K1_MAX_WORKERS, std::min(rows, (cols + 1) / 2)));
+}
 
 static void plan_geometry(FramePlan &p) {
   const mi_av1_config &c = p.cfg;
@@ -108,6 +117,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.m_cfl_sign = take(nmi); d.m_cfl_au = take(nmi); d.m_cfl_av = take(nmi); d.m_txsize = take(nmi);
   // state the kernels expect zeroed before every encode, in one block (one memset): decoded flags + deblock tallies
   d.m_decoded = take(zeroed_bytes(p)); d.lf_tally = (long long *)(d.m_decoded + align_up(nmi, 256));
+  d.sb_prog = (int *)(d.m_decoded + align_up(nmi, 256) + align_up(6 * 65 * sizeof(long long), 256));
   d.lf_out = (int *)take(64);
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
@@ -118,7 +128,8 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     d.lr_type = take(nlr); d.lr_set = take(nlr); d.lr_xqd = (int8_t *)take(nlr * 2);
     d.lr_cand = p.cfg.lrf ? take(nlr * 16 * sizeof(LrCand)) : nullptr;
   }
-  d.snap = take((size_t)p.ntiles * MI_SNAP_BYTES_ALL(4 << p.maxbs));
+  d.snap_rows = frame_max_workers(p);
+  d.snap = take((size_t)p.ntiles * d.snap_rows * MI_SNAP_BYTES_ALL(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
@@ -170,11 +181,18 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
-template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+// `max_workers`: the smallest snap_rows among the launch's frames.  A launch that does not fill the GPU with one workgroup per tile
+// (single images: 8 .. 512 tiles against 1024 resident workgroups of the 16x16 class, 256 of the others) gets row workers;
+// MI_K1_WORKERS=n forces n (clamped), =1 switches them off.
+template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
   const size_t lds = k1_lds_bytes<MAXBS, NW>();
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(njobs), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs);
+  const int resident = (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1) * 256;
+  static const int forced = [] { const char *v = getenv("MI_K1_WORKERS"); return v ? atoi(v) : 0; }();
+  int workers = forced > 0 ? forced : resident / std::max(njobs, 1);
+  workers = std::max(1, std::min(workers, max_workers));
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(njobs * workers), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs, workers);
   return hipGetLastError();
 }
 // jobs must all belong to frames of the same block-size class
@@ -186,16 +204,16 @@ static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const Tile
   return hipGetLastError();
 }
 // every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch
-static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, hipStream_t s) {
+static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   if (bottomup) {
-    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, njobs, s);
-    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, njobs, s);
-    return launch_search_t<4, 1, true>(d_frames, d_jobs, njobs, s);
+    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, njobs, max_workers, s);
+    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, njobs, max_workers, s);
+    return launch_search_t<4, 1, true>(d_frames, d_jobs, njobs, max_workers, s);
   }
-  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, njobs, s);
-  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, njobs, s);
-  return launch_search_t<4, 1, false>(d_frames, d_jobs, njobs, s);     // 64x64 blocks: alpha (4:0:0) frames only
+  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, njobs, max_workers, s);
+  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, njobs, max_workers, s);
+  return launch_search_t<4, 1, false>(d_frames, d_jobs, njobs, max_workers, s);     // 64x64 blocks: alpha (4:0:0) frames only
 }
 
 }  // namespace mi
@@ -492,7 +510,11 @@ int mi_batch_encode_async(mi_batch *b) {
   { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
     hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
   HIP_OK(hipEventRecord(b->ev[1], s));
-  for (int cls = 2; cls <= 4; cls++) HIP_OK(launch_search(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], s));
+  for (int cls = 2; cls <= 4; cls++) {
+    int max_workers = MI_K1_MAX_WORKERS;
+    for (auto &p : b->frames) if (std::max(p.maxbs, 2) == cls) max_workers = std::min(max_workers, p.dev.snap_rows);
+    HIP_OK(launch_search(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], max_workers, s));
+  }
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
   HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
@@ -847,7 +869,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
   hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
-  HIP_OK(launch_search(p.maxbs, p.cfg.encode_bottomup != 0, d_frame, d_jobs, njobs, s));
+  HIP_OK(launch_search(p.maxbs, p.cfg.encode_bottomup != 0, d_frame, d_jobs, njobs, p.dev.snap_rows, s));
   HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   HIP_OK(hipGetLastError());

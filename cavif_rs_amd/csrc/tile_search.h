@@ -1202,10 +1202,16 @@ static_assert(MI_PROFILE || k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit fo
 
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs) {
+// `workers` workgroups per tile (row workers, x265-WPP / libaom row-mt style): worker g searches the tile's superblock rows g, g + workers, ...
+// and starts a superblock once the row above is two superblocks ahead (its above-right neighbour is final).  Legal because the search
+// prices against static rate tables: a superblock depends on its left / above / above-right neighbours' reconstruction, mode info and
+// decoded flags only; the block order inside a superblock and every decision are unchanged.  Progress per (frame SB row, tile column)
+// goes through f->sb_prog with release / acquire at device scope.  Workers of a tile sit next to each other in the grid (the one a
+// worker waits for always has a lower block id and was dispatched first).  workers == 1: one workgroup per tile, no waiting.
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, int workers) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
-  const int job = blockIdx.x;
+  const int job = blockIdx.x / workers, wk = blockIdx.x - job * workers;
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
   const FrameDev *gf = frames + tj.frame;
@@ -1225,7 +1231,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     LDS TileB *t = &k.sh()->tile;
     t->mi_row_start = gf->tile_row_start[tj.tile_row] * 16; t->mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, gf->mi_rows);
     t->mi_col_start = gf->tile_col_start[tj.tile_col] * 16; t->mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, gf->mi_cols);
-    k.sh()->snap = gf->snap + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * MI_SNAP_BYTES_ALL(MAXN);
+    k.sh()->snap = gf->snap + ((size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * gf->snap_rows + wk) * MI_SNAP_BYTES_ALL(MAXN);
   }
   WG_SYNC();
   const LDS FrameDev *f = lf;
@@ -1236,11 +1242,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   if (DBG_IS(f, 1)) return;
   const unsigned long long clk0 = wall_clock64();
   const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
-  for (int r = row0; r < row1; r += 16)
-    for (int c = col0; c < col1; c += 16) {
+  const int ncols = (col1 - col0 + 15) >> 4;
+  for (int r = row0 + 16 * wk; r < row1; r += 16 * workers) {
+    int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;       // this row's counter; the row above: prog - tile_cols
+    for (int c = col0, ci = 0; c < col1; c += 16, ci++) {
+      if (workers > 1 && r > row0) {
+        if (threadIdx.x == 0) {
+          const int need = imin_(ci + 2, ncols);
+          while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+        }
+        WG_SYNC();
+      }
       if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
+      if (workers > 1) {
+        WG_SYNC();                                                                   // every wave's stores of this superblock are issued
+        if (threadIdx.x == 0) __hip_atomic_store(prog, ci + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-  if (threadIdx.x == 0) { unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
+  }
+  if (threadIdx.x == 0 && wk == 0) { unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
 #if MI_PROFILE
   WG_SYNC();
   if (gf->prof_out && threadIdx.x < 128) gf->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];

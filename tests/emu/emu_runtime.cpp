@@ -109,6 +109,7 @@ int xlane(int kind, int val, int old, int p0, int rm, int bm, int bc, int site) 
 void wave_barrier() { yield_to_scheduler(W_WAVE); }
 void wg_barrier() { yield_to_scheduler(W_WG); }
 unsigned long long ticks() { return ++W.tick; }
+void spin_yield() { std::this_thread::yield(); }
 
 // source lane of a DPP control for `lane`, -1 when there is none (CDNA3 ISA 12.x "DPP")
 static int dpp_src(int ctrl, int lane) {
@@ -245,7 +246,9 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       run_block(w, (int)nthreads);
     }
   };
-  static const unsigned hw = [] { const char *e = getenv("MI_EMU_THREADS"); unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency(); return n ? n : 1u; }();
+  // workgroups are claimed in block order; a kernel whose workgroups wait for earlier ones (the tile search's row workers, up to 16 per
+  // tile) needs that many of them in flight, so the pool is never smaller than 32 OS threads
+  static const unsigned hw = [] { const char *e = getenv("MI_EMU_THREADS"); unsigned n = e ? (unsigned)atoi(e) : std::max(32u, std::thread::hardware_concurrency()); return n ? n : 1u; }();
   const unsigned nt = (unsigned)(nblocks < hw ? nblocks : hw);
   if (nt <= 1) { work(); return; }
   std::vector<std::thread> th;

@@ -41,6 +41,7 @@ void wave_barrier();
 void wg_barrier();
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
 unsigned long long ticks();
+void spin_yield();
 }
 extern thread_local emu::Idx3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
@@ -54,7 +55,7 @@ extern thread_local alignas(16) uint8_t k4_smem[];
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::xlane(emu::X_DPP, (int)(src), (int)(old), (int)(ctrl), (int)(rm), (int)(bm), (int)(bc), __COUNTER__)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) emu::spin_yield()      /* a workgroup waiting for another one: let its OS thread run */
 inline int __shfl(int v, int src, int width = 64) { (void)width; return emu::xlane(emu::X_SHFL, v, 0, src, 0, 0, 0, -1); }
 inline void __syncthreads() { emu::wg_barrier(); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
@@ -66,6 +67,9 @@ inline unsigned long long wall_clock64() { return emu::ticks(); }
 // global / LDS atomics: workgroups of one launch may run on several OS threads
 template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
+#define __hip_atomic_store(ptr, v, order, scope) __atomic_store_n((ptr), (v), (order))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
 struct uchar4 { unsigned char x, y, z, w; };
 inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{ x, y, z, w }; }
