@@ -167,6 +167,7 @@ static bool resolve_wave(Worker &w, int base, int n, bool force) {
   }
   return progress;
 }
+static const bool reverse_lanes = getenv("MI_EMU_REVERSE") != nullptr;
 static void run_block(Worker &w, int nthreads) {
   if ((int)w.fib.size() < nthreads) w.fib.resize(nthreads, Fiber{ nullptr, nullptr, W_DONE, {}, 0 });
   for (int t = 0; t < nthreads; t++) fiber_init(w.fib[t]);
@@ -175,10 +176,12 @@ static void run_block(Worker &w, int nthreads) {
   int done = 0;
   while (done < nthreads) {
     bool progress = false;
-    for (int wv = 0; wv < nwaves; wv++) {
+    for (int wi = 0; wi < nwaves; wi++) {
+      const int wv = reverse_lanes ? nwaves - 1 - wi : wi;
       const int base = wv * 64, n = nthreads - base < 64 ? nthreads - base : 64;
-      for (int l = 0; l < n; l++) {                 // every runnable lane goes on to its next meeting point
-        Fiber &f = w.fib[base + l];
+      for (int li = 0; li < n; li++) {              // every runnable lane goes on to its next meeting point
+        const int l = reverse_lanes ? n - 1 - li : li;   // MI_EMU_REVERSE=1: a kernel whose result depends on the order in which the lanes of a
+        Fiber &f = w.fib[base + l];                      // wavefront pass between two meeting points has an unsynchronised exchange
         if (f.wait != W_RUN) continue;
         w.cur = base + l; threadIdx.x = (unsigned)(base + l);
         emu_switch(&w.sched_sp, f.sp);

@@ -16,7 +16,8 @@ def emu_env(oracle):
     return emu.env()
 
 
-def _run(emu_env, which, timeout):
+def _run(emu_env, which, timeout, **extra):
+    emu_env = dict(emu_env, **extra)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'emu_cases.py'), ROOT, which], env=emu_env, capture_output=True, text=True, timeout=timeout)
     rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
     return p, rows
@@ -28,6 +29,14 @@ def test_emulated_kernels_equal_oracle(emu_env):
     bad = [r['case'] for r in rows if not r['ok']]
     assert not bad and p.returncode == 0, 'emulated HIP path differs from the oracle: %s\n%s' % (bad, p.stderr[-2000:])
     assert len(rows) >= 6
+
+
+def test_emulated_kernels_do_not_depend_on_lane_order(emu_env):
+    """Between two meeting points the emulator runs the lanes of a wavefront one after another; with MI_EMU_REVERSE they (and the waves of
+    a workgroup) run in the opposite order.  A kernel with an unsynchronised LDS / global exchange between lanes gives different bytes."""
+    p, rows = _run(emu_env, 'quick', 900, MI_EMU_REVERSE='1')
+    bad = [r['case'] for r in rows if not r['ok']]
+    assert rows and not bad and p.returncode == 0, 'lane-order dependence: %s\n%s' % (bad, p.stderr[-2000:])
 
 
 def test_product_library_is_not_the_emulator():
