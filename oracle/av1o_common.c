@@ -109,10 +109,10 @@ size_t re_finish(RangeEnc *e, uint8_t **out) {
 /* ---------------- tx type helpers (spec 5.11.47 get_tx_set, 6.10.19 tables) ---------------- */
 static const uint8_t kInvSet1[7] = { IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST };
 static const uint8_t kInvSet2[5] = { IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST };
-int av1o_tx_set(int txs, int reduced) {
-  if (txs >= TX_32X32) return 0;
+int av1o_tx_set(int txs, int reduced) {          /* spec get_tx_set, intra: the larger dimension bounds the set, the smaller picks it */
+  if (dim_max_l(txs) >= 5) return 0;
   if (reduced) return 2;
-  if (txs == TX_16X16) return 2;
+  if (dim_min_l(txs) == 4) return 2;
   return 1;
 }
 int av1o_tx_set_count(int set) { return set == 0 ? 1 : (set == 1 ? 7 : 5); }
@@ -134,14 +134,24 @@ int av1o_tx_class(int t) {
   return TX_CLASS_2D;
 }
 const uint16_t *av1o_scan(int txs, int txtype, uint16_t *tmp) {
-  int n = imin(32, 4 << txs);
+  const int w = imin(32, 1 << dim_wl(txs)), h = imin(32, 1 << dim_hl(txs));
   int cls = av1o_tx_class(txtype);
-  if (cls == TX_CLASS_2D) {
-    switch (n) { case 4: return av1_default_scan_4x4; case 8: return av1_default_scan_8x8;
+  if (cls == TX_CLASS_2D && !dim_is_rect(txs)) {
+    switch (w) { case 4: return av1_default_scan_4x4; case 8: return av1_default_scan_8x8;
                  case 16: return av1_default_scan_16x16; default: return av1_default_scan_32x32; }
   }
-  if (cls == TX_CLASS_VERT) { for (int i = 0; i < n * n; i++) tmp[i] = (uint16_t)i; }           /* mrow scan */
-  else { int k = 0; for (int c = 0; c < n; c++) for (int r = 0; r < n; r++) tmp[k++] = (uint16_t)(r * n + c); } /* mcol */
+  if (cls == TX_CLASS_2D) {
+    /* spec Default_Scan_4x8 / 8x4: plain anti-diagonals; a tall block walks each one from its top-right end, a wide block from its
+     * bottom-left end */
+    int k = 0;
+    for (int d = 0; d < w + h - 1; d++) {
+      if (h > w) { for (int r = 0; r < h; r++) { const int c = d - r; if (c >= 0 && c < w) tmp[k++] = (uint16_t)(r * w + c); } }
+      else { for (int r = h - 1; r >= 0; r--) { const int c = d - r; if (c >= 0 && c < w) tmp[k++] = (uint16_t)(r * w + c); } }
+    }
+    return tmp;
+  }
+  if (cls == TX_CLASS_VERT) { for (int i = 0; i < w * h; i++) tmp[i] = (uint16_t)i; }           /* mrow scan */
+  else { int k = 0; for (int c = 0; c < w; c++) for (int r = 0; r < h; r++) tmp[k++] = (uint16_t)(r * w + c); } /* mcol */
   return tmp;
 }
 
@@ -327,11 +337,11 @@ void av1o_activity(Av1oFrame *f) {
     f->act[cy * cw + cx] = f->cfg.tune_psnr ? 16384u : av1o_psy_boost_q14(v, v);
   }
 }
-/* luma distortion of the n x n block at pixel (x, y): rec has pitch rs */
-int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n) {
-  const int cw = f->pw / 8, w = n == 4 ? 4 : 8;
+/* luma distortion of the bw x bh block at pixel (x, y): rec has pitch rs; 8x8 cells, 4x4 cells when a dimension is 4 */
+int64_t av1o_psy_dist_luma_wh(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int bw, int bh) {
+  const int cw = f->pw / 8, w = imin(bw, bh) == 4 ? 4 : 8;
   int64_t total = 0;
-  for (int by = 0; by < n; by += w) for (int bx = 0; bx < n; bx += w) {
+  for (int by = 0; by < bh; by += w) for (int bx = 0; bx < bw; bx += w) {
     int64_t sd = 0, qd = 0, sse = 0;
     for (int i = 0; i < w; i++) for (int j = 0; j < w; j++) {
       const int d = rec[(by + i) * rs + bx + j], sv = f->src[0][(size_t)(y + by + i) * f->stride + x + bx + j];
@@ -347,6 +357,7 @@ int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int 
   }
   return total;
 }
+int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n) { return av1o_psy_dist_luma_wh(f, rec, rs, x, y, n, n); }
 /* mean activity scale (Q14) of the cells covered by [x, x + w) x [y, y + h) */
 uint32_t av1o_act_mean(const Av1oFrame *f, int x, int y, int w, int h) {
   const int cw = f->pw / 8, cx0 = x >> 3, cx1 = (x + w - 1) >> 3, cy0 = y >> 3, cy1 = (y + h - 1) >> 3;

@@ -7,7 +7,7 @@
 
 /* ---------------- txb contexts (spec: all_zero ctx and dc_sign ctx derivation) ---------------- */
 void av1o_txb_ctx(const Av1oFrame *f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx) {
-  const int w4 = 1 << txs, ms = f->mi_stride;
+  const int w4 = 1 << (dim_wl(txs) - 2), h4 = 1 << (dim_hl(txs) - 2), ms = f->mi_stride;
   int top = 0, left = 0, dcs = 0, any_a = 0, any_l = 0;
   if (r4 - 1 >= t->mi_row_start) {
     for (int k = 0; k < w4; k++) if (c4 + k < f->mi_cols) {
@@ -16,7 +16,7 @@ void av1o_txb_ctx(const Av1oFrame *f, const TileB *t, int plane, int r4, int c4,
     }
   }
   if (c4 - 1 >= t->mi_col_start) {
-    for (int k = 0; k < w4; k++) if (r4 + k < f->mi_rows) {
+    for (int k = 0; k < h4; k++) if (r4 + k < f->mi_rows) {
       int l = f->m_lvl[plane][(r4 + k) * ms + c4 - 1], d = f->m_dc[plane][(r4 + k) * ms + c4 - 1];
       left = imax(left, l); any_l |= l | d; dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
     }
@@ -32,7 +32,7 @@ void av1o_txb_ctx(const Av1oFrame *f, const TileB *t, int plane, int r4, int c4,
     else ctx = 6;
     *skip_ctx = ctx;
   } else {
-    *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (bs > txs ? 3 : 0);
+    *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (dim_wl(bs) + dim_hl(bs) > dim_wl(txs) + dim_hl(txs) ? 3 : 0);
   }
 }
 
@@ -41,8 +41,8 @@ void av1o_code_coeffs(const Av1oFrame *f, const int32_t *qc, int eob, int plane,
                       int skip_ctx, int dc_ctx, int tx_cdf_off, int tx_sym, int tx_nsyms,
                       const SymSink *k, int *cul_level, int *dc_cat) {
   (void)f;
-  const int n = imin(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
-  const int txs_ctx = txs;                         /* square: (sqr + sqr_up + 1) >> 1 == txs */
+  const int bwl = imin(5, dim_wl(txs)), bhl = imin(5, dim_hl(txs)), n = 1 << bwl, nh = 1 << bhl;   /* coded area n wide, nh high */
+  const int txs_ctx = (dim_min_l(txs) - 2 + dim_max_l(txs) - 2 + 1) >> 1;                            /* (sqr + sqr_up + 1) >> 1 */
   const int pt = plane > 0;
   const int cls = av1o_tx_class(txtype);
   *cul_level = 0; *dc_cat = 0;
@@ -55,7 +55,7 @@ void av1o_code_coeffs(const Av1oFrame *f, const int32_t *qc, int eob, int plane,
   int eob_pt, eob_extra_bits = 0;
   if (eob < 3) eob_pt = eob; else { eob_pt = 32 - __builtin_clz((uint32_t)(eob - 1)) + 1; }
   /* eob_pt: eob=1 ->1, 2 ->2, 3..4 ->3, 5..8 ->4, ... ; base = (1 << (eob_pt-2)) + 1 */
-  const int eob_multi = 2 * bwl - 4;               /* 0..6 */
+  const int eob_multi = bwl + bhl - 4;             /* 0..6 */
   static const int pt_off[7] = { CDF_EOB_PT_16, CDF_EOB_PT_32, CDF_EOB_PT_64, CDF_EOB_PT_128, CDF_EOB_PT_256, CDF_EOB_PT_512, CDF_EOB_PT_1024 };
   static const int pt_str[7] = { CDF_EOB_PT_16_STRIDE, CDF_EOB_PT_32_STRIDE, CDF_EOB_PT_64_STRIDE, CDF_EOB_PT_128_STRIDE,
                                  CDF_EOB_PT_256_STRIDE, CDF_EOB_PT_512_STRIDE, CDF_EOB_PT_1024_STRIDE };
@@ -70,9 +70,9 @@ void av1o_code_coeffs(const Av1oFrame *f, const int32_t *qc, int eob, int plane,
   /* level map with a 4-wide zero border to the right/bottom */
   const int st = n + 4;
   static uint8_t lev[(32 + 4) * (32 + 4)];
-  memset(lev, 0, (size_t)st * (size_t)(n + 4));
+  memset(lev, 0, (size_t)st * (size_t)(nh + 4));
   for (int i = 0; i < eob; i++) { int p = scan[i]; int a = iabs(qc[p]); lev[(p >> bwl) * st + (p & (n - 1))] = (uint8_t)imin(a, 127); }
-  const int area = n * n;
+  const int area = n * nh;
   for (int c = eob - 1; c >= 0; c--) {
     const int p = scan[c], row = p >> bwl, col = p & (n - 1);
     const int level = iabs(qc[p]);
@@ -86,6 +86,8 @@ void av1o_code_coeffs(const Av1oFrame *f, const int32_t *qc, int eob, int plane,
         mag += imin(L[st + 1], 3) + imin(L[2], 3) + imin(L[2 * st], 3);
         int m = imin((mag + 1) >> 1, 4);
         if (row == 0 && col == 0) ctx = 0;
+        else if (bhl > bwl) ctx = m + (row < 2 ? 11 : (row + col < 4 ? 6 : 21));      /* spec Coeff_Base_Ctx_Offset, tall transforms */
+        else if (bwl > bhl) ctx = m + (col < 2 ? 16 : (row + col < 4 ? 6 : 21));      /* wide transforms */
         else if (row + col < 2) ctx = m + 1;
         else if (row + col < 4) ctx = m + 6;
         else ctx = m + 21;
@@ -164,8 +166,9 @@ int av1o_intra_tx_cdf(const Av1oFrame *f, int txs, int ymode, int *nsyms, int *s
   int set = av1o_tx_set(txs, f->cfg.reduced_tx_set);
   *set_out = set;
   if (set == 0 || f->base_q_idx == 0) { *nsyms = 0; return -1; }
-  if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + (txs * 13 + ymode) * CDF_INTRA_TX1_STRIDE; }
-  *nsyms = 5; return CDF_INTRA_TX2 + (txs * 13 + ymode) * CDF_INTRA_TX2_STRIDE;
+  const int sq = dim_min_l(txs) - 2;                /* the CDFs are indexed by the square size of the smaller dimension */
+  if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + (sq * 13 + ymode) * CDF_INTRA_TX1_STRIDE; }
+  *nsyms = 5; return CDF_INTRA_TX2 + (sq * 13 + ymode) * CDF_INTRA_TX2_STRIDE;
 }
 
 static void write_block(TileW *w, int r, int c, int bs) {
@@ -186,12 +189,13 @@ static void write_block(TileW *w, int r, int c, int bs) {
   const int ymode = f->m_ymode[mi];
   const int am = intra_mode_ctx[availU ? f->m_ymode[mi - ms] : DC_PRED], lm = intra_mode_ctx[availL ? f->m_ymode[mi - 1] : DC_PRED];
   re_symbol(&w->ec, ymode, w->cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
-  if (bs >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
+  const int big = dim_min_l(bs) >= 3;                /* angle deltas: blocks of at least 8x8 */
+  if (big && ymode >= V_PRED && ymode <= D67_PRED)
     re_symbol(&w->ec, f->m_angle_y[mi] + 3, w->cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
   int uvmode = 0;
   if (f->np > 1) {
     uvmode = f->m_uvmode[mi];
-    if (bs <= BS_32) re_symbol(&w->ec, uvmode, w->cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
+    if (dim_max_l(bs) <= 5) re_symbol(&w->ec, uvmode, w->cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
     else re_symbol(&w->ec, uvmode, w->cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
     if (uvmode == UV_CFL_PRED) {
       int js = f->m_cfl_sign[mi], su = (js + 1) / 3, sv = (js + 1) % 3;
@@ -199,27 +203,29 @@ static void write_block(TileW *w, int r, int c, int bs) {
       if (su) re_symbol(&w->ec, f->m_cfl_au[mi], w->cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
       if (sv) re_symbol(&w->ec, f->m_cfl_av[mi], w->cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
     }
-    if (bs >= BS_8 && uvmode >= V_PRED && uvmode <= D67_PRED)
+    if (big && uvmode >= V_PRED && uvmode <= D67_PRED)
       re_symbol(&w->ec, f->m_angle_uv[mi] + 3, w->cdf + CDF_ANGLE + (uvmode - V_PRED) * CDF_ANGLE_STRIDE, 7);
   }
   /* read_block_tx_size(): tx_depth for every intra block above 4x4 under TX_MODE_SELECT, coded even when skip */
   const int txs_y = f->m_txsize[mi];
-  if (f->tx_mode_select && bs > BS_4) {
-    const int maxw = 4 << bs;
-    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
-    re_symbol(&w->ec, bs - txs_y, w->cdf + CDF_TX_SIZE + ((bs - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, bs == BS_8 ? 2 : 3);
+  if (f->tx_mode_select && bs != BS_4) {
+    const int actx = availU && dim_wl(f->m_txsize[mi - ms]) >= dim_wl(bs), lctx = availL && dim_hl(f->m_txsize[mi - 1]) >= dim_hl(bs);
+    const int cat = dim_is_rect(bs) ? 0 : bs - 1;
+    const int depth = txs_y == bs ? 0 : (dim_is_rect(bs) ? 1 : bs - txs_y);
+    re_symbol(&w->ec, depth, w->cdf + CDF_TX_SIZE + (cat * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, cat == 0 ? 2 : 3);
   }
   if (skip) return;
   /* residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not) */
   static int32_t qc[1024];
   for (int p = 0; p < f->np; p++) {
-    const int txs = p == 0 ? txs_y : bs, n = imin(32, 4 << txs), step = 1 << txs, nblk = 1 << (bs - txs);
-    for (int by = 0; by < nblk; by++) for (int bx = 0; bx < nblk; bx++) {
-      const int rr = r + by * step, cc = c + bx * step, tmi = rr * ms + cc;
+    const int txs = p == 0 ? txs_y : bs, n = imin(32, 1 << dim_wl(txs)), nh = imin(32, 1 << dim_hl(txs));
+    const int stepw = 1 << (dim_wl(txs) - 2), steph = 1 << (dim_hl(txs) - 2), nbw = 1 << (dim_wl(bs) - dim_wl(txs)), nbh = 1 << (dim_hl(bs) - dim_hl(txs));
+    for (int by = 0; by < nbh; by++) for (int bx = 0; bx < nbw; bx++) {
+      const int rr = r + by * steph, cc = c + bx * stepw, tmi = rr * ms + cc;
       if (rr >= f->mi_rows || cc >= f->mi_cols) continue;   /* transform blocks that start outside the frame are not coded */
       const int eob = f->m_eob[p][tmi];
       const int32_t *src = f->coef[p] + (rr * 4) * f->stride + cc * 4;
-      for (int i = 0; i < n; i++) memcpy(qc + i * n, src + i * f->stride, sizeof(int32_t) * (size_t)n);
+      for (int i = 0; i < nh; i++) memcpy(qc + i * n, src + i * f->stride, sizeof(int32_t) * (size_t)n);
       int txtype, off = -1, sym = 0, ns = 0, set;
       if (p == 0) {
         txtype = f->m_txtype[tmi];
@@ -246,9 +252,9 @@ static void write_partition(TileW *w, int r, int c, int bs) {
   const int actual = f->m_bsize[r * ms + c];
   int part = PARTITION_NONE;
   if (bs >= BS_8) {
-    part = actual == bs ? PARTITION_NONE : PARTITION_SPLIT;
+    part = actual == bs ? PARTITION_NONE : (bs == BS_8 && actual == BS_8X4 ? PARTITION_HORZ : (bs == BS_8 && actual == BS_4X8 ? PARTITION_VERT : PARTITION_SPLIT));
     const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-    const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+    const int above = availU && dim_wl(f->m_bsize[(r - 1) * ms + c]) < 2 + bs, left = availL && dim_hl(f->m_bsize[r * ms + c - 1]) < 2 + bs;
     const int ctx = left * 2 + above;
     uint16_t *cdf = w->cdf + CDF_PARTITION + ((bs - 1) * 4 + ctx) * CDF_PARTITION_STRIDE;
     const int ns = bs == BS_8 ? 4 : 10;
@@ -266,6 +272,8 @@ static void write_partition(TileW *w, int r, int c, int bs) {
     } else part = PARTITION_SPLIT;
   }
   if (part == PARTITION_NONE) write_block(w, r, c, bs);
+  else if (part == PARTITION_HORZ) { write_block(w, r, c, BS_8X4); write_block(w, r + 1, c, BS_8X4); }
+  else if (part == PARTITION_VERT) { write_block(w, r, c, BS_4X8); write_block(w, r, c + 1, BS_4X8); }
   else {
     write_partition(w, r, c, bs - 1); write_partition(w, r, c + half, bs - 1);
     write_partition(w, r + half, c, bs - 1); write_partition(w, r + half, c + half, bs - 1);

@@ -7,7 +7,11 @@
 
 /* ------------------------------------------------------------------ deblock */
 /* transform size at a 4x4 position: luma from the block's tx size, chroma (4:4:4) always the block's largest transform */
-static int tx_px(const Av1oFrame *f, int plane, int r, int c) { return plane == 0 ? 4 << f->m_txsize[r * f->mi_stride + c] : 4 << f->m_bsize[r * f->mi_stride + c]; }
+/* transform extent across the edge direction: width for vertical edges (pass 0), height for horizontal ones; chroma transforms = the block */
+static int tx_px(const Av1oFrame *f, int plane, int pass, int r, int c) {
+  const int code = plane == 0 ? f->m_txsize[r * f->mi_stride + c] : f->m_bsize[r * f->mi_stride + c];
+  return 1 << (pass == 0 ? dim_wl(code) : dim_hl(code));
+}
 
 static void filter_edge_sample(uint16_t *px, int step /* distance between p/q samples */, int filter_size, int plane, int lvl, int sharp, int bd) {
   /* px points at q0; p_i = px[-(i+1)*step], q_i = px[i*step] */
@@ -70,9 +74,9 @@ static int edge_fsz(const Av1oFrame *f, int plane, int pass, int r, int c) {
   if (x >= f->w || y >= f->h) return 0;
   if (pass == 0 && c == 0) return 0;
   if (pass == 1 && r == 0) return 0;
-  const int cur = imin(64, tx_px(f, plane, r, c));
+  const int cur = imin(64, tx_px(f, plane, pass, r, c));
   if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;   /* tx (== block) edge? origins are aligned to their size */
-  const int prev = pass == 0 ? imin(64, tx_px(f, plane, r, c - 1)) : imin(64, tx_px(f, plane, r - 1, c));
+  const int prev = pass == 0 ? imin(64, tx_px(f, plane, pass, r, c - 1)) : imin(64, tx_px(f, plane, pass, r - 1, c));
   const int base = imin(cur, prev);
   return plane == 0 ? imin(16, base) : imin(8, base);
 }

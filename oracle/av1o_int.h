@@ -11,6 +11,20 @@
 #define AV1O_TX_DEPTH_MAX 2
 #endif
 
+/* Rectangular partitions (PARTITION_HORZ / PARTITION_VERT) of 8x8 nodes: rav1e tries them up to its
+ * non_square_partition_max_threshold (8x8 from speed 2 on) [UPSTREAM-RECALL].  0 = squares only (what the HIP path implements). */
+#ifndef AV1O_RECT_PART
+#define AV1O_RECT_PART 0
+#endif
+/* Block-size and transform-size codes: 0..4 = the squares 4 << code; 5 = 4 wide x 8 tall, 6 = 8 wide x 4 tall (same numbering for both). */
+enum { BS_4X8 = 5, BS_8X4 = 6, TX_4X8 = 5, TX_8X4 = 6 };
+static inline int dim_wl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 2 : 3); }     /* log2 of the width in samples */
+static inline int dim_hl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 3 : 2); }     /* log2 of the height */
+static inline int dim_is_rect(int code) { return code > 4; }
+static inline int dim_min_l(int code) { const int a = dim_wl(code), b = dim_hl(code); return a < b ? a : b; }
+static inline int dim_max_l(int code) { const int a = dim_wl(code), b = dim_hl(code); return a > b ? a : b; }
+static inline int dim_code(int wl, int hl) { return wl == hl ? wl - 2 : (wl == 2 && hl == 3 ? 5 : 6); }
+
 #define MI 4
 #define SB 64
 #define SB_MI 16
@@ -108,6 +122,7 @@ uint32_t av1o_psy_boost_q14(uint32_t svar, uint32_t dvar);
 uint32_t av1o_cell_var(int64_t sum, int64_t sum2, int w, int bd);
 void av1o_activity(Av1oFrame *f);
 int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n);
+int64_t av1o_psy_dist_luma_wh(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int bw, int bh);
 uint32_t av1o_act_mean(const Av1oFrame *f, int x, int y, int w, int h);
 
 /* prediction (spec 7.11.2) */
@@ -116,6 +131,10 @@ void av1o_predict_intra(const Av1oFrame *f, const TileB *t, int plane, int x, in
                         int have_left, int have_above, int have_above_rt, int have_below_lft,
                         int mode, int angle_delta, int filter_type, uint16_t *dst, int dst_stride);
 void av1o_predict_cfl(const Av1oFrame *f, int plane, int x, int y, int log2w, int alpha, uint16_t *dst, int dst_stride);
+void av1o_predict_intra_wh(const Av1oFrame *f, const TileB *t, int plane, int x, int y, int log2w, int log2h,
+                           int have_left, int have_above, int have_above_rt, int have_below_lft,
+                           int mode, int angle_delta, int filter_type, uint16_t *dst, int dst_stride);
+void av1o_predict_cfl_wh(const Av1oFrame *f, int plane, int x, int y, int log2w, int log2h, int alpha, uint16_t *dst, int dst_stride);
 
 /* transforms + quant (spec 7.13.3 inverse; forward = encoder side) */
 void av1o_fwd_txfm2d(const int16_t *resid, int rstride, int32_t *coef, int txs, int txtype, int bd);

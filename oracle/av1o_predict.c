@@ -78,8 +78,16 @@ static void edge_upsample_do(uint16_t *buf, int num_px, int bd) {               
 void av1o_predict_intra(const Av1oFrame *f, const TileB *t, int plane, int x, int y, int log2w,
                         int have_left, int have_above, int have_above_rt, int have_below_lft,
                         int mode, int angle_delta, int filter_type, uint16_t *dst, int ds) {
+  av1o_predict_intra_wh(f, t, plane, x, y, log2w, log2w, have_left, have_above, have_above_rt, have_below_lft, mode, angle_delta, filter_type, dst, ds);
+}
+/* w x h block (a transform block of the block being predicted): the above-right run is as long as the block is WIDE and the
+ * below-left run as long as it is HIGH (libaom / dav1d edge preparation: n_topright_px <= txw, n_bottomleft_px <= txh), the rest
+ * of the w + h samples an angle may reach repeats the last one. */
+void av1o_predict_intra_wh(const Av1oFrame *f, const TileB *t, int plane, int x, int y, int log2w, int log2h,
+                           int have_left, int have_above, int have_above_rt, int have_below_lft,
+                           int mode, int angle_delta, int filter_type, uint16_t *dst, int ds) {
   (void)t;
-  const int w = 1 << log2w, h = w, bd = f->bd;
+  const int w = 1 << log2w, h = 1 << log2h, bd = f->bd;
   const int max_x = f->mi_cols * MI - 1, max_y = f->mi_rows * MI - 1;
   const uint16_t *rec = f->rec[plane]; const int rs = f->stride;
   uint16_t above_buf[16 + 2 * 64 + 64 + 16], left_buf[16 + 2 * 64 + 64 + 16];
@@ -112,19 +120,19 @@ void av1o_predict_intra(const Av1oFrame *f, const TileB *t, int plane, int x, in
     }
   } else if (mode == DC_PRED) {
     int v;
-    if (have_left && have_above) { int s = 0; for (int k = 0; k < w; k++) s += above[k] + left[k]; v = (s + ((w + h) >> 1)) / (w + h); }
-    else if (have_left) { int s = 0; for (int k = 0; k < h; k++) s += left[k]; v = (s + (h >> 1)) >> log2w; }
+    if (have_left && have_above) { int s = 0; for (int k = 0; k < w; k++) s += above[k]; for (int k = 0; k < h; k++) s += left[k]; v = (s + ((w + h) >> 1)) / (w + h); }
+    else if (have_left) { int s = 0; for (int k = 0; k < h; k++) s += left[k]; v = (s + (h >> 1)) >> log2h; }
     else if (have_above) { int s = 0; for (int k = 0; k < w; k++) s += above[k]; v = (s + (w >> 1)) >> log2w; }
     else v = 1 << (bd - 1);
     for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) dst[i * ds + j] = (uint16_t)v;
   } else if (mode == SMOOTH_PRED) {
-    const uint8_t *sw = sm_weights(log2w);
+    const uint8_t *sw = sm_weights(log2w), *sh = sm_weights(log2h);
     for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) {
-      int p = sw[i] * above[j] + (256 - sw[i]) * left[h - 1] + sw[j] * left[i] + (256 - sw[j]) * above[w - 1];
+      int p = sh[i] * above[j] + (256 - sh[i]) * left[h - 1] + sw[j] * left[i] + (256 - sw[j]) * above[w - 1];
       dst[i * ds + j] = (uint16_t)round2(p, 9);
     }
   } else if (mode == SMOOTH_V_PRED) {
-    const uint8_t *sw = sm_weights(log2w);
+    const uint8_t *sw = sm_weights(log2h);
     for (int i = 0; i < h; i++) for (int j = 0; j < w; j++)
       dst[i * ds + j] = (uint16_t)round2(sw[i] * above[j] + (256 - sw[i]) * left[h - 1], 8);
   } else if (mode == SMOOTH_H_PRED) {
@@ -194,12 +202,15 @@ void av1o_predict_intra(const Av1oFrame *f, const TileB *t, int plane, int x, in
 
 /* 7.11.5 chroma-from-luma for 4:4:4: dst holds the DC prediction on entry. */
 void av1o_predict_cfl(const Av1oFrame *f, int plane, int x, int y, int log2w, int alpha, uint16_t *dst, int ds) {
+  av1o_predict_cfl_wh(f, plane, x, y, log2w, log2w, alpha, dst, ds);
+}
+void av1o_predict_cfl_wh(const Av1oFrame *f, int plane, int x, int y, int log2w, int log2h, int alpha, uint16_t *dst, int ds) {
   (void)plane;
-  const int w = 1 << log2w, h = w, mx = (1 << f->bd) - 1;
+  const int w = 1 << log2w, h = 1 << log2h, mx = (1 << f->bd) - 1;
   const uint16_t *luma = f->rec[0]; const int rs = f->stride;
   int sum = 0;
   for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) sum += luma[(y + i) * rs + x + j] << 3;
-  int avg = round2(sum, 2 * log2w);
+  int avg = round2(sum, log2w + log2h);
   for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) {
     int l = (luma[(y + i) * rs + x + j] << 3) - avg;
     int v = alpha * l;

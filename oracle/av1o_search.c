@@ -58,17 +58,18 @@ static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save)
   }
 }
 static void set_decoded(Av1oFrame *f, int r, int c, int bs, int v) {
-  const int n4 = 1 << bs;
-  for (int i = 0; i < n4; i++) memset(f->m_decoded + (r + i) * f->mi_stride + c, v, (size_t)n4);
+  const int w4 = 1 << (dim_wl(bs) - 2), h4 = 1 << (dim_hl(bs) - 2);
+  for (int i = 0; i < h4; i++) memset(f->m_decoded + (r + i) * f->mi_stride + c, v, (size_t)w4);
 }
-static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) {
-  for (int i = 0; i < n4; i++) memset(m + (r + i) * ms + c, v, (size_t)n4);
+static void fill_map2(uint8_t *m, int ms, int r, int c, int w4, int h4, int v) {
+  for (int i = 0; i < h4; i++) memset(m + (r + i) * ms + c, v, (size_t)w4);
 }
+static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) { fill_map2(m, ms, r, c, n4, n4, v); }
 
 /* 4x4 Hadamard SATD summed over the block (rav1e get_satd uses 8x8 for larger blocks) */
-static int64_t satd_block(const uint16_t *src, int ss, const uint16_t *pred, int ps, int n) {
+static int64_t satd_block_wh(const uint16_t *src, int ss, const uint16_t *pred, int ps, int w, int h) {
   int64_t total = 0;
-  for (int by = 0; by < n; by += 4) for (int bx = 0; bx < n; bx += 4) {
+  for (int by = 0; by < h; by += 4) for (int bx = 0; bx < w; bx += 4) {
     int d[16], t[16];
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) d[i * 4 + j] = (int)src[(by + i) * ss + bx + j] - (int)pred[(by + i) * ps + bx + j];
     for (int i = 0; i < 4; i++) {
@@ -84,59 +85,61 @@ static int64_t satd_block(const uint16_t *src, int ss, const uint16_t *pred, int
   }
   return total;
 }
-static int64_t sse_block(const uint16_t *a, int as, const uint16_t *b, int bs_, int n) {
+static int64_t satd_block(const uint16_t *src, int ss, const uint16_t *pred, int ps, int n) { return satd_block_wh(src, ss, pred, ps, n, n); }
+static int64_t sse_block_wh(const uint16_t *a, int as, const uint16_t *b, int bs_, int w, int h) {
   int64_t s = 0;
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { int d = (int)a[i * as + j] - (int)b[i * bs_ + j]; s += (int64_t)d * d; }
+  for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) { int d = (int)a[i * as + j] - (int)b[i * bs_ + j]; s += (int64_t)d * d; }
   return s;
 }
+static int64_t sse_block(const uint16_t *a, int as, const uint16_t *b, int bs_, int n) { return sse_block_wh(a, as, b, bs_, n, n); }
 
 /* One transform block: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J. */
 typedef struct { int eob, cul, dcc; int64_t sse; uint32_t rate; } TxRes;
 static int64_t eval_tx(Search *s, int plane, int r, int c, int txs, int bs /* block size (all-zero context) */, const uint16_t *pred /* n x n, stride n */, int txtype,
                        int tx_off, int tx_sym, int tx_ns, uint16_t *rec_out /* n x n */, int32_t *qc_out, TxRes *tr) {
   Av1oFrame *f = s->f;
-  const int n = 4 << txs, cs = imin(n, 32), x = c * 4, y = r * 4;
+  const int n = 1 << dim_wl(txs), nh = 1 << dim_hl(txs), cs = imin(n, 32), x = c * 4, y = r * 4;      /* pred / rec_out: nh rows of n samples */
   static int16_t resid[64 * 64]; static int32_t coef[32 * 32], dq[32 * 32];
   const uint16_t *src = f->src[plane] + y * f->stride + x;
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
+  for (int i = 0; i < nh; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
   av1o_fwd_txfm2d(resid, n, coef, txs, txtype, f->bd);
   int eob = av1o_quantize(coef, qc_out, txs, txtype, f->dc_q[plane], f->ac_q[plane]);
   int sctx, dctx;
   av1o_txb_ctx(f, &s->t, plane, r, c, txs, bs, &sctx, &dctx);
   tr->rate = av1o_coef_rate_full(f, qc_out, eob, plane, txs, txtype, sctx, dctx, tx_off, tx_sym, tx_ns, &tr->cul, &tr->dcc);
-  memcpy(rec_out, pred, sizeof(uint16_t) * (size_t)(n * n));
+  memcpy(rec_out, pred, sizeof(uint16_t) * (size_t)(n * nh));
   if (eob > 0) {
     av1o_dequantize(qc_out, dq, txs, f->dc_q[plane], f->ac_q[plane], f->bd, eob, txtype);
     av1o_inv_txfm2d_add(dq, rec_out, n, txs, txtype, f->bd);
   }
   tr->eob = eob;
   /* distortion: luma = psychovisual cdef-dist per 8x8 cell x activity; chroma = SSE x the block's mean activity */
-  if (plane == 0) tr->sse = av1o_psy_dist_luma(f, rec_out, n, x, y, n);
-  else tr->sse = (sse_block(src, f->stride, rec_out, n, n) * av1o_act_mean(f, x, y, n, n) + 8192) >> 14;
+  if (plane == 0) tr->sse = av1o_psy_dist_luma_wh(f, rec_out, n, x, y, n, nh);
+  else tr->sse = (sse_block_wh(src, f->stride, rec_out, n, n, nh) * av1o_act_mean(f, x, y, n, nh) + 8192) >> 14;
   (void)cs;
   return ((tr->sse * s->wq[plane]) >> 5) + (((int64_t)tr->rate * f->rdmult[0] + 256) >> 9);
 }
 
 static void commit_plane(Av1oFrame *f, int plane, int r, int c, int bs, const uint16_t *rec, const int32_t *qc, const TxRes *tr) {
-  const int n = 4 << bs, cs = imin(n, 32), n4 = 1 << bs;
-  for (int i = 0; i < n; i++) memcpy(f->rec[plane] + (r * 4 + i) * f->stride + c * 4, rec + i * n, 2 * (size_t)n);
-  for (int i = 0; i < cs; i++) memcpy(f->coef[plane] + (r * 4 + i) * f->stride + c * 4, qc + i * cs, 4 * (size_t)cs);
-  fill_map(f->m_lvl[plane], f->mi_stride, r, c, n4, tr->cul);
-  fill_map(f->m_dc[plane], f->mi_stride, r, c, n4, tr->dcc);
+  const int n = 1 << dim_wl(bs), nh = 1 << dim_hl(bs), cs = imin(n, 32), ch = imin(nh, 32);
+  for (int i = 0; i < nh; i++) memcpy(f->rec[plane] + (r * 4 + i) * f->stride + c * 4, rec + i * n, 2 * (size_t)n);
+  for (int i = 0; i < ch; i++) memcpy(f->coef[plane] + (r * 4 + i) * f->stride + c * 4, qc + i * cs, 4 * (size_t)cs);
+  fill_map2(f->m_lvl[plane], f->mi_stride, r, c, n >> 2, nh >> 2, tr->cul);
+  fill_map2(f->m_dc[plane], f->mi_stride, r, c, n >> 2, nh >> 2, tr->dcc);
   f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)tr->eob;
 }
 
 /* rdo_cfl_alpha: per plane, the alpha (|a| in 1..16, sign) minimising prediction SSE; 0 = CFL_SIGN_ZERO */
 static int cfl_best_alpha(Search *s, int plane, int r, int c, int bs, const uint16_t *dc_pred) {
-  Av1oFrame *f = s->f; const int n = 4 << bs;
+  Av1oFrame *f = s->f; const int n = 1 << dim_wl(bs), nh = 1 << dim_hl(bs);
   static uint16_t tmp[64 * 64];
   const uint16_t *src = f->src[plane] + r * 4 * f->stride + c * 4;
-  int best = 0; int64_t best_sse = sse_block(src, f->stride, dc_pred, n, n);
+  int best = 0; int64_t best_sse = sse_block_wh(src, f->stride, dc_pred, n, n, nh);
   for (int mag = 1; mag <= 16; mag++) for (int sg = 0; sg < 2; sg++) {
     int alpha = sg ? -mag : mag;
-    memcpy(tmp, dc_pred, 2 * (size_t)(n * n));
-    av1o_predict_cfl(f, plane, c * 4, r * 4, 2 + bs, alpha, tmp, n);
-    int64_t e = sse_block(src, f->stride, tmp, n, n);
+    memcpy(tmp, dc_pred, 2 * (size_t)(n * nh));
+    av1o_predict_cfl_wh(f, plane, c * 4, r * 4, dim_wl(bs), dim_hl(bs), alpha, tmp, n);
+    int64_t e = sse_block_wh(src, f->stride, tmp, n, n, nh);
     if (e < best_sse) { best_sse = e; best = alpha; }
   }
   return best;
@@ -145,11 +148,13 @@ static int cfl_best_alpha(Search *s, int plane, int r, int c, int bs, const uint
 /* Full decision for one block; writes maps/recon/coefs for the area and returns its RD cost. */
 static int64_t try_block(Search *s, int r, int c, int bs) {
   Av1oFrame *f = s->f; const TileB *t = &s->t;
-  const int n = 4 << bs, n4 = 1 << bs, ms = f->mi_stride, mi = r * ms + c, log2w = 2 + bs, txs = bs;
+  /* bs: a square (BS_4 .. BS_64) or BS_4X8 / BS_8X4 (av1o_int.h); n = width = pitch of the block-sized scratch arrays */
+  const int wl = dim_wl(bs), hl = dim_hl(bs), n = 1 << wl, bh = 1 << hl, w4 = n >> 2, h4 = bh >> 2, big = dim_min_l(bs) >= 3;
+  const int ms = f->mi_stride, mi = r * ms + c, txs = bs;
   const int x = c * 4, y = r * 4;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int have_ar = availU && (c + n4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + n4];
-  const int have_bl = availL && (r + n4 < t->mi_row_end) && f->m_decoded[(r + n4) * ms + c - 1];
+  const int have_ar = availU && (c + w4 < t->mi_col_end) && f->m_decoded[(r - 1) * ms + c + w4];
+  const int have_bl = availL && (r + h4 < t->mi_row_end) && f->m_decoded[(r + h4) * ms + c - 1];
   const int amode = availU ? f->m_ymode[mi - ms] : DC_PRED, lmode = availL ? f->m_ymode[mi - 1] : DC_PRED;
   const uint32_t *ycost = f->cost + CDF_KF_Y + (intra_mode_ctx[amode] * 5 + intra_mode_ctx[lmode]) * CDF_KF_Y_STRIDE;
   #define IS_SMOOTH(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
@@ -162,8 +167,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   /* ---- luma: SATD pre-filter over the 13 modes ---- */
   int64_t satd[13]; int order[13];
   for (int m = 0; m < 13; m++) {
-    av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, 0, ftype_y, pred, n);
-    satd[m] = satd_block(src, f->stride, pred, n, n);
+    av1o_predict_intra_wh(f, t, 0, x, y, wl, hl, availL, availU, have_ar, have_bl, m, 0, ftype_y, pred, n);
+    satd[m] = satd_block_wh(src, f->stride, pred, n, n, bh);
     order[m] = m;
   }
   for (int i = 1; i < 13; i++) { int v = order[i], j = i; while (j > 0 && satd[order[j - 1]] > satd[v]) { order[j] = order[j - 1]; j--; } order[j] = v; }
@@ -175,18 +180,18 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     const int m = order[ci];
     int delta = 0;
     const int directional = m >= V_PRED && m <= D67_PRED;
-    if (directional && bs >= BS_8 && f->cfg.fine_directional) {
+    if (directional && big && f->cfg.fine_directional) {
       int64_t bsd = satd[m];
       static const int dl[6] = { -1, 1, -2, 2, -3, 3 };
       for (int k = 0; k < 6; k++) {
-        av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, dl[k], ftype_y, pred, n);
-        int64_t sd = satd_block(src, f->stride, pred, n, n);
+        av1o_predict_intra_wh(f, t, 0, x, y, wl, hl, availL, availU, have_ar, have_bl, m, dl[k], ftype_y, pred, n);
+        int64_t sd = satd_block_wh(src, f->stride, pred, n, n, bh);
         if (sd < bsd) { bsd = sd; delta = dl[k]; }
       }
     }
-    av1o_predict_intra(f, t, 0, x, y, log2w, availL, availU, have_ar, have_bl, m, delta, ftype_y, pred, n);
+    av1o_predict_intra_wh(f, t, 0, x, y, wl, hl, availL, availU, have_ar, have_bl, m, delta, ftype_y, pred, n);
     uint32_t mode_rate = ycost[m];
-    if (directional && bs >= BS_8) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+    if (directional && big) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
     const int tx_off = av1o_intra_tx_cdf(f, txs, m, &tx_ns, &tx_set);
     const int ntx = (f->cfg.rdo_tx && tx_off >= 0) ? tx_ns : 1;
     for (int ti = 0; ti < ntx; ti++) {
@@ -199,7 +204,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
       if (j < best_j) {
         best_mode_j = ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
         best_j = j; best_mode = m; best_delta = delta; best_tx = txtype; best_tr = tr;
-        memcpy(rec_best[0], rec_tmp, 2 * (size_t)(n * n)); memcpy(qc_best[0], qc_tmp, 4 * (size_t)imin(n * n, 1024));
+        memcpy(rec_best[0], rec_tmp, 2 * (size_t)(n * bh)); memcpy(qc_best[0], qc_tmp, 4 * (size_t)imin(n * bh, 1024));
       }
     }
   }
@@ -209,29 +214,32 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
    * type.  A depth is abandoned as soon as its running cost reaches the best so far; the frame buffers always hold the trial in
    * progress, the best split so far waits in a snapshot of the block's area. */
   int txs_final = bs, any_coef = best_tr.eob > 0;
-  if (f->tx_mode_select && bs > BS_4) {
-    const int maxw = 4 << bs;
-    const int actx = availU && (4 << f->m_txsize[mi - ms]) >= maxw, lctx = availL && (4 << f->m_txsize[mi - 1]) >= maxw;
-    const uint32_t *dcost = f->cost + CDF_TX_SIZE + ((bs - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
+  if (f->tx_mode_select && bs != BS_4) {
+    /* tx_depth context: the above neighbour's transform WIDTH against this block's largest transform width, the left one's HEIGHT
+     * against its height (spec get_tx_size_context); category by Max_Tx_Depth: 8x8 and the 2:1 blocks of it share the first */
+    const int actx = availU && dim_wl(f->m_txsize[mi - ms]) >= wl, lctx = availL && dim_hl(f->m_txsize[mi - 1]) >= hl;
+    const int cat = dim_is_rect(bs) ? 0 : bs - 1;
+    const uint32_t *dcost = f->cost + CDF_TX_SIZE + (cat * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     best_j += ((int64_t)dcost[0] * f->rdmult[0] + 256) >> 9;
     if (f->cfg.rdo_tx) {
       static AreaSnap split_snap;
-      const int max_depth = bs >= BS_16 ? AV1O_TX_DEPTH_MAX : 1;
+      const int max_depth = (!dim_is_rect(bs) && bs >= BS_16) ? AV1O_TX_DEPTH_MAX : 1;
       for (int d = 1; d <= max_depth; d++) {
-        const int G = 1 << d, half = n4 >> d, hn = n >> d, stx = bs - d;
+        /* sub-transforms: a square splits into 2^d x 2^d squares, a 2:1 block into its two squares (Split_Tx_Size) */
+        const int stx = dim_is_rect(bs) ? dim_min_l(bs) - 2 : bs - d, hn = 4 << stx, half = 1 << stx, G = n / hn, GH = bh / hn;
         int64_t j_split = best_mode_j + (((int64_t)dcost[d] * f->rdmult[0] + 256) >> 9);
         int sub_any = 0;
         static uint16_t spred[32 * 32], srec[2][32 * 32]; static int32_t sqc[2][32 * 32];
         int stx_ns, stx_set;
         const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
-        for (int k = 0; k < G * G && j_split < best_j; k++) {
+        for (int k = 0; k < G * GH && j_split < best_j; k++) {
           const int bi = k / G, bj_ = k % G;
           const int rr = r + bi * half, cc = c + bj_ * half;
           const int sU = availU || bi, sL = availL || bj_;
           const int s_ar = sU && (cc + half < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + half];
           const int s_bl = sL && (rr + half < t->mi_row_end) && f->m_decoded[(rr + half) * ms + cc - 1];
-          av1o_predict_intra(f, t, 0, cc * 4, rr * 4, log2w - d, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
+          av1o_predict_intra(f, t, 0, cc * 4, rr * 4, 2 + stx, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
           int64_t bj = INT64_MAX; int btx = DCT_DCT, cur = 0; TxRes btr = { 0, 0, 0, 0, 0 };
           for (int ti = 0; ti < sntx; ti++) {
             int txtype;
@@ -257,17 +265,17 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   }
   if (txs_final == bs) {
     commit_plane(f, 0, r, c, bs, rec_best[0], qc_best[0], &best_tr);
-    fill_map(f->m_txtype, ms, r, c, n4, best_tr.eob ? best_tx : DCT_DCT);
+    fill_map2(f->m_txtype, ms, r, c, w4, h4, best_tr.eob ? best_tx : DCT_DCT);
   }
-  fill_map(f->m_txsize, ms, r, c, n4, txs_final);
-  fill_map(f->m_ymode, ms, r, c, n4, best_mode);
-  fill_map((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)best_delta);
-  fill_map(f->m_bsize, ms, r, c, n4, bs);
+  fill_map2(f->m_txsize, ms, r, c, w4, h4, txs_final);
+  fill_map2(f->m_ymode, ms, r, c, w4, h4, best_mode);
+  fill_map2((uint8_t *)f->m_angle_y, ms, r, c, w4, h4, (uint8_t)(int8_t)best_delta);
+  fill_map2(f->m_bsize, ms, r, c, w4, h4, bs);
   int64_t total_j = best_j;
 
   /* ---- chroma ---- */
   if (f->np > 1) {
-    const int cfl_allowed = bs <= BS_32;
+    const int cfl_allowed = dim_max_l(bs) <= 5;
     const uint32_t *uvcost = cfl_allowed ? f->cost + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : f->cost + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     int cands[16], nc = 0;
     cands[nc++] = DC_PRED;
@@ -278,16 +286,16 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     static uint16_t rec_c[3][64 * 64]; static int32_t qc_c[3][32 * 32];
     for (int ci = 0; ci < nc; ci++) {
       const int um = cands[ci];
-      int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && bs >= BS_8) ? best_delta : 0;
+      int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && big) ? best_delta : 0;
       int alpha[3] = { 0, 0, 0 }, jsign = 0;
       uint32_t mode_rate = uvcost[um];
-      if (um >= V_PRED && um <= D67_PRED && bs >= BS_8) mode_rate += f->cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
+      if (um >= V_PRED && um <= D67_PRED && big) mode_rate += f->cost[CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
       int txtype = av1o_mode_to_txtype(um);
       if (!av1o_tx_type_in_set(av1o_tx_set(txs, f->cfg.reduced_tx_set), txtype)) txtype = DCT_DCT;
       int64_t j = 0; TxRes trs[3]; int ok = 1;
       for (int p = 1; p < 3 && ok; p++) {
         if (um == UV_CFL_PRED) {
-          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
+          av1o_predict_intra_wh(f, t, p, x, y, wl, hl, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
           alpha[p] = cfl_best_alpha(s, p, r, c, bs, pred);
           if (p == 2) {
             if (alpha[1] == 0 && alpha[2] == 0) { ok = 0; break; }
@@ -302,31 +310,31 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
       if (!ok) continue;
       for (int p = 1; p < 3; p++) {
         if (um == UV_CFL_PRED) {
-          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
-          if (alpha[p]) av1o_predict_cfl(f, p, x, y, log2w, alpha[p], pred, n);
+          av1o_predict_intra_wh(f, t, p, x, y, wl, hl, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
+          if (alpha[p]) av1o_predict_cfl_wh(f, p, x, y, wl, hl, alpha[p], pred, n);
         } else {
-          av1o_predict_intra(f, t, p, x, y, log2w, availL, availU, have_ar, have_bl, um, delta, ftype_uv, pred, n);
+          av1o_predict_intra_wh(f, t, p, x, y, wl, hl, availL, availU, have_ar, have_bl, um, delta, ftype_uv, pred, n);
         }
         j += eval_tx(s, p, r, c, bs, bs, pred, txtype, -1, 0, 0, rec_best[p], qc_best[p], &trs[p]);
       }
       j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
       if (j < best_uv) {
         best_uv = j; buv = um; bdelta = delta; bsign = jsign; bau = alpha[1]; bav = alpha[2]; btr[1] = trs[1]; btr[2] = trs[2];
-        for (int p = 1; p < 3; p++) { memcpy(rec_c[p], rec_best[p], 2 * (size_t)(n * n)); memcpy(qc_c[p], qc_best[p], 4 * (size_t)imin(n * n, 1024)); }
+        for (int p = 1; p < 3; p++) { memcpy(rec_c[p], rec_best[p], 2 * (size_t)(n * bh)); memcpy(qc_c[p], qc_best[p], 4 * (size_t)imin(n * bh, 1024)); }
       }
     }
     for (int p = 1; p < 3; p++) { commit_plane(f, p, r, c, bs, rec_c[p], qc_c[p], &btr[p]); any_coef |= btr[p].eob > 0; }
-    fill_map(f->m_uvmode, ms, r, c, n4, buv);
-    fill_map((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)bdelta);
-    fill_map(f->m_cfl_sign, ms, r, c, n4, bsign);
-    fill_map(f->m_cfl_au, ms, r, c, n4, bau ? iabs(bau) - 1 : 0);
-    fill_map(f->m_cfl_av, ms, r, c, n4, bav ? iabs(bav) - 1 : 0);
+    fill_map2(f->m_uvmode, ms, r, c, w4, h4, buv);
+    fill_map2((uint8_t *)f->m_angle_uv, ms, r, c, w4, h4, (uint8_t)(int8_t)bdelta);
+    fill_map2(f->m_cfl_sign, ms, r, c, w4, h4, bsign);
+    fill_map2(f->m_cfl_au, ms, r, c, w4, h4, bau ? iabs(bau) - 1 : 0);
+    fill_map2(f->m_cfl_av, ms, r, c, w4, h4, bav ? iabs(bav) - 1 : 0);
     total_j += best_uv;
   }
   /* ---- skip flag ---- */
   const int skip = !any_coef;
-  fill_map(f->m_skip, ms, r, c, n4, skip);
-  if (skip) for (int p = 0; p < f->np; p++) { fill_map(f->m_lvl[p], ms, r, c, n4, 0); fill_map(f->m_dc[p], ms, r, c, n4, 0); }
+  fill_map2(f->m_skip, ms, r, c, w4, h4, skip);
+  if (skip) for (int p = 0; p < f->np; p++) { fill_map2(f->m_lvl[p], ms, r, c, w4, h4, 0); fill_map2(f->m_dc[p], ms, r, c, w4, h4, 0); }
   const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
   total_j += ((int64_t)f->cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult[0] + 256) >> 9;
   set_decoded(f, r, c, bs, 1);
@@ -336,7 +344,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
 static uint32_t partition_rate(Search *s, int r, int c, int bs, int part) {
   Av1oFrame *f = s->f; const TileB *t = &s->t; const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+  /* partition context: is the above block narrower / the left block lower than this node (spec 8.3.2, AboveSegPredContext-style maps) */
+  const int above = availU && dim_wl(f->m_bsize[(r - 1) * ms + c]) < 2 + bs, left = availL && dim_hl(f->m_bsize[r * ms + c - 1]) < 2 + bs;
   return f->cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
@@ -372,6 +381,22 @@ static int rd_partition(Search *s, int r, int c, int bs, int64_t known_j) {
       sub_j[k] = try_block(s, rr, cc, bs - 1);
       j_split += sub_j[k];
       if (bs - 1 >= BS_8) j_split += ((int64_t)partition_rate(s, rr, cc, bs - 1, PARTITION_NONE) * f->rdmult[0] + 256) >> 9;
+    }
+    /* PARTITION_HORZ / PARTITION_VERT of an 8x8 node (two 8x4 / 4x8 blocks), tried against the best of NONE / SPLIT so far */
+    int rect_won = 0;
+    if (AV1O_RECT_PART && bs == BS_8) {
+      static AreaSnap best_snap, split_snap;
+      int64_t j_best = j_none; int have_split = 0;
+      if (j_split < j_none) { j_best = j_split; area_copy(f, &split_snap, r, c, bs, 1); have_split = 1; }
+      for (int part = PARTITION_HORZ; part <= PARTITION_VERT; part++) {
+        const int rb = part == PARTITION_HORZ ? BS_8X4 : BS_4X8;
+        set_decoded(f, r, c, bs, 0);
+        int64_t j = ((int64_t)partition_rate(s, r, c, bs, part) * f->rdmult[0] + 256) >> 9;
+        for (int k = 0; k < 2 && j < j_best; k++) j += try_block(s, r + (part == PARTITION_HORZ ? k : 0), c + (part == PARTITION_VERT ? k : 0), rb);
+        if (j < j_best) { j_best = j; rect_won = part; area_copy(f, &best_snap, r, c, bs, 1); }
+      }
+      if (rect_won) { area_copy(f, &best_snap, r, c, bs, 0); set_decoded(f, r, c, bs, 1); return 1; }   /* 1: the later siblings' trial results are stale */
+      if (have_split) area_copy(f, &split_snap, r, c, bs, 0);      /* the 4x4 trial results are back in place for the chain below */
     }
     if (j_split < j_none) do_split = 1;
     else { area_copy(f, &snap[bs], r, c, bs, 0); set_decoded(f, r, c, bs, 1); }
@@ -412,6 +437,20 @@ static int64_t rd_partition_bottomup(Search *s, int r, int c, int bs) {
   for (int k = 0; k < 4; k++) {
     if (!must_split && j_split >= j_none) break;               /* costs only grow */
     j_split += rd_partition_bottomup(s, r + (k >> 1) * half, c + (k & 1) * half, bs - 1);
+  }
+  if (AV1O_RECT_PART && bs == BS_8 && !must_split) {
+    static AreaSnap best_snap, split_snap;
+    int64_t j_best = j_none; int rect_won = 0, have_split = 0;
+    if (j_split < j_none) { j_best = j_split; area_copy(f, &split_snap, r, c, bs, 1); have_split = 1; }
+    for (int part = PARTITION_HORZ; part <= PARTITION_VERT; part++) {
+      const int rb = part == PARTITION_HORZ ? BS_8X4 : BS_4X8;
+      set_decoded(f, r, c, bs, 0);
+      int64_t j = ((int64_t)partition_rate(s, r, c, bs, part) * f->rdmult[0] + 256) >> 9;
+      for (int k = 0; k < 2 && j < j_best; k++) j += try_block(s, r + (part == PARTITION_HORZ ? k : 0), c + (part == PARTITION_VERT ? k : 0), rb);
+      if (j < j_best) { j_best = j; rect_won = part; area_copy(f, &best_snap, r, c, bs, 1); }
+    }
+    if (rect_won) { area_copy(f, &best_snap, r, c, bs, 0); set_decoded(f, r, c, bs, 1); return j_best; }
+    if (have_split) { area_copy(f, &split_snap, r, c, bs, 0); set_decoded(f, r, c, bs, 1); return j_split; }
   }
   if (must_split || j_split < j_none) return j_split;
   area_copy(f, &snap[bs], r, c, bs, 0);

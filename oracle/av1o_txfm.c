@@ -39,49 +39,63 @@ static void tx_kinds(int t, int *col, int *row) {
 }
 static inline int32_t rshift_round(int32_t v, int s) { return s <= 0 ? (int32_t)((uint32_t)v << -s) : (v + (1 << (s - 1))) >> s; }
 
+/* w x h transform (txs code, av1o_int.h dim_wl / dim_hl); coefficients row-major in the coded area cw x ch = min(32, w) x min(32, h).
+ * Rectangular 2:1 sizes (4x8, 8x4): libaom's stage shifts {2, -1, 0} and the sqrt(2) scale after the row pass forward, the spec's
+ * 1/sqrt(2) scale (Round2(x * 2896, 12)) before the row pass and rowShift 0 inverse (7.13.3). */
 void av1o_fwd_txfm2d(const int16_t *resid, int rstride, int32_t *coef, int txs, int txtype, int bd) {
   (void)bd;
-  const int n = 4 << txs, cs = imin(n, 32);
-  static const int8_t sh[5][3] = { { 2, 0, 0 }, { 2, -1, 0 }, { 2, -2, 0 }, { 2, -4, 0 }, { 0, -2, -2 } };
+  const int w = 1 << dim_wl(txs), h = 1 << dim_hl(txs), cw = imin(w, 32), ch = imin(h, 32);
+  static const int8_t sh_sq[5][3] = { { 2, 0, 0 }, { 2, -1, 0 }, { 2, -2, 0 }, { 2, -4, 0 }, { 0, -2, -2 } };
+  static const int8_t sh_rect[3] = { 2, -1, 0 };
+  const int8_t *sh = dim_is_rect(txs) ? sh_rect : sh_sq[txs];
   int ck, rk; tx_kinds(txtype, &ck, &rk);
-  tx1d_fn colf = pick(1, ck, n), rowf = pick(1, rk, n);
+  tx1d_fn colf = pick(1, ck, h), rowf = pick(1, rk, w);
   static int32_t buf[64 * 64];
   int32_t t[64];
-  for (int c = 0; c < n; c++) {
-    for (int r = 0; r < n; r++) t[r] = rshift_round(resid[r * rstride + c], -sh[txs][0]);
+  for (int c = 0; c < w; c++) {
+    for (int r = 0; r < h; r++) t[r] = rshift_round(resid[r * rstride + c], -sh[0]);
     colf(t);
-    for (int r = 0; r < n; r++) buf[r * n + c] = rshift_round(t[r], -sh[txs][1]);
+    for (int r = 0; r < h; r++) buf[r * w + c] = rshift_round(t[r], -sh[1]);
   }
-  for (int r = 0; r < cs; r++) {          /* rows >= 32 of a 64-point block are discarded */
-    for (int c = 0; c < n; c++) t[c] = buf[r * n + c];
+  for (int r = 0; r < ch; r++) {          /* rows >= 32 of a 64-point block are discarded */
+    for (int c = 0; c < w; c++) t[c] = buf[r * w + c];
     rowf(t);
-    for (int c = 0; c < cs; c++) coef[r * cs + c] = rshift_round(t[c], -sh[txs][2]);
+    for (int c = 0; c < cw; c++) {
+      int32_t v = rshift_round(t[c], -sh[2]);
+      if (dim_is_rect(txs)) v = (int32_t)(((int64_t)v * 5793 + 2048) >> 12);
+      coef[r * cw + c] = v;
+    }
   }
 }
 
 void av1o_inv_txfm2d_add(const int32_t *dq, uint16_t *dst, int dstride, int txs, int txtype, int bd) {
-  const int n = 4 << txs, cs = imin(n, 32);
-  static const int8_t row_shift[5] = { 0, 1, 2, 2, 2 };
+  const int w = 1 << dim_wl(txs), h = 1 << dim_hl(txs), cw = imin(w, 32), ch = imin(h, 32);
+  static const int8_t row_shift_sq[5] = { 0, 1, 2, 2, 2 };
+  const int row_shift = dim_is_rect(txs) ? 0 : row_shift_sq[txs];
   int ck, rk; tx_kinds(txtype, &ck, &rk);
-  tx1d_fn colf = pick(0, ck, n), rowf = pick(0, rk, n);
+  tx1d_fn colf = pick(0, ck, h), rowf = pick(0, rk, w);
   static int32_t res[64 * 64];
   int32_t t[64];
   const int rmax = (1 << (bd + 7)) - 1, rmin = -(1 << (bd + 7));
   const int cbits = imax(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
-  for (int i = 0; i < n; i++) {
-    if (i < cs) {
-      for (int j = 0; j < n; j++) t[j] = j < cs ? iclamp(dq[i * cs + j], rmin, rmax) : 0;
+  for (int i = 0; i < h; i++) {
+    if (i < ch) {
+      for (int j = 0; j < w; j++) {
+        int v = j < cw ? iclamp(dq[i * cw + j], rmin, rmax) : 0;
+        if (dim_is_rect(txs)) v = round2(v * 2896, 12);
+        t[j] = v;
+      }
       rowf(t);
-      for (int j = 0; j < n; j++) res[i * n + j] = iclamp(round2(t[j], row_shift[txs]), cmin, cmax);
+      for (int j = 0; j < w; j++) res[i * w + j] = iclamp(round2(t[j], row_shift), cmin, cmax);
     } else {
-      for (int j = 0; j < n; j++) res[i * n + j] = 0;
+      for (int j = 0; j < w; j++) res[i * w + j] = 0;
     }
   }
   const int mx = (1 << bd) - 1;
-  for (int j = 0; j < n; j++) {
-    for (int i = 0; i < n; i++) t[i] = res[i * n + j];
+  for (int j = 0; j < w; j++) {
+    for (int i = 0; i < h; i++) t[i] = res[i * w + j];
     colf(t);
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < h; i++) {
       int v = dst[i * dstride + j] + round2(t[i], 4);
       dst[i * dstride + j] = (uint16_t)iclamp(v, 0, mx);
     }
@@ -91,7 +105,7 @@ void av1o_inv_txfm2d_add(const int32_t *dq, uint16_t *dst, int dstride, int txs,
 /* rav1e QuantizationContext::quantize (recalled): dead-zone offsets 109/256 (DC, AC level>=1), 98/256 (AC level 0),
  * eob threshold (1 - 88/256) q; no trellis. */
 int av1o_quantize(const int32_t *coef, int32_t *qc, int txs, int txtype, int dcq, int acq) {
-  const int n = imin(32, 4 << txs), nc = n * n;
+  const int nc = imin(32, 1 << dim_wl(txs)) * imin(32, 1 << dim_hl(txs));
   const int ls = txs == TX_32X32 ? 1 : (txs == TX_64X64 ? 2 : 0);
   uint16_t tmp[1024];
   const uint16_t *scan = av1o_scan(txs, txtype, tmp);
@@ -120,7 +134,7 @@ int av1o_quantize(const int32_t *coef, int32_t *qc, int txs, int txtype, int dcq
 /* spec 7.12.3 */
 void av1o_dequantize(const int32_t *qc, int32_t *dq, int txs, int dcq, int acq, int bd, int eob, int txtype) {
   (void)eob; (void)txtype;
-  const int n = imin(32, 4 << txs), nc = n * n;
+  const int nc = imin(32, 1 << dim_wl(txs)) * imin(32, 1 << dim_hl(txs));
   const int sh = txs == TX_32X32 ? 1 : (txs == TX_64X64 ? 2 : 0);
   const int mx = (1 << (7 + bd)) - 1, mn = -(1 << (7 + bd));
   for (int i = 0; i < nc; i++) {

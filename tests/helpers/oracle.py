@@ -34,7 +34,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
+        path = os.environ.get('MI_ORACLE_LIB') or os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
