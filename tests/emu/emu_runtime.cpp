@@ -246,7 +246,13 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       const unsigned long long b = next.fetch_add(1);
       if (b >= nblocks) break;
       blockIdx.x = (unsigned)(b % grid.x); blockIdx.y = (unsigned)((b / grid.x) % grid.y); blockIdx.z = (unsigned)(b / ((unsigned long long)grid.x * grid.y));
+      // dynamic LDS: the launch asked for lds_bytes; a canary behind it catches a kernel that writes past its allocation (on the GPU: a fault
+      // or silent corruption of a neighbouring workgroup's LDS)
+      uint8_t *dyn[2] = { smem, k4_smem };
+      if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) memset(dyn[q] + lds_bytes, 0xA5, 256);
       run_block(w, (int)nthreads);
+      if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) for (int i = 0; i < 256; i++) if (dyn[q][lds_bytes + i] != 0xA5) {
+        fprintf(stderr, "emu: block %u wrote past its dynamic LDS allocation of %zu bytes (offset %zu)\n", blockIdx.x, lds_bytes, lds_bytes + (size_t)i); abort(); }
     }
   };
   // workgroups are claimed in block order; a kernel whose workgroups wait for earlier ones (the tile search's row workers, up to 16 per
