@@ -11,6 +11,11 @@
 #ifndef MI_TX_DEPTH_MAX
 #define MI_TX_DEPTH_MAX 2
 #endif
+// PARTITION_HORZ / PARTITION_VERT of 8x8 nodes (8x4 / 4x8 blocks, 2:1 transforms; dev_rect.h) -- the oracle's AV1O_RECT_PART.  0 until the
+// kernels have been checked on the hardware; block / transform size codes 5 (4x8) and 6 (8x4) then appear in m_bsize / m_txsize.
+#ifndef MI_RECT_PART
+#define MI_RECT_PART 0
+#endif
 #define MI_MAX_TILE_COLS 64
 #define MI_MAX_TILE_ROWS 64
 

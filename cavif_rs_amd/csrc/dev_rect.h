@@ -1,0 +1,651 @@
+// dev_rect.h -- rectangular blocks (PARTITION_HORZ / PARTITION_VERT of an 8x8 node: 8x4 and 4x8 blocks with their 2:1 transforms) for the
+// tile search K1.  Compiled only with -DMI_RECT_PART=1 (the oracle's AV1O_RECT_PART); mirrors oracle/av1o_search.c try_block for the
+// codes BS_4X8 = 5 / BS_8X4 = 6 (oracle/av1o_int.h).  One candidate per wavefront, 32 samples on 32 lanes, no grouping: correctness
+// first -- the square paths keep their tuned code.
+#pragma once
+#if MI_RECT_PART
+enum { BS_4X8 = 5, BS_8X4 = 6 };
+__device__ __forceinline__ int dim_wl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 2 : 3); }   // log2 width / height in samples
+__device__ __forceinline__ int dim_hl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 3 : 2); }
+
+// spec Default_Scan_4x8 (tall: each anti-diagonal from its top-right end) / Default_Scan_8x4 (wide: from its bottom-left end)
+static __device__ const uint8_t rect_scan_4x8[32] = { 0, 1, 4, 2, 5, 8, 3, 6, 9, 12, 7, 10, 13, 16, 11, 14, 17, 20, 15, 18, 21, 24, 19, 22, 25, 28, 23, 26, 29, 27, 30, 31 };
+static __device__ const uint8_t rect_scan_8x4[32] = { 0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 25, 18, 11, 4, 26, 19, 12, 5, 27, 20, 13, 6, 28, 21, 14, 7, 29, 22, 15, 30, 23, 31 };
+__device__ __forceinline__ int rect_scan_pos(int wl, int hl, int cls, int i) {
+  const int w = 1 << wl, h = 1 << hl;
+  if (cls == TXC_2D) return hl > wl ? rect_scan_4x8[i] : rect_scan_8x4[i];
+  if (cls == TXC_VERT) return i;                              // mrow
+  const int c = i / h, r = i - c * h; return r * w + c;       // mcol
+}
+
+// raw edges of a w x h block: above[-1 .. w+h-1], left[-1 .. w+h-1] (oracle av1o_predict_intra_wh edge preparation)
+__device__ inline void load_edges_wh(const LDS FrameDev *f, int plane, int x, int y, int w, int h, int have_left, int have_above, int have_ar, int have_bl,
+                                     LDS uint16_t *above, LDS uint16_t *left) {
+  const int bd = f->bd, rs = f->stride, tot = w + h;
+  const uint16_t *rec = f->rec[plane];
+  const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
+  const int lim_a = imin_(max_x, x + (have_ar ? 2 * w : w) - 1), lim_l = imin_(max_y, y + (have_bl ? 2 * h : h) - 1);
+  for (int i = LANE; i <= tot; i += 64) {
+    const bool corner = i == tot;
+    int ia, il;
+    if (have_above) ia = (y - 1) * rs + (corner ? (have_left ? x - 1 : x) : imin_(lim_a, x + i));
+    else ia = y * rs + (have_left ? x - 1 : x);
+    if (have_left) il = imin_(lim_l, y + i) * rs + x - 1;
+    else il = (have_above ? y - 1 : y) * rs + x;
+    uint16_t a = rec[ia], l = rec[il];
+    if (!have_above && !have_left) { a = (uint16_t)(corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1); l = (uint16_t)((1 << (bd - 1)) + 1); }
+    if (corner) { above[-1] = a; left[-1] = a; } else { above[i] = a; left[i] = l; }
+  }
+  WAVE_SYNC();
+}
+
+// w x h prediction (dev_predict.h predict_block with both dimensions)
+__device__ inline void predict_block_wh(const LDS FrameDev *f, int x, int y, int wl, int hl, int have_left, int have_above, int mode, int angle_delta, int ftype,
+                                        const LDS uint16_t *ra, const LDS uint16_t *rl, LDS uint16_t *wa, LDS uint16_t *wl_, LDS uint16_t *tmp, LDS uint16_t *pred) {
+  const int w = 1 << wl, h = 1 << hl, bd = f->bd, nn = w * h;
+  const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
+  if (mode == PAETH_PRED) {
+    const int tl = ra[-1];
+    for (int idx = LANE; idx < nn; idx += 64) {
+      const int i = idx >> wl, j = idx & (w - 1);
+      const int base = ra[j] + rl[i] - tl;
+      const int pl = iabs_(base - rl[i]), pt = iabs_(base - ra[j]), ptl = iabs_(base - tl);
+      pred[idx] = (pl <= pt && pl <= ptl) ? rl[i] : (pt <= ptl ? ra[j] : (uint16_t)tl);
+    }
+  } else if (mode == DC_PRED) {
+    int v;
+    if (have_left || have_above) {
+      int s = 0;
+      for (int k = LANE; k < imax_(w, h); k += 64) s += ((have_above && k < w) ? ra[k] : 0) + ((have_left && k < h) ? rl[k] : 0);
+      s = wave_sum_i32(s);
+      if (have_left && have_above) v = (s + ((w + h) >> 1)) / (w + h);
+      else if (have_left) v = (s + (h >> 1)) >> hl;
+      else v = (s + (w >> 1)) >> wl;
+    } else v = 1 << (bd - 1);
+    for (int idx = LANE; idx < nn; idx += 64) pred[idx] = (uint16_t)v;
+  } else if (mode == SMOOTH_PRED || mode == SMOOTH_V_PRED || mode == SMOOTH_H_PRED) {
+    const uint8_t *sw = sm_weights_dev(wl), *sh = sm_weights_dev(hl);
+    const int bl = rl[h - 1], tr = ra[w - 1];
+    for (int idx = LANE; idx < nn; idx += 64) {
+      const int i = idx >> wl, j = idx & (w - 1);
+      int p;
+      if (mode == SMOOTH_PRED) p = round2_(sh[i] * ra[j] + (256 - sh[i]) * bl + sw[j] * rl[i] + (256 - sw[j]) * tr, 9);
+      else if (mode == SMOOTH_V_PRED) p = round2_(sh[i] * ra[j] + (256 - sh[i]) * bl, 8);
+      else p = round2_(sw[j] * rl[i] + (256 - sw[j]) * tr, 8);
+      pred[idx] = (uint16_t)p;
+    }
+  } else {
+    const int pa = mode_angle_of(mode) + angle_delta * 3;
+    for (int i = LANE; i < w + h + 1; i += 64) { wa[i - 1] = ra[i - 1]; wl_[i - 1] = rl[i - 1]; }
+    WAVE_SYNC();
+    int up_a = 0, up_l = 0;
+    if (pa != 90 && pa != 180) {
+      if (pa > 90 && pa < 180 && w + h >= 24) {
+        if (LANE == 0) { const int v = round2_(wl_[0] * 5 + wa[-1] * 6 + wa[0] * 5, 4); wa[-1] = (uint16_t)v; wl_[-1] = (uint16_t)v; }
+        WAVE_SYNC();
+      }
+      if (have_above) edge_filter_dev(wa, imin_(w, max_x - x + 1) + (pa < 90 ? h : 0) + 1, edge_strength_dev(w, h, ftype, pa - 90), tmp);
+      if (have_left) edge_filter_dev(wl_, imin_(h, max_y - y + 1) + (pa > 180 ? w : 0) + 1, edge_strength_dev(w, h, ftype, pa - 180), tmp);
+    }
+    up_a = edge_upsample_sel_dev(w, h, ftype, pa - 90);
+    if (up_a) edge_upsample_dev(wa, w + (pa < 90 ? h : 0), bd, tmp);
+    up_l = edge_upsample_sel_dev(w, h, ftype, pa - 180);
+    if (up_l) edge_upsample_dev(wl_, h + (pa > 180 ? w : 0), bd, tmp);
+    int dx = 0, dy = 0;
+    if (pa < 90) dx = dr_deriv_dev(pa); else if (pa > 90 && pa < 180) dx = dr_deriv_dev(180 - pa);
+    if (pa > 90 && pa < 180) dy = dr_deriv_dev(pa - 90); else if (pa > 180) dy = dr_deriv_dev(270 - pa);
+    for (int idx = LANE; idx < nn; idx += 64) {
+      const int i = idx >> wl, j = idx & (w - 1);
+      int v;
+      if (pa < 90) {
+        const int max_base = (w + h - 1) << up_a;
+        const int id = (i + 1) * dx, base = (id >> (6 - up_a)) + (j << up_a), sh = ((id << up_a) >> 1) & 0x1F;
+        v = base < max_base ? round2_(wa[base] * (32 - sh) + wa[base + 1] * sh, 5) : wa[max_base];
+      } else if (pa > 90 && pa < 180) {
+        int id = (j << 6) - (i + 1) * dx, base = id >> (6 - up_a);
+        if (base >= -(1 << up_a)) { const int sh = ((id << up_a) >> 1) & 0x1F; v = round2_(wa[base] * (32 - sh) + wa[base + 1] * sh, 5); }
+        else { id = (i << 6) - (j + 1) * dy; base = id >> (6 - up_l); const int sh = ((id << up_l) >> 1) & 0x1F; v = round2_(wl_[base] * (32 - sh) + wl_[base + 1] * sh, 5); }
+      } else if (pa > 180) {
+        const int id = (j + 1) * dy, base = (id >> (6 - up_l)) + (i << up_l), sh = ((id << up_l) >> 1) & 0x1F;
+        v = round2_(wl_[base] * (32 - sh) + wl_[base + 1] * sh, 5);
+      } else if (pa == 90) v = wa[j];
+      else v = wl_[i];
+      pred[idx] = (uint16_t)v;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// 4x4-Hadamard SATD of a w x h block (satd_dev with both dimensions; pitch w)
+__device__ inline long long satd_wh(const LDS uint16_t *src, const LDS uint16_t *pred, int w, int h) {
+  const int units = w * (h >> 2);
+  int total = 0;
+  for (int u = LANE; u < units; u += 64) {
+    const int x = u % w, o = (u / w) * 4 * w + x;
+    const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + w] - (int)pred[o + w];
+    const int d2 = (int)src[o + 2 * w] - (int)pred[o + 2 * w], d3 = (int)src[o + 3 * w] - (int)pred[o + 3 * w];
+    const int a = d0 + d1, b = d0 - d1, c = d2 + d3, e = d2 - d3;
+    int t[4] = { a + c, b + e, a - c, b - e };
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { int v = satd_quad_step<0xB1>(t[i], 1); v = satd_quad_step<0x4E>(v, 2); s += iabs_(v); }
+    total += s;
+  }
+  return (long long)wave_sum_i32(total);
+}
+
+// 2:1 transforms, W x H in {4x8, 8x4}: libaom's forward stage shifts {2, -1, 0} with the sqrt(2) scale after the row pass, the spec's inverse
+// (7.13.3: Round2(x * 2896, 12) before the row pass, rowShift 0).  tbuf: int32 [H][W + 1]; coef / dq: [H][W].
+template <int W, int H> __device__ inline void fwd_txfm_rect(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) {
+  constexpr int P = W + 1;
+  int ck, rk; tx_kinds(txtype, &ck, &rk);
+  for (int c = LANE; c < W; c += 64) {
+    int32_t x[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) x[r] = tbuf[r * P + c] << 2;
+    tx1d<H>(x, ck, true);
+#pragma unroll
+    for (int r = 0; r < H; r++) tbuf[r * P + c] = rshift_round_(x[r], 1);
+  }
+  WAVE_SYNC();
+  for (int r = LANE; r < H; r += 64) {
+    int32_t x[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) x[c] = tbuf[r * P + c];
+    tx1d<W>(x, rk, true);
+#pragma unroll
+    for (int c = 0; c < W; c++) coef[r * W + c] = (int32_t)(((long long)x[c] * 5793 + 2048) >> 12);
+  }
+  WAVE_SYNC();
+}
+template <int W, int H> __device__ inline void inv_txfm_rect_add(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) {
+  constexpr int P = W + 1;
+  int ck, rk; tx_kinds(txtype, &ck, &rk);
+  const int cbits = imax_(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
+  for (int i = LANE; i < H; i += 64) {
+    int32_t x[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) x[j] = round2_(dq[i * W + j] * 2896, 12);      // dq already clamped to 8 + bd bits by the dequantiser
+    tx1d<W>(x, rk, false);
+#pragma unroll
+    for (int j = 0; j < W; j++) tbuf[i * P + j] = iclamp_(x[j], cmin, cmax);
+  }
+  WAVE_SYNC();
+  const int mx = (1 << bd) - 1;
+  for (int j = LANE; j < W; j += 64) {
+    int32_t x[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) x[i] = tbuf[i * P + j];
+    tx1d<H>(x, ck, false);
+#pragma unroll
+    for (int i = 0; i < H; i++) rec[i * W + j] = (uint16_t)iclamp_((int)rec[i * W + j] + round2_(x[i], 4), 0, mx);
+  }
+  WAVE_SYNC();
+}
+
+// tx set / CDF row of a 2:1 transform (oracle av1o_tx_set / av1o_intra_tx_cdf): the larger dimension (8) bounds the set, the smaller (4) indexes the CDFs
+template <typename FP> __device__ __forceinline__ int rect_tx_cdf(FP f, int ymode, int *nsyms, int *set_out) {
+  const int set = f->reduced_tx_set ? 2 : 1;
+  *set_out = set;
+  if (f->base_q_idx == 0) { *nsyms = 0; return -1; }
+  if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + ymode * CDF_INTRA_TX1_STRIDE; }
+  *nsyms = 5; return CDF_INTRA_TX2 + ymode * CDF_INTRA_TX2_STRIDE;
+}
+
+// Quantise (rav1e dead-zone rule as quantize_dev), level map, rate (oracle av1o_code_coeffs priced against the static table, one scan position per
+// lane), dequantise in place.  cbuf: coefficients in, dequantised out; qc: levels out; lev: (w + 4) x (h + 4) bytes.  Returns eob.
+template <typename CostPtr>
+__device__ inline int rect_quant_rate(CostPtr cost, LDS int32_t *cbuf, LDS int32_t *qc, LDS uint8_t *lev, int plane, int wl, int hl, int txtype, int dcq, int acq,
+                                      uint32_t dc_recip, uint32_t ac_recip, int bd, int skip_ctx, int dc_ctx, int tx_off, int tx_sym, uint32_t *rate_out, int *cul_out, int *dc_cat) {
+  const int w = 1 << wl, h = 1 << hl, nc = w * h, st = w + 4;
+  const int cls = tx_class_of(txtype), pt = plane > 0, txs_ctx = 1;          // (sqr + sqr_up + 1) >> 1 of 4x8 / 8x4
+  const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
+  const uint32_t thr = (uint32_t)acq - off_eob, uq = (uint32_t)acq;
+  const int i = LANE, valid = i < nc;
+  const int pos = valid ? rect_scan_pos(wl, hl, cls, i) : 0;
+  const int cf = valid ? cbuf[pos] : 0;
+  const uint32_t mag = (uint32_t)iabs_(cf); const int neg = cf < 0;
+  int last = (valid && i >= 1 && mag >= thr) ? i + 1 : 0;
+  last = wave_max_i32(last);
+  const uint32_t x0 = (uint32_t)iabs_(cbuf[0]) + dc_off;
+  uint32_t l0u = __umulhi(x0, dc_recip);
+  if (x0 - l0u * (uint32_t)dcq >= (uint32_t)dcq) l0u++;
+  const int l0 = (int)l0u;
+  int eob = last;
+  if (eob == 0) eob = l0 ? 1 : 0;
+  WAVE_SYNC();
+  int lv = 0;
+  if (valid && i < eob) {
+    if (i == 0) lv = l0;
+    else {
+      uint32_t lv0 = __umulhi(mag, ac_recip);
+      if (mag - lv0 * uq >= uq) lv0++;
+      const uint32_t off = lv0 > 0 ? off1 : off0;
+      lv = (int)lv0 + ((mag + off) >= (lv0 + 1) * uq);
+    }
+  }
+  // level map with a 4-wide zero border
+  for (int q = LANE; q < st * (h + 4); q += 64) lev[q] = 0;
+  WAVE_SYNC();
+  const int dmx = (1 << (7 + bd)) - 1, dmn = -(1 << (7 + bd));
+  if (valid) {
+    qc[pos] = neg ? -lv : lv;
+    lev[(pos >> wl) * st + (pos & (w - 1))] = (uint8_t)imin_(lv, 127);
+    uint32_t m = (uint32_t)lv * (uint32_t)(pos == 0 ? dcq : acq);
+    m &= 0xFFFFFF;
+    const int v = neg ? -(int)m : (int)m;
+    cbuf[pos] = v < dmn ? dmn : (v > dmx ? dmx : v);
+  }
+  WAVE_SYNC();
+  *cul_out = 0; *dc_cat = 0;
+  uint32_t head = cost[CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  if (eob == 0) { *rate_out = head; for (int q = LANE; q < st * (h + 4); q += 64) lev[q] = 0; WAVE_SYNC(); return 0; }
+  if (tx_off >= 0) head += cost[tx_off + tx_sym];
+  const int eob_pt = eob_to_pt(eob);
+  head += cost[eob_pt_cdf(1, pt, cls) + eob_pt - 1];                          // eob_multi = log2(32) - 4 = 1: the 32-coefficient table
+  if (eob_pt >= 3) {
+    const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+    head += cost[CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi] + 512u * (uint32_t)(nb - 1);
+  }
+  uint32_t mine = 0;
+  if (valid && i < eob) {
+    const int row = pos >> wl, col = pos & (w - 1), level = lv;
+    const LDS uint8_t *L = lev + row * st + col;
+    if (i == eob - 1) {
+      const int ctx = i == 0 ? 0 : (i <= nc / 8 ? 1 : (i <= nc / 4 ? 2 : 3));
+      mine += cost[CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+    } else {
+      int ctx = base_ctx(L, st, cls, row, col);
+      if (cls == TXC_2D && !(row == 0 && col == 0)) {                          // spec Coeff_Base_Ctx_Offset of the 2:1 sizes
+        int mg = imin_(L[1], 3) + imin_(L[st], 3) + imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3);
+        const int m = imin_((mg + 1) >> 1, 4);
+        if (hl > wl) ctx = m + (row < 2 ? 11 : (row + col < 4 ? 6 : 21));
+        else ctx = m + (col < 2 ? 16 : (row + col < 4 ? 6 : 21));
+      }
+      mine += cost[CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+    }
+    if (level > 2) {
+      const int off = CDF_COEFF_BR + ((txs_ctx * 2 + pt) * 21 + br_ctx(L, st, cls, row, col, i)) * CDF_COEFF_BR_STRIDE;
+      int rem = level - 3;
+      for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); mine += cost[off + s]; rem -= s; if (s < 3) break; }
+    }
+    if (level) {
+      if (i == 0) mine += cost[CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + neg];
+      else mine += 512u;
+      if (level > 14) { const uint32_t xg = (uint32_t)(level - 14); const int len = 32 - __clz(xg); mine += 512u * (uint32_t)(2 * len - 1); }
+    }
+  }
+  const int cul = imin_(wave_sum_i32((valid && i < eob) ? lv : 0), 63);
+  const int dcneg = __builtin_amdgcn_readlane(neg, 0), dclv = __builtin_amdgcn_readlane(lv, 0);
+  *cul_out = cul; *dc_cat = dclv ? (dcneg ? 1 : 2) : 0;
+  *rate_out = head + (uint32_t)wave_sum_i32((int)mine);
+  // the square sizes keep their level maps' borders zero for the whole tile (dev_rate.h LEV_OFF: 4x4 at 0, 8x8 at 64): leave this region as found
+  for (int q = LANE; q < st * (h + 4); q += 64) lev[q] = 0;
+  WAVE_SYNC();
+  return eob;
+}
+
+// One 2:1 transform block by one wave (eval_tx for the rectangular sizes).  psv2 / act: the two 4x4 cells' source variances and the activity of the
+// 8x8 cell the block lies in (luma, Tune::Psychovisual); cact: the same activity for chroma.
+template <int MAXN, int WL, int HL, int NW>
+__device__ inline long long eval_rect(const Ctx<MAXN, NW> k, int plane, int sctx, int dctx, const LDS uint16_t *src, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+                                      LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, int psv_a, int psv_b, int act) {
+  constexpr int W = 1 << WL, H = 1 << HL, P = W + 1, NN = W * H;
+  const LDS FrameDev *f = k.f(); LDS WaveScratch<MAXN> *S = k.s();
+  for (int idx = LANE; idx < NN; idx += 64) { S->tbuf[(idx >> WL) * P + (idx & (W - 1))] = (int)src[idx] - (int)pred[idx]; rec_out[idx] = pred[idx]; }
+  WAVE_SYNC();
+  fwd_txfm_rect<W, H>(S->tbuf, S->cbuf, txtype);
+  const int eob = rect_quant_rate(k.cost(), S->cbuf, qc_out, S->lev, plane, WL, HL, txtype, f->dc_q[plane], f->ac_q[plane], f->dc_recip[plane], f->ac_recip[plane], f->bd,
+                                  sctx, dctx, tx_off, tx_sym, &tr->rate, &tr->cul, &tr->dcc);
+  if (eob > 0) inv_txfm_rect_add<W, H>(S->cbuf, S->tbuf, rec_out, txtype, f->bd);
+  tr->eob = eob;
+  // distortion: luma = the two 4x4 cells priced like psy_dist_wave (boost x activity), chroma = SSE x activity
+  int sd[2] = { 0, 0 }, qd[2] = { 0, 0 }, se[2] = { 0, 0 };
+  if (LANE < NN) {
+    const int i = LANE >> WL, j = LANE & (W - 1), cell = W == 8 ? (j >> 2) : (i >> 2);
+    const int d = rec_out[LANE], e = (int)src[LANE] - d;
+    sd[cell] = d; qd[cell] = d * d; se[cell] = e * e;
+  }
+  long long dist;
+  if (plane == 0 && !f->tune_psnr) {
+    dist = 0;
+#pragma unroll
+    for (int cell = 0; cell < 2; cell++) {
+      const uint32_t s1 = (uint32_t)wave_sum_i32(sd[cell]), s2 = (uint32_t)wave_sum_i32(qd[cell]), s3 = (uint32_t)wave_sum_i32(se[cell]);
+      dist += psy_cell_dist(s3, s1, s2, (uint32_t)(cell ? psv_b : psv_a), (uint32_t)act, 4, f->bd);
+    }
+  } else {
+    const long long e = (long long)wave_sum_i32(se[0] + se[1]);
+    dist = plane == 0 ? e : (e * act + 8192) >> 14;
+  }
+  tr->sse = dist;
+  return ((dist * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
+}
+#endif  // MI_RECT_PART
+
+#if MI_RECT_PART
+// ---- the block search for an 8x4 / 4x8 block (oracle try_block with bs = BS_8X4 / BS_4X8): same candidates, same order, same tie-breaks ----
+template <int WL, int HL> __device__ inline void commit_rect(const LDS FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
+  constexpr int W = 1 << WL, H = 1 << HL;
+  uint16_t *gr = f->rec[plane] + (size_t)(r * 4) * f->stride + c * 4;
+  int32_t *gc = f->coef[plane] + (size_t)(r * 4) * f->stride + c * 4;
+  for (int idx = LANE; idx < W * H; idx += 64) { gr[(idx >> WL) * f->stride + (idx & (W - 1))] = rec[idx]; gc[(idx >> WL) * f->stride + (idx & (W - 1))] = qc[idx]; }
+  if (LANE < 2) { const int rr = r + (H == 8 ? LANE : 0), cc = c + (W == 8 ? LANE : 0); f->m_lvl[plane][rr * f->mi_stride + cc] = (uint8_t)cul; f->m_dc[plane][rr * f->mi_stride + cc] = (uint8_t)dcc; }
+  if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
+}
+// the block's two cells of a byte map
+template <int WL, int HL> __device__ __forceinline__ void fill_rect(uint8_t *m, int ms, int r, int c, int v) {
+  if (LANE < 2) m[(r + (HL == 3 ? LANE : 0)) * ms + c + (WL == 3 ? LANE : 0)] = (uint8_t)v;
+}
+// all_zero / dc_sign contexts of a transform block of w4 x h4 cells inside a block (txb_ctx_dev with both dimensions); `whole`: the transform is the block
+template <typename FP, typename TP> __device__ inline void txb_ctx_wh(FP f, TP t, int plane, int r4, int c4, int w4, int h4, int whole, int *skip_ctx, int *dc_ctx) {
+  const int ms = f->mi_stride;
+  int top = 0, left = 0, dcs = 0, any_a = 0, any_l = 0;
+  const int k = LANE;
+  if (k < imax_(w4, h4)) {
+    const bool ha = k < w4 && r4 - 1 >= t->mi_row_start && c4 + k < f->mi_cols, hl = k < h4 && c4 - 1 >= t->mi_col_start && r4 + k < f->mi_rows;
+    const int ia = ha ? (r4 - 1) * ms + c4 + k : r4 * ms + c4, il = hl ? (r4 + k) * ms + c4 - 1 : r4 * ms + c4;
+    const int la = f->m_lvl[plane][ia], da = f->m_dc[plane][ia], ll = f->m_lvl[plane][il], dl = f->m_dc[plane][il];
+    if (ha) { top = la; any_a = la | da; dcs += da == 1 ? -1 : (da == 2 ? 1 : 0); }
+    if (hl) { left = ll; any_l = ll | dl; dcs += dl == 1 ? -1 : (dl == 2 ? 1 : 0); }
+  }
+  top = wave_max_i32(top); left = wave_max_i32(left); dcs = wave_sum_i32(dcs);
+  any_a = wave_or_i32(any_a); any_l = wave_or_i32(any_l);
+  *dc_ctx = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+  if (plane == 0) {
+    int ctx;
+    if (whole) ctx = 0;
+    else if (top == 0 && left == 0) ctx = 1;
+    else if (top == 0 || left == 0) ctx = 2 + (imax_(top, left) > 3);
+    else if (imax_(top, left) <= 3) ctx = 4;
+    else if (imin_(top, left) <= 3) ctx = 5;
+    else ctx = 6;
+    *skip_ctx = ctx;
+  } else *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (whole ? 0 : 3);
+}
+
+template <int MAXN, int BSR, int NW>
+__device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+  constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL, NN = W_ * H_, w4 = W_ >> 2, h4 = H_ >> 2;
+  const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
+  const int W = NW > 1 ? WAVE_ID : 0;
+  const int ms = f->mi_stride, mi = r * ms + c, x = c * 4, y = r * 4;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int can_ar = availU && (c + w4 < t->mi_col_end), can_bl = availL && (r + h4 < t->mi_row_end);
+  const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
+  const int have_ar = can_ar && uni32(f->m_decoded[can_ar ? (r - 1) * ms + c + w4 : mi]), have_bl = can_bl && uni32(f->m_decoded[can_bl ? (r + h4) * ms + c - 1 : mi]);
+  const int amode = availU ? uni32(f->m_ymode[iU]) : DC_PRED, lmode = availL ? uni32(f->m_ymode[iL]) : DC_PRED;
+  const int uvU = f->np > 1 ? uni32(f->m_uvmode[iU]) : 0, uvL = f->np > 1 ? uni32(f->m_uvmode[iL]) : 0;
+  const int nb_skip = (availU ? uni32(f->m_skip[iU]) : 0) + (availL ? uni32(f->m_skip[iL]) : 0);
+  const int nb_txU = availU ? uni32(f->m_txsize[iU]) : -1, nb_txL = availL ? uni32(f->m_txsize[iL]) : -1;
+  const uint16_t *ycost = k.cost() + CDF_KF_Y + (intra_mode_ctx(amode) * 5 + intra_mode_ctx(lmode)) * CDF_KF_Y_STRIDE;
+  const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);
+  const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uvU)) || (availL && IS_SMOOTH_(uvL)));
+  LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
+
+  // ---- stage the source block, the raw edges and the transform contexts of every plane (plane p by wave p % NW), the psychovisual references
+  for (int p = 0; p < f->np; p++) if (p % NW == W) {
+    int sc_, dc_;
+    txb_ctx_wh(f, t, p, r, c, w4, h4, 1, &sc_, &dc_);
+    if (LANE == 0) { SH->sctx[p] = sc_; SH->dctx[p] = dc_; }
+    const uint16_t *g = f->src[p] + (size_t)y * f->stride + x;
+    for (int idx = LANE; idx < NN; idx += 64) SH->srcb[p][idx] = g[(idx >> WL) * f->stride + (idx & (W_ - 1))];
+    load_edges_wh(f, p, x, y, W_, H_, availL, availU, have_ar, have_bl, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF);
+  }
+  if (W == NW - 1 && LANE < 2) {
+    SH->psv4[LANE] = (int)f->svar4[(r + (HL == 3 ? LANE : 0)) * ms + c + (WL == 3 ? LANE : 0)];
+    if (LANE == 0) { const int a = (int)f->act[(y >> 3) * (f->pw >> 3) + (x >> 3)]; SH->pact[0] = a; SH->cact = a; }
+  }
+  WG_SYNC();
+  const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];
+  const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
+  const int psv_a = f->tune_psnr ? 0 : SH->psv4[0], psv_b = f->tune_psnr ? 0 : SH->psv4[1], act = SH->pact[0];
+
+  // ---- luma: SATD over the 13 modes (mode m by wave m % NW), stable sort ----
+  for (int m = W; m < 13; m += NW) {
+    predict_block_wh(f, x, y, WL, HL, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+    const long long sd = satd_wh(SH->srcb[0], S->pred, W_, H_);
+    if (LANE == 0) SH->satd[m] = sd;
+  }
+  WG_SYNC();
+  if (LANE < 13) {
+    const long long mine = SH->satd[LANE];
+    int rank = 0;
+    for (int j = 0; j < 13; j++) { const long long o = SH->satd[j]; rank += (o < mine) || (o == mine && j < LANE); }
+    SH->order[rank] = LANE;
+  }
+  WG_SYNC();
+  // ---- full RD over the surviving modes x tx types (no angle deltas below 8x8): evaluation e = ci * ntx + ti by wave e % NW ----
+  const int ncand = f->complex_modes ? 7 : 3;
+  int tx_ns = 0, tx_set = 0;
+  const int tx_off0 = rect_tx_cdf(f, 0, &tx_ns, &tx_set);
+  const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 }; uint32_t my_mrate = 0;
+  for (int e = W; e < ncand * ntx; e += NW) {
+    const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
+    predict_block_wh(f, x, y, WL, HL, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+    const uint32_t mode_rate = ycost[m];
+    int ns2, set2;
+    const int tx_off = rect_tx_cdf(f, m, &ns2, &set2);
+    int txtype;
+    if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
+    else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
+    TxRes tr;
+    long long j = eval_rect<MAXN, WL, HL, NW>(k, 0, sctx_y, dctx_y, SH->srcb[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr, psv_a, psv_b, act);
+    j += ((long long)mode_rate * f->rdmult + 256) >> 9;
+    if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
+  }
+  if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
+  WG_SYNC();
+  int win = 0;
+  for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
+  const long long best_j = SH->wbest_j[win];
+  if (W == win) {
+    const int b = cur ^ 1;
+    commit_rect<WL, HL>(f, 0, r, c, S->rec[b], S->qc[b], my_tr.eob, my_tr.cul, my_tr.dcc);
+    fill_rect<WL, HL>(f->m_ymode, ms, r, c, my_mode);
+    fill_rect<WL, HL>((uint8_t *)f->m_angle_y, ms, r, c, 0);
+    fill_rect<WL, HL>(f->m_txtype, ms, r, c, my_tr.eob ? my_tx : DCT_DCT);
+    fill_rect<WL, HL>(f->m_bsize, ms, r, c, BSR);
+    fill_rect<WL, HL>(f->m_txsize, ms, r, c, BSR);
+    if (f->np > 1) for (int i = LANE; i < NN; i += 64) SH->luma_rec[i] = S->rec[b][i];
+    if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_eob = my_tr.eob; SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9; SH->lm_tx = my_tr.cul; SH->lm_delta = my_tr.dcc; }
+  }
+  WG_SYNC();
+  const int best_mode = SH->lm_mode;
+  long long luma_j = best_j; int any_coef = SH->lm_eob > 0;
+  // ---- luma transform size: the 2:1 transform against its two 4x4 halves (Split_Tx_Size), tx_depth priced with the 8x8 category ----
+  if (f->tx_mode_select) {
+    const int actx = nb_txU >= 0 && dim_wl(nb_txU) >= WL, lctx = nb_txL >= 0 && dim_hl(nb_txL) >= HL;
+    const uint16_t *dcost = k.cost() + CDF_TX_SIZE + (actx + lctx) * CDF_TX_SIZE_STRIDE;
+    luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
+    if (f->rdo_tx) {
+      long long j_split = SH->lm_mode_j + (((long long)dcost[1] * f->rdmult + 256) >> 9);
+      int stx_ns = 0, stx_set = 0;
+      const int stx_off = intra_tx_cdf(f, 0, best_mode, &stx_ns, &stx_set);
+      const int sntx = stx_off >= 0 ? stx_ns : 1;
+      LDS uint16_t *split_rec = (LDS uint16_t *)SH->ssrc + 64;             // [NN] (ssrc[0..31] = the two sub-sources)
+      LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;   // [2][16]
+      LDS int *sub = (LDS int *)SH->dsd;                                     // [2][4]: tx, eob, cul, dcc of the halves
+      int sub_any = 0;
+      if (W == 0) for (int idx = LANE; idx < NN; idx += 64) { const int q = W_ == 8 ? ((idx & 7) >> 2) : (idx >> 4), i = (idx >> WL) & 3, j = idx & 3; SH->ssrc[q * 16 + i * 4 + j] = SH->srcb[0][idx]; }
+      WG_SYNC();
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) {
+        if (j_split >= budget && luma_j >= budget) return luma_j;
+        if (!(j_split < luma_j)) break;
+        const int bi = H_ == 8 ? q : 0, bj = W_ == 8 ? q : 0, rr = r + bi, cc = c + bj, sx = x + bj * 4, sy = y + bi * 4;
+        const int sU = availU || bi, sL = availL || bj;
+        if (W == 0) {
+          // availability of the halves' above-right / below-left runs (oracle: the decoded flags of the cells they start in)
+          const bool c_ar = sU && cc + 1 < t->mi_col_end, c_bl = sL && rr + 1 < t->mi_row_end;
+          const int s_ar = c_ar && uni32(f->m_decoded[c_ar ? (rr - 1) * ms + cc + 1 : mi]), s_bl = c_bl && uni32(f->m_decoded[c_bl ? (rr + 1) * ms + cc - 1 : mi]);
+          LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+          const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+          const uint16_t *grec = f->rec[0];
+          const int lim_a = imin_(max_x, sx + (s_ar ? 8 : 4) - 1), lim_l = imin_(max_y, sy + (s_bl ? 8 : 4) - 1);
+          auto px = [&](int ax, int ay) -> int {
+            const int xr = ax - x, yr = ay - y;
+            if (xr >= 0 && xr < W_ && yr >= 0 && yr < H_) return (int)split_rec[yr * W_ + xr];
+            if (yr == -1 && xr >= -1 && xr < W_ + H_) return (int)ra[xr];
+            if (xr == -1 && yr >= 0 && yr < W_ + H_) return (int)rl[yr];
+            return (int)grec[(size_t)ay * rs + ax];
+          };
+          for (int i = LANE; i <= 8; i += 64) {
+            const bool corner = i == 8;
+            int a, l;
+            if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+            if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+            if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+            if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+          }
+          WAVE_SYNC();
+          predict_block(f, sx, sy, 2, sL, sU, best_mode, 0, ftype_y, A, Lf, wa, wl, S->etmp, SH->spred);
+          int ssc, sdc;
+          txb_ctx_wh(f, t, 0, rr, cc, 1, 1, 0, &ssc, &sdc);                  // the first half's contexts are in the frame by the time the second asks (committed below)
+          if (LANE == 0) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; sub[8] = ssc; sub[9] = sdc; }
+        }
+        WG_SYNC();
+        const int ssc = sub[8], sdc = sub[9];
+        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, scur = 0;
+        for (int e = W; e < sntx; e += NW) {
+          int txtype;
+          if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
+          else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+          TxRes tr;
+          const long long j = eval_tx<MAXN, 0, NW>(k, 0, ssc, sdc, SH->spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
+                                                 SH->ssrc + q * 16, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
+          if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
+        }
+        if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+        WG_SYNC();
+        int sw = 0;
+        for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
+        const long long sub_j = SH->wbest_j[sw];
+        if (W == sw) {
+          const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
+          for (int i = LANE; i < 16; i += 64) { split_rec[(bi * 4 + (i >> 2)) * W_ + bj * 4 + (i & 3)] = srec[i]; split_qc[q * 16 + i] = sqc[i]; }
+          if (LANE == 0) {
+            sub[q * 4 + 0] = s_eob ? stx : DCT_DCT; sub[q * 4 + 1] = s_eob; sub[q * 4 + 2] = s_cul; sub[q * 4 + 3] = s_dcc;
+            // the second half reads the first one's contexts from the frame maps (txb_ctx_wh above): leave them there for the trial; the undivided
+            // transform's values come back below if the split loses
+            f->m_lvl[0][rr * ms + cc] = (uint8_t)s_cul; f->m_dc[0][rr * ms + cc] = (uint8_t)s_dcc;
+          }
+        }
+        WG_SYNC();
+        sub_any |= sub[q * 4 + 1] > 0;
+        j_split += sub_j;
+      }
+      if (j_split < luma_j) {
+        luma_j = j_split; any_coef = sub_any;
+        uint16_t *gr_ = f->rec[0] + (size_t)y * f->stride + x;
+        int32_t *gc_ = f->coef[0] + (size_t)y * f->stride + x;
+        for (int i = threadIdx.x; i < NN; i += 64 * NW) {
+          const uint16_t v = split_rec[i]; gr_[(i >> WL) * f->stride + (i & (W_ - 1))] = v; if (f->np > 1) SH->luma_rec[i] = v;
+          const int q = W_ == 8 ? ((i & 7) >> 2) : (i >> 4), ii = (i >> WL) & 3, jj = i & 3;
+          gc_[(i >> WL) * f->stride + (i & (W_ - 1))] = split_qc[q * 16 + ii * 4 + jj];
+        }
+        if (W == 0 && LANE < 2) {
+          const int rr = r + (H_ == 8 ? LANE : 0), cc = c + (W_ == 8 ? LANE : 0), o = rr * ms + cc;
+          f->m_txsize[o] = 0; f->m_txtype[o] = (uint8_t)sub[LANE * 4 + 0]; f->m_eob[0][o] = (uint16_t)sub[LANE * 4 + 1];
+          f->m_lvl[0][o] = (uint8_t)sub[LANE * 4 + 2]; f->m_dc[0][o] = (uint8_t)sub[LANE * 4 + 3];
+        }
+      } else if (W == 0 && LANE < 2) {                                        // the undivided transform stays: its contexts back over the trial's
+        const int o = (r + (H_ == 8 ? LANE : 0)) * ms + c + (W_ == 8 ? LANE : 0);
+        f->m_lvl[0][o] = (uint8_t)SH->lm_tx; f->m_dc[0][o] = (uint8_t)SH->lm_delta;
+      }
+      WG_SYNC();
+    }
+  }
+  if (luma_j >= budget) return luma_j;
+  long long total_j = luma_j;
+  // ---- chroma: the candidates one after the other, plane p on wave p - 1 (oracle order: DC, the luma mode, [the other modes,] CfL) ----
+  if constexpr (NW >= 2) if (f->np > 1) {
+    const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
+    unsigned long long cand_pack = 0; int nc = 0;
+    auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
+    push(DC_PRED);
+    if (best_mode != DC_PRED) push(best_mode);
+    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    push(UV_CFL_PRED);
+    const int uvset = f->reduced_tx_set ? 2 : 1;
+    const int p = W + 1, mine = W < 2;
+    long long best_uv = J_INF; int b_um = DC_PRED, b_sign = 0, b_au = 0, b_av = 0, ccur = 0; TxRes b_tr = { 0, 0, 0, 0, 0 };
+    for (int ci = 0; ci < nc; ci++) {
+      const int um = lut4(cand_pack, ci);
+      int txtype = mode_to_txtype(um);
+      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
+      TxRes tr = { 0, 0, 0, 0, 0 };
+      if (mine) {
+        if (um == UV_CFL_PRED) {
+          predict_block_wh(f, x, y, WL, HL, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
+          // rdo_cfl_alpha: oracle cfl_best_alpha -- alpha 0, then +1, -1, +2, -2, ... +16, -16; the first strictly smaller SSE wins
+          int lsum = LANE < NN ? (int)SH->luma_rec[LANE] << 3 : 0;
+          lsum = wave_sum_i32(lsum);
+          const int avg = round2_(lsum, WL + HL), mx = (1 << f->bd) - 1;
+          const int l = LANE < NN ? ((int)SH->luma_rec[LANE] << 3) - avg : 0, dcv = LANE < NN ? (int)S->dcp[LANE] : 0, sv = LANE < NN ? (int)SH->srcb[p][LANE] : 0;
+          int d0 = LANE < NN ? sv - dcv : 0;
+          long long bsse = (long long)wave_sum_i32(d0 * d0); int balpha = 0;
+          for (int mag = 1; mag <= 16; mag++) for (int sg = 0; sg < 2; sg++) {
+            const int alpha = sg ? -mag : mag, v = alpha * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+            const int d = LANE < NN ? sv - iclamp_(dcv + sc, 0, mx) : 0;
+            const long long e = (long long)wave_sum_i32(d * d);
+            if (e < bsse) { bsse = e; balpha = alpha; }
+          }
+          if (LANE == 0) SH->calpha[0][p - 1] = balpha;
+        }
+      }
+      if (um == UV_CFL_PRED) WG_SYNC();
+      const int alpha_u = um == UV_CFL_PRED ? SH->calpha[0][0] : 0, alpha_v = um == UV_CFL_PRED ? SH->calpha[0][1] : 0;
+      const int ok = !(um == UV_CFL_PRED && alpha_u == 0 && alpha_v == 0);
+      if (mine && ok) {
+        if (um == UV_CFL_PRED) {
+          const int al = p == 1 ? alpha_u : alpha_v;
+          if (al) {
+            int lsum = LANE < NN ? (int)SH->luma_rec[LANE] << 3 : 0;
+            lsum = wave_sum_i32(lsum);
+            const int avg = round2_(lsum, WL + HL), mx = (1 << f->bd) - 1;
+            if (LANE < NN) { const int l = ((int)SH->luma_rec[LANE] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6); S->pred[LANE] = (uint16_t)iclamp_((int)S->dcp[LANE] + sc, 0, mx); }
+          } else if (LANE < NN) S->pred[LANE] = S->dcp[LANE];
+          WAVE_SYNC();
+        } else predict_block_wh(f, x, y, WL, HL, availL, availU, um, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->pred);
+        const long long jp = eval_rect<MAXN, WL, HL, NW>(k, p, SH->sctx[p], SH->dctx[p], SH->srcb[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &tr, 0, 0, SH->cact);
+        if (LANE == 0) SH->cj[ci][p - 1] = jp;
+      }
+      WG_SYNC();
+      if (ok) {
+        int jsign = 0;
+        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, false, 0, um == UV_CFL_PRED, alpha_u, alpha_v, &jsign);
+        const long long j = SH->cj[ci][0] + SH->cj[ci][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        if (j < best_uv) { best_uv = j; b_um = um; b_sign = jsign; b_au = alpha_u; b_av = alpha_v; b_tr = tr; ccur ^= 1; }
+      }
+      WG_SYNC();
+    }
+    if (mine) {
+      const int b = ccur ^ 1;
+      commit_rect<WL, HL>(f, p, r, c, S->rec[b], S->qc[b], b_tr.eob, b_tr.cul, b_tr.dcc);
+      if (LANE == 0) SH->ceob[p - 1] = b_tr.eob;
+      if (p == 1) {
+        fill_rect<WL, HL>(f->m_uvmode, ms, r, c, b_um);
+        fill_rect<WL, HL>((uint8_t *)f->m_angle_uv, ms, r, c, 0);
+        fill_rect<WL, HL>(f->m_cfl_sign, ms, r, c, b_sign);
+        fill_rect<WL, HL>(f->m_cfl_au, ms, r, c, b_au ? iabs_(b_au) - 1 : 0);
+        fill_rect<WL, HL>(f->m_cfl_av, ms, r, c, b_av ? iabs_(b_av) - 1 : 0);
+      }
+    }
+    WG_SYNC();
+    any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
+    total_j += best_uv;
+  }
+  // ---- skip flag ----
+  const int skip = !any_coef;
+  if (W == 0) {
+    fill_rect<WL, HL>(f->m_skip, ms, r, c, skip);
+    if (skip) for (int p = 0; p < f->np; p++) { fill_rect<WL, HL>(f->m_lvl[p], ms, r, c, 0); fill_rect<WL, HL>(f->m_dc[p], ms, r, c, 0); }
+    fill_rect<WL, HL>(f->m_decoded, ms, r, c, 1);
+  }
+  total_j += ((long long)k.cost()[CDF_SKIP + nb_skip * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
+  WG_SYNC();
+  return total_j;
+}
+#endif  // MI_RECT_PART

@@ -138,22 +138,41 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
                                                   int tx_off, int tx_sym, int tx_ns) {
   const int eob = uni32(eob_in);
   RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
-  const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
+#if MI_RECT_PART
+  const bool rect = txs > 4;                              // 5 = 4x8, 6 = 8x4 (dev_rect.h)
+  const int bwl = rect ? (txs == 5 ? 2 : 3) : imin_(5, 2 + txs), bhl = rect ? (txs == 5 ? 3 : 2) : bwl, n = 1 << bwl, nh = 1 << bhl;
+  const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = rect ? 1 : txs;
+#else
+  const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, nh = n, bhl = bwl;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
+#endif
   re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
   K4CNT(9, 1); K4CNT(10, eob == 0);
   if (eob == 0) { K4PH(3); return; }
   // ---- (P) contexts, lane-parallel
-  const int st = n + 4, area = n * n;
+  const int st = n + 4, area = n * nh;
   for (int c = LANE; c < eob; c += 64) {
+#if MI_RECT_PART
+    const int p = rect ? rect_scan_pos(bwl, bhl, cls, c) : scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
+#else
     const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
+#endif
     const int v = qc[p], level = iabs_(v);
     const LDS uint8_t *L = lev + row * st + col;
     int off;                                                 // last position: its base_eob CDF row; the others: the base context (0..41)
     if (c == eob - 1) {
       const int ctx = c == 0 ? 0 : (c <= area / 8 ? 1 : (c <= area / 4 ? 2 : 3));
       off = CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE;
-    } else off = CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + base_ctx(L, st, cls, row, col)) * CDF_COEFF_BASE_STRIDE;
+    } else {
+      int bctx = base_ctx(L, st, cls, row, col);
+#if MI_RECT_PART
+      if (rect && cls == TXC_2D && !(row == 0 && col == 0)) {          // spec Coeff_Base_Ctx_Offset of the 2:1 sizes
+        const int mg = imin_(L[1], 3) + imin_(L[st], 3) + imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3), m = imin_((mg + 1) >> 1, 4);
+        bctx = bhl > bwl ? m + (row < 2 ? 11 : (row + col < 4 ? 6 : 21)) : m + (col < 2 ? 16 : (row + col < 4 ? 6 : 21));
+      }
+#endif
+      off = CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + bctx) * CDF_COEFF_BASE_STRIDE;
+    }
     int boff = 0;
     if (level > 2) boff = CDF_COEFF_BR + ((imin_(txs_ctx, 3) * 2 + pt) * 21 + br_ctx(L, st, cls, row, col, c)) * CDF_COEFF_BR_STRIDE;
     w->rec_off[c] = (uint16_t)off; w->rec_br[c] = (uint16_t)boff; w->rec_lv[c] = ((uint32_t)level << 1) | (uint32_t)(v < 0);
@@ -162,7 +181,7 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   K4PH(3);
   // ---- (S) serial coding
   if (tx_off >= 0) re_symbol_dev(e, tx_sym, cdf + tx_off, tx_ns);
-  const int eob_pt = eob_to_pt(eob), eob_multi = 2 * bwl - 4;
+  const int eob_pt = eob_to_pt(eob), eob_multi = bwl + bhl - 4;
   re_symbol_dev(e, eob_pt - 1, cdf + eob_pt_cdf(eob_multi, pt, cls), 5 + eob_multi);
   if (eob_pt >= 3) {
     const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
@@ -248,7 +267,11 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
   if (BS > 0 && w->tx_mode_select) {
     const int maxw = 4 << BS;
+#if MI_RECT_PART
+    const int actx = availU && (1 << dim_wl(v_txU)) >= maxw, lctx = availL && (1 << dim_hl(v_txL)) >= maxw;
+#else
     const int actx = availU && (4 << v_txU) >= maxw, lctx = availL && (4 << v_txL) >= maxw;
+#endif
     re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   K4PH(1); K4CNT(8, 1);
@@ -285,15 +308,93 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   WAVE_SYNC();
 }
 
+#if MI_RECT_PART
+// An 8x4 / 4x8 block (oracle write_block with a 2:1 size): no angle deltas, CfL allowed, tx_depth in the 8x8 category, one 2:1 transform or its two
+// 4x4 halves per luma block, one 2:1 transform per chroma plane.
+template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *w, int r, int c) {
+  constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL;
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
+  const int l_skip = f->m_skip[mi], l_ymode = f->m_ymode[mi], l_txs_y = f->m_txsize[mi];
+  const int l_skU = f->m_skip[iU], l_skL = f->m_skip[iL], l_ymU = f->m_ymode[iU], l_ymL = f->m_ymode[iL], l_txU = f->m_txsize[iU], l_txL = f->m_txsize[iL];
+  const int l_cdef = f->cdef_idx[(r >> 4) * w->sb_cols + (c >> 4)];
+  int l_uvmode = 0, l_js = 0, l_au = 0, l_av = 0;
+  if (w->np > 1) { l_uvmode = f->m_uvmode[mi]; l_js = f->m_cfl_sign[mi]; l_au = f->m_cfl_au[mi]; l_av = f->m_cfl_av[mi]; }
+  const int skip = U_(l_skip), ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
+  const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_cdef = U_(l_cdef), uvmode = U_(l_uvmode), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
+  RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
+  re_symbol_dev(e, skip, cdf + CDF_SKIP + ((availU ? v_skU : 0) + (availL ? v_skL : 0)) * CDF_SKIP_STRIDE, 2);
+  if (!skip && w->enable_cdef && w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, w->cdef_bits); }
+  const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
+  re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
+  if (w->np > 1) {
+    re_symbol_dev(e, uvmode, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
+    if (uvmode == UV_CFL_PRED) {
+      const int js = v_js, su = (js + 1) / 3, sv = (js + 1) % 3;
+      re_symbol_dev(e, js, cdf + CDF_CFL_SIGN, 8);
+      if (su) re_symbol_dev(e, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
+      if (sv) re_symbol_dev(e, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
+    }
+  }
+  if (w->tx_mode_select) {
+    const int actx = availU && dim_wl(v_txU) >= WL, lctx = availL && dim_hl(v_txL) >= HL;
+    re_symbol_dev(e, txs_y == BSR ? 0 : 1, cdf + CDF_TX_SIZE + (actx + lctx) * CDF_TX_SIZE_STRIDE, 2);
+  }
+  if (skip) return;
+  for (int p = 0; p < w->np; p++) {
+    const int txs = p == 0 ? txs_y : BSR, split = txs != BSR;                       // luma may be two 4x4 transforms
+    for (int bi = 0; bi < (split ? 2 : 1); bi++) {
+      const int rr = r + ((split && H_ == 8) ? bi : 0), cc = c + ((split && W_ == 8) ? bi : 0), tmi = rr * ms + cc;
+      if (rr >= w->mi_rows || cc >= w->mi_cols) continue;
+      const int l_eob = f->m_eob[p][tmi], l_txt = f->m_txtype[tmi];
+      const int tw = split ? 4 : W_, th = split ? 4 : H_, twl = split ? 2 : WL;
+      const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
+      WAVE_SYNC();
+      for (int idx = LANE; idx < tw * th; idx += 64) w->qc[idx] = src[(idx >> twl) * f->stride + (idx & (tw - 1))];
+      WAVE_SYNC();
+      {                                                                            // level map with its 4-wide zero border (build_level_map for tw x th)
+        const int st = tw + 4;
+        for (int i = LANE; i < st * (th + 4); i += 64) w->lev[i] = 0;
+        WAVE_SYNC();
+        for (int i = LANE; i < tw * th; i += 64) w->lev[(i >> twl) * st + (i & (tw - 1))] = (uint8_t)imin_(iabs_(w->qc[i]), 127);
+        WAVE_SYNC();
+      }
+      const int eob = U_(l_eob), v_txt = U_(l_txt);
+      int txtype, off = -1, sym = 0, ns = 0, set;
+      if (p == 0) {
+        txtype = v_txt;
+        off = split ? intra_tx_cdf(&w->txc, 0, ymode, &ns, &set) : rect_tx_cdf(&w->txc, ymode, &ns, &set);
+        if (off >= 0) sym = txtype_to_sym(set, txtype);
+      } else {
+        set = w->txc.reduced_tx_set ? 2 : 1;
+        txtype = mode_to_txtype(uvmode);
+        if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
+      }
+      int sctx2, dctx;
+      txb_ctx_wh(f, t, p, rr, cc, tw >> 2, th >> 2, !split, &sctx2, &dctx);
+      code_coeffs_lane0(w, eob, p, split ? 0 : BSR, txtype, sctx2, dctx, off, sym, ns);
+    }
+  }
+  WAVE_SYNC();
+}
+#endif
+
 // Partition symbol of the node (r, c, bs >= 1); returns 0 (NONE) or 3 (SPLIT).  spec 5.11.4
 __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int c, int bs) {
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms;
   const int half = (1 << bs) >> 1;
   const int has_rows = (r + half) < w->mi_rows, has_cols = (c + half) < w->mi_cols;
   const int actual = U_(f->m_bsize[r * ms + c]);
+#if MI_RECT_PART
+  int part = actual == bs ? 0 : ((bs == BS_8 && actual == BS_8X4) ? 1 : ((bs == BS_8 && actual == BS_4X8) ? 2 : 3));
+  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+  const int above = availU && dim_wl(U_(f->m_bsize[(r - 1) * ms + c])) < 2 + bs, left = availL && dim_hl(U_(f->m_bsize[r * ms + c - 1])) < 2 + bs;
+#else
   int part = actual == bs ? 0 : 3;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+#endif
   LDS uint16_t *cdf = w->cdf + CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
   const int ns = bs == BS_8 ? 4 : 10;
   if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
@@ -366,6 +467,10 @@ template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter
         }
         sp--; continue;
       }
+#if MI_RECT_PART
+      if (part == 1) { write_block_rect<BS_8X4>(w, r, c); write_block_rect<BS_8X4>(w, r + 1, c); sp--; continue; }
+      if (part == 2) { write_block_rect<BS_4X8>(w, r, c); write_block_rect<BS_4X8>(w, r, c + 1); sp--; continue; }
+#endif
     }
     if (kk == 4) { sp--; continue; }
     const int half = (1 << bs) >> 1;

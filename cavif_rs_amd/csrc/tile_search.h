@@ -259,6 +259,8 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
   if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
 }
 
+#include "dev_rect.h"
+
 // `budget`: the caller only needs to know whether the block's cost stays below it (split trials: cost of the
 // undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
 // reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
@@ -557,7 +559,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   // of the sub-block are dealt to the waves (16-lane rows for 4x4 / 8x8 transforms) like the candidates of a block.
   if constexpr (BS > 0) if (f->tx_mode_select) {
     const int maxw = 4 << BS;
+#if MI_RECT_PART
+    const int actx = nb_txU >= 0 && (1 << dim_wl(nb_txU)) >= maxw, lctx = nb_txL >= 0 && (1 << dim_hl(nb_txL)) >= maxw;   // neighbours may carry 2:1 transform codes
+#else
     const int actx = nb_txU >= 0 && (4 << nb_txU) >= maxw, lctx = nb_txL >= 0 && (4 << nb_txL) >= maxw;
+#endif
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
     if (tx_trial) {
@@ -1077,11 +1083,17 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
   WG_SYNC();
 }
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
+#define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
+#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0))   /* + the 8x8 node's best rectangular / split candidates */
 
 __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
+#if MI_RECT_PART
+  const int above = availU && dim_wl(f->m_bsize[(r - 1) * ms + c]) < 2 + bs, left = availL && dim_hl(f->m_bsize[r * ms + c - 1]) < 2 + bs;
+#else
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
+#endif
   return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
@@ -1119,6 +1131,28 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           j_split += sub_j[q];
           if (BS - 1 >= BS_8) j_split += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9);
         }
+#if MI_RECT_PART
+        if constexpr (BS == 1) {
+          // PARTITION_HORZ / PARTITION_VERT (two 8x4 / 4x8 blocks) against the best of NONE / SPLIT so far (oracle rd_partition)
+          uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
+          long long j_best = j_none; int have_split = 0, rect_won = 0;
+          if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
+          {
+            set_decoded_wg<NW>(f, r, c, n4, 0);
+            long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 1) * f->rdmult + 256) >> 9);
+            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
+            if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
+          }
+          {
+            set_decoded_wg<NW>(f, r, c, n4, 0);
+            long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 2) * f->rdmult + 256) >> 9);
+            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
+            if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
+          }
+          if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return 1; }   // 1: the later siblings' trial results are stale
+          if (have_split) area_copy_dev<BS, NW>(f, split_snap, r, c, 0);
+        }
+#endif
         if (j_split < j_none && !DBG_IS(f, 7) && !DBG_IS(f, 8) && !(DBG_IS(f, 10) && BS == 1)) do_split = 1;
         else { area_copy_dev<BS, NW>(f, k.snap(), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
       }
@@ -1153,7 +1187,6 @@ template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(i
   for (int b = maxbs; b > bs; b--) o += MI_SNAP_BYTES(4 << b);
   return o;
 }
-#define MI_SNAP_BYTES_ALL(n) (2 * MI_SNAP_BYTES(n))           /* sum over the levels < 4/3 of the largest */
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
   static __device__ MI_K1_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
     const LDS FrameDev *f = k.f();
@@ -1179,6 +1212,27 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       if (!must_split && j_split >= j_none) break;
       j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half);
     }
+#if MI_RECT_PART
+    if constexpr (BS == 1) if (!must_split) {
+      uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
+      long long j_best = j_none; int have_split = 0, rect_won = 0;
+      if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
+      {
+        set_decoded_wg<NW>(f, r, c, n4, 0);
+        long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 1) * f->rdmult + 256) >> 9);
+        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
+        if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
+      }
+      {
+        set_decoded_wg<NW>(f, r, c, n4, 0);
+        long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 2) * f->rdmult + 256) >> 9);
+        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
+        if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
+      }
+      if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_best; }
+      if (have_split) { area_copy_dev<BS, NW>(f, split_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_split; }
+    }
+#endif
     if (must_split || j_split < j_none) return j_split;
     if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
     return j_none;

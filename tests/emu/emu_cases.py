@@ -18,6 +18,7 @@ oracle.build(); oracle.lib()
 PLANE_CASES = {
     'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0),
               (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: two row workers (K1 waits on the row above)
+    'rect': [(129, 101, 10, 4, 121, False, 0), (136, 72, 8, 4, 10, False, 0), (96, 64, 10, 4, 66, True, 0), (72, 72, 10, 1, 121, False, 0)],
     'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
              (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),
              (72, 136, 8, 8, 160, False, 2), (8, 8, 8, 4, 121, False, 0), (17, 9, 10, 4, 90, False, 0), (200, 120, 10, 2, 121, False, 0), (200, 120, 8, 3, 170, False, 0)],
@@ -32,6 +33,8 @@ for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
     ok_all &= ok
     print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d' % (w, h, bd, speed, q, int(mono), tiles), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
 
+if which == 'rect':
+    sys.exit(0 if ok_all else 1)
 # ravif level: RGBA with a used alpha channel, UnassociatedClean (dirty-alpha kernels + front end + colour and alpha frames + container)
 img = rgba_noisy()[:40, :56].copy()
 e = m.Encoder().with_quality(66).with_alpha_quality(88).with_speed(6).with_num_threads(1).with_alpha_color_mode('clean')

@@ -39,6 +39,17 @@ def test_emulated_kernels_do_not_depend_on_lane_order(emu_env):
     assert rows and not bad and p.returncode == 0, 'lane-order dependence: %s\n%s' % (bad, p.stderr[-2000:])
 
 
+def test_emulated_rect_partition_kernels_equal_rect_oracle(oracle):
+    """Groundwork (SURVEY 8 R-4 / R-6): with -DMI_RECT_PART=1 the kernels search and code PARTITION_HORZ / PARTITION_VERT of 8x8 nodes (dev_rect.h);
+    the emulated build must equal the oracle built with -DAV1O_RECT_PART=1 byte for byte.  Both switches are off in the product until a GPU check."""
+    from tests import emu
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'rect'])
+    env = dict(os.environ, MI_AVIF_LIB=emu.build(rect=True), MI_ORACLE_LIB=os.path.join(ROOT, 'oracle', '_build', 'liboracle_rect.so'))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'emu_cases.py'), ROOT, 'rect'], env=env, capture_output=True, text=True, timeout=900)
+    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert rows and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m
