@@ -109,7 +109,13 @@ int xlane(int kind, int val, int old, int p0, int rm, int bm, int bc, int site) 
 void wave_barrier() { yield_to_scheduler(W_WAVE); }
 void wg_barrier() { yield_to_scheduler(W_WG); }
 unsigned long long ticks() { return ++W.tick; }
-void spin_yield() { std::this_thread::yield(); }
+// A workgroup waiting for another one (the tile search's row workers).  The one it waits for runs on another OS thread of the pool; if it has not
+// moved after a very long time the pool is too small for the launch (MI_EMU_THREADS below the workers per tile) or the protocol is stuck.
+static thread_local unsigned long long spins = 0;
+void spin_yield() {
+  if (++spins > 400000000ull) { fprintf(stderr, "emu: block %u has been waiting for another workgroup for too long (MI_EMU_THREADS too small for this launch?)\n", blockIdx.x); abort(); }
+  std::this_thread::yield();
+}
 
 // source lane of a DPP control for `lane`, -1 when there is none (CDNA3 ISA 12.x "DPP")
 static int dpp_src(int ctrl, int lane) {
@@ -250,6 +256,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       // or silent corruption of a neighbouring workgroup's LDS)
       uint8_t *dyn[2] = { smem, k4_smem };
       if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) memset(dyn[q] + lds_bytes, 0xA5, 256);
+      spins = 0;
       run_block(w, (int)nthreads);
       if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) for (int i = 0; i < 256; i++) if (dyn[q][lds_bytes + i] != 0xA5) {
         fprintf(stderr, "emu: block %u wrote past its dynamic LDS allocation of %zu bytes (offset %zu)\n", blockIdx.x, lds_bytes, lds_bytes + (size_t)i); abort(); }
