@@ -12,6 +12,7 @@
 #include <future>
 #include <chrono>
 #include <exception>
+#include <algorithm>
 #include "host_av1.h"
 #include "png_reader.h"
 #include "tile_search.h"
@@ -195,6 +196,30 @@ template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const Fr
   hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(njobs * workers), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs, workers);
   return hipGetLastError();
 }
+#if MI_K1_QUEUE_KERNEL
+// The same search as a work queue (tile_search.h tile_search_queue_kernel): `items` = the launch's superblocks in dependency order.
+template <int MAXBS, int NW, bool BU> static hipError_t launch_search_queue_t(const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int grid, hipStream_t s) {
+  const size_t lds = k1_lds_bytes<MAXBS, NW>();
+  hipError_t e = hipFuncSetAttribute((const void *)tile_search_queue_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((tile_search_queue_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
+  return hipGetLastError();
+}
+static int k1_resident(int maxbs) { return (maxbs <= 2 ? MI_K1_WG_PER_CU : 1) * 256; }
+static size_t k1_snap_bytes(int maxbs) { return maxbs <= 2 ? MI_SNAP_BYTES_ALL(16) : (maxbs == 3 ? MI_SNAP_BYTES_ALL(32) : MI_SNAP_BYTES_ALL(64)); }
+static hipError_t launch_search_queue(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, hipStream_t s) {
+  if (nitems <= 0) return hipSuccess;
+  const int grid = std::min(nitems, k1_resident(maxbs));
+  if (bottomup) {
+    if (maxbs <= 2) return launch_search_queue_t<2, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+    if (maxbs == 3) return launch_search_queue_t<3, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+    return launch_search_queue_t<4, 1, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+  }
+  if (maxbs <= 2) return launch_search_queue_t<2, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+  if (maxbs == 3) return launch_search_queue_t<3, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+  return launch_search_queue_t<4, 1, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+}
+#endif
 // jobs must all belong to frames of the same block-size class
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
 static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, hipStream_t s) {
@@ -255,6 +280,9 @@ struct mi_batch {
   int *h_alpha = nullptr; FrameDev *h_frames = nullptr; TileJob *h_jobs = nullptr;   // pinned: alpha flags (D2H), frame descriptors and tile jobs (H2D sources)
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
   std::vector<TileJob> jobs;
+  // MI_K1_QUEUE=1: the tile search as a work queue -- the superblocks of each block-size class in dependency order, the claim counters, one snapshot area per
+  // persistent workgroup (allocated on first use)
+  std::vector<uint32_t> q_items; uint32_t *d_q_items = nullptr; size_t q_items_cap = 0; int *d_q_next = nullptr; uint8_t *d_q_snap = nullptr; size_t q_snap_bytes = 0;
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
   hipEvent_t ev[8]{}; double stage_ms[8]{};
   bool planned = false, in_flight = false;
@@ -287,6 +315,9 @@ static void batch_free_device(mi_batch *b) {
   if (b->d_precarry) (void)hipFree(b->d_precarry); b->d_precarry = nullptr;
   if (b->d_offsets) (void)hipFree(b->d_offsets); b->d_offsets = nullptr;
   if (b->d_prof) (void)hipFree(b->d_prof); b->d_prof = nullptr;
+  if (b->d_q_items) (void)hipFree(b->d_q_items); b->d_q_items = nullptr;
+  if (b->d_q_next) (void)hipFree(b->d_q_next); b->d_q_next = nullptr;
+  if (b->d_q_snap) (void)hipFree(b->d_q_snap); b->d_q_snap = nullptr;
   if (b->d_packed) (void)hipFree(b->d_packed); b->d_packed = nullptr;
   if (b->h_packed) (void)hipHostFree(b->h_packed); b->h_packed = nullptr;
   if (b->h_lens) (void)hipHostFree(b->h_lens); b->h_lens = nullptr;
@@ -510,6 +541,36 @@ int mi_batch_encode_async(mi_batch *b) {
   { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
     hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
   HIP_OK(hipEventRecord(b->ev[1], s));
+#if MI_K1_QUEUE_KERNEL
+  static const bool use_queue = [] { const char *v = getenv("MI_K1_QUEUE"); return v && atoi(v) > 0; }();
+  if (use_queue) {
+    // one item per superblock of every tile, per class in (2 * row + column, job) order; jobs are indexed inside their class segment of d_jobs
+    b->q_items.clear();
+    int q_begin[6] = { 0, 0, 0, 0, 0, 0 }; size_t snap_need = 0;
+    for (int cls = 2; cls <= 4; cls++) {
+      q_begin[cls] = (int)b->q_items.size();
+      std::vector<std::pair<uint32_t, uint32_t>> keyed;
+      for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
+        const TileJob &tj = b->jobs[j]; const FramePlan &p = b->frames[tj.frame];
+        const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
+        const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) keyed.push_back({ (uint32_t)(2 * r + c), MI_QITEM(j - class_begin[cls], r, c) });
+      }
+      std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c2) { return a.first < c2.first; });
+      for (auto &kv : keyed) b->q_items.push_back(kv.second);
+      if (!keyed.empty()) snap_need = std::max(snap_need, (size_t)std::min<int>((int)keyed.size(), k1_resident(cls)) * k1_snap_bytes(cls));
+    }
+    q_begin[5] = (int)b->q_items.size();
+    if (b->q_items.size() > b->q_items_cap) { if (b->d_q_items) (void)hipFree(b->d_q_items); b->q_items_cap = b->q_items.size(); HIP_OK(hipMalloc(&b->d_q_items, b->q_items_cap * 4)); }
+    if (!b->d_q_next) HIP_OK(hipMalloc(&b->d_q_next, 8 * sizeof(int)));
+    if (snap_need > b->q_snap_bytes) { if (b->d_q_snap) (void)hipFree(b->d_q_snap); b->q_snap_bytes = snap_need; HIP_OK(hipMalloc(&b->d_q_snap, snap_need)); }
+    HIP_OK(hipMemcpyAsync(b->d_q_items, b->q_items.data(), b->q_items.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync(b->d_q_next, 0, 8 * sizeof(int), s));
+    for (int cls = 2; cls <= 4; cls++)
+      HIP_OK(launch_search_queue(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], b->d_q_items + q_begin[cls], q_begin[cls + 1] - q_begin[cls],
+                                 b->d_q_next + cls, b->d_q_snap, s));
+  } else
+#endif
   for (int cls = 2; cls <= 4; cls++) {
     int max_workers = MI_K1_MAX_WORKERS;
     for (auto &p : b->frames) if (std::max(p.maxbs, 2) == cls) max_workers = std::min(max_workers, p.dev.snap_rows);

@@ -85,6 +85,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
   uint16_t split_rec[N <= 16 ? 1 : N * N];
   TileB tile; uint8_t *snap;                       // the tile's bounds (mi units) and its snapshot area (per-tile constants of Ctx)
+  int q_item;                                      // tile_search_queue_kernel: the work item the workgroup has just claimed
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -1320,3 +1321,71 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   if (gf->prof_out && threadIdx.x < 128) gf->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];
 #endif
 }
+
+// ---- K1 as a work queue (build with -DMI_K1_QUEUE_KERNEL=1, run with MI_K1_QUEUE=1; measured next round) ----
+// A compile-time option because a second kernel calling the partition walker stops the compiler from inlining the walker into tile_search_kernel,
+// which would change the code that was benchmarked.
+#ifndef MI_K1_QUEUE_KERNEL
+#define MI_K1_QUEUE_KERNEL 0
+#endif
+#if MI_K1_QUEUE_KERNEL
+// Persistent workgroups claim superblocks from one list per launch: item = (tile job, superblock row, superblock column inside the tile), sorted by
+// 2 * row + column (then by job), so everything an item waits for -- its left neighbour and the superblock two to the right in the row above -- sits
+// earlier in the list and has been claimed by a workgroup that is running or done: no deadlock, whatever the number of resident workgroups.  A row's
+// counter in f->sb_prog counts its finished superblocks (they finish in column order because each waits for its left neighbour).  Same decisions, same
+// bytes as one workgroup per tile; what changes is that no resident slot idles while its tile's neighbours are still at work.
+#define MI_QITEM(job, sbr, sbc) (((uint32_t)(job) << 12) | ((uint32_t)(sbr) << 6) | (uint32_t)(sbc))
+template <int MAXBS, int NW, bool BU>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_queue_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
+                                                                                                                const uint32_t *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
+  constexpr int MAXN = 4 << MAXBS;
+  extern __shared__ __align__(16) uint8_t smem[];
+  using K = Ctx<MAXN, NW>;
+  K k;
+  k.base = (LDS uint8_t *)smem;
+  k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);
+  LDS uint16_t *lsc = (LDS uint16_t *)(smem + K::LS_OFF);
+  LDS FrameDev *lf = (LDS FrameDev *)(smem + K::F_OFF);
+  if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
+  for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;
+  if (threadIdx.x == 0) k.sh()->snap = snap_pool + (size_t)blockIdx.x * MI_SNAP_BYTES_ALL(MAXN);
+  int cur_frame = -1, cur_job = -1;
+  for (;;) {
+    WG_SYNC();                                                             // everyone is done with the previous item (and has read q_item)
+    if (threadIdx.x == 0) k.sh()->q_item = atomicAdd(next_item, 1);
+    WG_SYNC();
+    const int it = k.sh()->q_item;
+    if (it >= nitems) break;
+    const uint32_t item = items[it];
+    const int job = (int)(item >> 12), sbr = (int)((item >> 6) & 63), sbc = (int)(item & 63);
+    const TileJob tj = jobs[job];
+    const FrameDev *gf = frames + tj.frame;
+    if (frame_idle(gf)) continue;
+    if (tj.frame != cur_frame) {                                           // the frame descriptor head and the coefficient slices of its rate table
+      for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];
+      load_coef_cost(k.cc_base(), gf->cost, MAXBS, threadIdx.x, 64 * NW);
+      cur_frame = tj.frame;
+    }
+    if (job != cur_job) {
+      if (threadIdx.x == 0) {
+        LDS TileB *t = &k.sh()->tile;
+        t->mi_row_start = gf->tile_row_start[tj.tile_row] * 16; t->mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, gf->mi_rows);
+        t->mi_col_start = gf->tile_col_start[tj.tile_col] * 16; t->mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, gf->mi_cols);
+      }
+      cur_job = job;
+    }
+    WG_SYNC();
+    const int row0 = k.t()->mi_row_start, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
+    const int ncols = (col1 - col0 + 15) >> 4, r = row0 + 16 * sbr, c = col0 + 16 * sbc;
+    int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;
+    if (threadIdx.x == 0) {
+      if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sbc) __builtin_amdgcn_s_sleep(8);
+      if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8); }
+    }
+    WG_SYNC();
+    if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
+    WG_SYNC();
+    if (threadIdx.x == 0) __hip_atomic_store(prog, sbc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#endif  // MI_K1_QUEUE_KERNEL

@@ -22,7 +22,7 @@ PLANE_CASES = {
     'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
              (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),
              (72, 136, 8, 8, 160, False, 2), (8, 8, 8, 4, 121, False, 0), (17, 9, 10, 4, 90, False, 0), (200, 120, 10, 2, 121, False, 0), (200, 120, 8, 3, 170, False, 0)],
-}[which]
+}.get(which, [])
 ok_all = True
 for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
     pl = planes(h, w, seed=w + h, bd=bd, mono=mono)
@@ -34,6 +34,20 @@ for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
     print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d' % (w, h, bd, speed, q, int(mono), tiles), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
 
 if which == 'rect':
+    sys.exit(0 if ok_all else 1)
+if which == 'queue':                               # batch API: several images, colour + alpha frames, bottom-up order (MI_K1_QUEUE=1 in the environment)
+    from cavif_rs_amd.synth import synth_image
+    ok_all = True
+    for (w, h, speed, q, depth, alpha, nimg) in [(200, 136, 4, 80.0, 10, False, 3), (136, 100, 4, 60.0, 8, True, 2), (136, 136, 1, 80.0, 10, False, 1)]:
+        e = m.Encoder().with_quality(q).with_alpha_quality(90.0).with_speed(speed).with_bit_depth(depth)
+        imgs = [synth_image(w, h, index=i, alpha=alpha) for i in range(nimg)]
+        b = m.BatchEncoder(e, nimg, w, h, 4 if alpha else 3)
+        for i, im in enumerate(imgs): b.upload(i, im)
+        t = time.time(); b.encode()
+        ok = all(b.get(i).avif_file == oracle.ravif_encode(im, quality=q, alpha_quality=90.0, speed=speed, depth=depth)[0] for i, im in enumerate(imgs))
+        ok_all &= ok
+        print(json.dumps({'case': 'queue batch %dx%d s%d n%d alpha%d' % (w, h, speed, nimg, int(alpha)), 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
+        b.close()
     sys.exit(0 if ok_all else 1)
 # ravif level: RGBA with a used alpha channel, UnassociatedClean (dirty-alpha kernels + front end + colour and alpha frames + container)
 img = rgba_noisy()[:40, :56].copy()

@@ -50,6 +50,16 @@ def test_emulated_rect_partition_kernels_equal_rect_oracle(oracle):
     assert rows and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
+def test_emulated_k1_work_queue_equals_oracle(oracle):
+    """Groundwork: the tile search as a work queue of superblocks (-DMI_K1_QUEUE_KERNEL=1, MI_K1_QUEUE=1) makes the same decisions:
+    batches of colour and colour + alpha images, top-down and bottom-up, equal the oracle byte for byte under the emulator's thread pool."""
+    from tests import emu
+    env = dict(os.environ, MI_AVIF_LIB=emu.build(queue=True), MI_K1_QUEUE='1')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'emu_cases.py'), ROOT, 'queue'], env=env, capture_output=True, text=True, timeout=1200)
+    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(rows) == 3 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m
