@@ -9,13 +9,29 @@
 #include "dev_rate.h"
 #include "restoration.h"
 
+// MI_K4_PIPE (build option, measured next round -- DESIGN.md section 9): two wavefronts per tile.  Wave 1 walks the tile exactly as the single
+// wave does -- contexts, CDF rows, adaptation -- but instead of range-coding a symbol it appends its bounds to a ring in LDS; wave 0 pops the records
+// and does nothing but the range arithmetic and the byte output.  Record: bit 31 = literal (value in 0..19, bit count in 20..24), else fl >> 6 in 0..9
+// (512 = the top of the range), fh >> 6 in 10..19, the symbol in 20..23, nsyms - 1 in 24..27.  The producer publishes `head` after every block
+// header / transform block; LDS executes one wave's operations in order, so a consumer that sees head = h finds the records below h written.
+#ifndef MI_K4_PIPE
+#define MI_K4_PIPE 0
+#endif
+#define MI_K4_RING 2048
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
   uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
+#if MI_K4_PIPE
+  LDS uint32_t *ring; LDS volatile uint32_t *ctl;      // ctl[0] = head (producer), ctl[1] = tail (consumer), ctl[2] = done
+  uint32_t h, tail_seen;                                // producer: records written / the consumer's tail as last read
+#endif
 };
 
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
   e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9;
+#if MI_K4_PIPE
+  e->h = 0; e->tail_seen = 0;
+#endif
 }
 __device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) {
   if (e->offs < e->cap && LANE == 0) e->pre[e->offs] = v;   // offs counts every unit, stored or not: overflow <=> offs > cap at the end (re_finish_dev)
@@ -35,8 +51,36 @@ __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, u
   }
   e->low = low << d; e->rng = rng << d; e->cnt = s;
 }
+#if MI_K4_PIPE
+__device__ __forceinline__ void pipe_publish(RangeEncDev *e) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (LANE == 0) e->ctl[0] = e->h;
+}
+__device__ __forceinline__ void pipe_emit(RangeEncDev *e, uint32_t rec) {
+  if (e->h - e->tail_seen >= MI_K4_RING) {                       // wave-uniform: the ring looks full -- publish, then wait for the consumer
+    pipe_publish(e);
+    for (;;) {
+      const uint32_t t = (uint32_t)uni32((int)e->ctl[1]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      e->tail_seen = t;
+      if (e->h - t < MI_K4_RING) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  if (LANE == 0) e->ring[e->h & (MI_K4_RING - 1)] = rec;
+  e->h++;
+}
+__device__ __forceinline__ void re_encode_core(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms);
+// producer side: the symbol's bounds go to the ring
+__device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
+  pipe_emit(e, (fl >> 6) | ((fh >> 6) << 10) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24));
+}
+__device__ __forceinline__ void re_encode_core(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
+  uint32_t l = e->low; uint32_t r = e->rng;
+#else
 __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
   uint32_t l = e->low; uint32_t r = e->rng;
+#endif
   const int N = nsyms - 1;
   if (fl < 32768) {
     const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4 * (uint32_t)(N - (s - 1));
@@ -70,8 +114,43 @@ __device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit_in, uint32_t
 }
 __device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, int nbits_in) {
   const uint32_t v = (uint32_t)uni32((int)v_in); const int nbits = uni32(nbits_in);
+#if MI_K4_PIPE
+  if (nbits > 0) pipe_emit(e, 0x80000000u | (v & 0xFFFFFu) | ((uint32_t)nbits << 20));
+#else
   for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
+#endif
 }
+#if MI_K4_PIPE
+// consumer side (wave 0): pops records until the producer is done, 64 at a time into a register
+__device__ __forceinline__ void pipe_consume(RangeEncDev *e) {
+  uint32_t t = 0;
+  for (;;) {
+    uint32_t h = (uint32_t)uni32((int)e->ctl[0]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (h == t) {
+      if (uni32((int)e->ctl[2])) { h = (uint32_t)uni32((int)e->ctl[0]); if (h == t) break; }
+      else { __builtin_amdgcn_s_sleep(4); continue; }
+    }
+    while (t != h) {
+      const uint32_t chunk = (h - t) < 64u ? (h - t) : 64u;
+      const uint32_t v = e->ring[(t + (uint32_t)LANE) & (MI_K4_RING - 1)];
+      for (uint32_t j = 0; j < chunk; j++) {
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j);
+        if (rec & 0x80000000u) {
+          const uint32_t val = rec & 0xFFFFFu; const int nbits = (int)((rec >> 20) & 31);
+          for (int i = nbits - 1; i >= 0; i--) { const int bit = (int)((val >> i) & 1); re_encode_core(e, bit ? 16384u : 32768u, bit ? 0u : 16384u, bit, 2); }
+        } else {
+          const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u;
+          re_encode_core(e, fl6 << 6, fh6 << 6, (int)((rec >> 20) & 15), (int)((rec >> 24) & 15) + 1);
+        }
+      }
+      t += chunk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (LANE == 0) e->ctl[1] = t;
+    }
+  }
+}
+#endif
 // returns number of bytes; out must hold them.  (lane 0)
 __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
   unsigned long long l = e->low; int c = e->cnt; int s = 10;
@@ -275,6 +354,9 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   K4PH(1); K4CNT(8, 1);
+#if MI_K4_PIPE
+  pipe_publish(&w->ec);
+#endif
   if (skip) return;                                    // wave-uniform
   // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
   for (int p = 0; p < w->np; p++) {
@@ -303,6 +385,9 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
       txb_ctx_dev(f, t, p, rr, cc, txs, BS, &sctx2, &dctx);
       K4PH(2);
       code_coeffs_lane0(w, eob, p, txs, txtype, sctx2, dctx, off, sym, ns);
+#if MI_K4_PIPE
+      pipe_publish(&w->ec);
+#endif
     }
   }
   WAVE_SYNC();
@@ -496,10 +581,13 @@ template <int CS> struct EntropyLds {
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
   uint16_t lr_cdf[4]; int lr_ref[6];
+#if MI_K4_PIPE
+  uint32_t ring[MI_K4_RING]; uint32_t ctl[4];
+#endif
 };
 
 template <int MAXBS>
-__global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
+__global__ __launch_bounds__(MI_K4_PIPE ? 128 : 64) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
   constexpr int CS = MAXBS <= 2 ? 16 : 32;
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
   EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
@@ -524,6 +612,20 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__rest
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
+#if MI_K4_PIPE
+  w.ec.ring = (LDS uint32_t *)L.ring; w.ec.ctl = (LDS volatile uint32_t *)L.ctl;
+  if (threadIdx.x < 4) L.ctl[threadIdx.x] = 0;
+  __syncthreads();                                             // ring control words and (below, producer only) the tile's tables
+  const int pipe_wave = (int)(threadIdx.x >> 6);
+  if (pipe_wave == 0) {                                         // consumer: range arithmetic + byte output only
+    pipe_consume(&w.ec);
+    if (LANE == 0) {
+      uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
+      f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
+    }
+    return;
+  }
+#endif
 #if MI_PROFILE == 2
   for (int i = 0; i < 16; i++) w.prof[i] = 0;
   w.pt = clock64();
@@ -534,6 +636,12 @@ __global__ __launch_bounds__(64) void tile_entropy_kernel(const FrameDev *__rest
     for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
       write_superblock<MAXBS>(&w, r, c);
   WAVE_SYNC();
+#if MI_K4_PIPE
+  pipe_publish(&w.ec);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (LANE == 0) L.ctl[2] = 1;
+  return;
+#endif
   if (LANE == 0) {
     const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
     (void)ti;

@@ -59,7 +59,7 @@ emu_switch:
 )");
 
 namespace emu {
-enum Wait { W_RUN = 0, W_XLANE, W_WAVE, W_WG, W_DONE };
+enum Wait { W_RUN = 0, W_XLANE, W_WAVE, W_WG, W_DONE, W_SLEEP };
 struct XArgs { int kind, val, old, p0, rm, bm, bc, site; };
 struct Fiber { void *sp; uint8_t *stack; int wait; XArgs x; int out; };
 static const size_t STACK_BYTES = 1 << 20;   // untouched pages stay uncommitted
@@ -113,6 +113,8 @@ unsigned long long ticks() { return ++W.tick; }
 // moved after a very long time the pool is too small for the launch (MI_EMU_THREADS below the workers per tile) or the protocol is stuck.
 static thread_local unsigned long long spins = 0;
 void spin_yield() {
+  // inside a workgroup the lane steps aside so that the other wavefronts of its own workgroup can run too (a wave polling an LDS flag another wave sets)
+  if (W.cur >= 0 && W.nthreads > 64) yield_to_scheduler(W_SLEEP);
   if (++spins > 400000000ull) { fprintf(stderr, "emu: block %u has been waiting for another workgroup for too long (MI_EMU_THREADS too small for this launch?)\n", blockIdx.x); abort(); }
   std::this_thread::yield();
 }
@@ -185,6 +187,7 @@ static void run_block(Worker &w, int nthreads) {
     for (int wi = 0; wi < nwaves; wi++) {
       const int wv = reverse_lanes ? nwaves - 1 - wi : wi;
       const int base = wv * 64, n = nthreads - base < 64 ? nthreads - base : 64;
+      for (int l = 0; l < n; l++) if (w.fib[base + l].wait == W_SLEEP) w.fib[base + l].wait = W_RUN;
       for (int li = 0; li < n; li++) {              // every runnable lane goes on to its next meeting point
         const int l = reverse_lanes ? n - 1 - li : li;   // MI_EMU_REVERSE=1: a kernel whose result depends on the order in which the lanes of a
         Fiber &f = w.fib[base + l];                      // wavefront pass between two meeting points has an unsynchronised exchange

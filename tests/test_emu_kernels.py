@@ -60,6 +60,15 @@ def test_emulated_k1_work_queue_equals_oracle(oracle):
     assert len(rows) == 3 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
+def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
+    """Groundwork: -DMI_K4_PIPE=1 splits the entropy coder of a tile into a walker wave (contexts, CDF adaptation, symbol bounds into an
+    LDS ring) and a range-coder wave; the bytes must not change.  The emulator runs the two waves as fibers that yield to each other while they poll."""
+    from tests import emu
+    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=True)), 'quick', 900)
+    bad = [r['case'] for r in rows if not r['ok']]
+    assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m
