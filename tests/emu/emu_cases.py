@@ -18,7 +18,7 @@ oracle.build(); oracle.lib()
 PLANE_CASES = {
     'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0),
               (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: two row workers (K1 waits on the row above)
-    'rect': [(129, 101, 10, 4, 121, False, 0), (136, 72, 8, 4, 10, False, 0), (96, 64, 10, 4, 66, True, 0), (72, 72, 10, 1, 121, False, 0)],
+    'rect': [(129, 101, 10, 4, 121, False, 0), (136, 72, 8, 4, 10, False, 0), (96, 64, 10, 4, 66, True, 0), (72, 40, 10, 1, 121, False, 0)],
     'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
              (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),
              (72, 136, 8, 8, 160, False, 2), (8, 8, 8, 4, 121, False, 0), (17, 9, 10, 4, 90, False, 0), (200, 120, 10, 2, 121, False, 0), (200, 120, 8, 3, 170, False, 0)],
@@ -38,7 +38,7 @@ if which == 'rect':
 if which == 'queue':                               # batch API: several images, colour + alpha frames, bottom-up order (MI_K1_QUEUE=1 in the environment)
     from cavif_rs_amd.synth import synth_image
     ok_all = True
-    for (w, h, speed, q, depth, alpha, nimg) in [(200, 136, 4, 80.0, 10, False, 3), (136, 100, 4, 60.0, 8, True, 2), (136, 136, 1, 80.0, 10, False, 1)]:
+    for (w, h, speed, q, depth, alpha, nimg) in [(200, 136, 4, 80.0, 10, False, 3), (136, 100, 4, 60.0, 8, True, 2), (72, 72, 2, 80.0, 10, False, 1)]:
         e = m.Encoder().with_quality(q).with_alpha_quality(90.0).with_speed(speed).with_bit_depth(depth)
         imgs = [synth_image(w, h, index=i, alpha=alpha) for i in range(nimg)]
         b = m.BatchEncoder(e, nimg, w, h, 4 if alpha else 3)
