@@ -420,10 +420,14 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = rect_tx_cdf(f, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  // the surviving modes are predicted once (candidate ci by wave ci % NW) into the prediction cache and shared by their tx-type trials
+  LDS uint16_t *pcache = MAXN <= 16 ? (LDS uint16_t *)SH->lpred : (LDS uint16_t *)SH->split_rec;      // [7][NN]; both are free until the tx-size trial
+  for (int ci = W; ci < ncand; ci += NW) predict_block_wh(f, x, y, WL, HL, availL, availU, SH->order[ci], 0, ftype_y, ra, rl, wa, wl, S->etmp, pcache + ci * NN);
+  WG_SYNC();
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 }; uint32_t my_mrate = 0;
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
-    predict_block_wh(f, x, y, WL, HL, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
+    const LDS uint16_t *cpred = pcache + ci * NN;
     const uint32_t mode_rate = ycost[m];
     int ns2, set2;
     const int tx_off = rect_tx_cdf(f, m, &ns2, &set2);
@@ -431,7 +435,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
     TxRes tr;
-    long long j = eval_rect<MAXN, WL, HL, NW>(k, 0, sctx_y, dctx_y, SH->srcb[0], S->pred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr, psv_a, psv_b, act);
+    long long j = eval_rect<MAXN, WL, HL, NW>(k, 0, sctx_y, dctx_y, SH->srcb[0], cpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr, psv_a, psv_b, act);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
   }
