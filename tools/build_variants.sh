@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds the prepared kernel variants next to the product library (git-ignored *.so, they travel with gpurun):
+#   libmi_queue.so  -DMI_K1_QUEUE_KERNEL=1   tile search as a work queue (run with MI_K1_QUEUE=1)
+#   libmi_pipe.so   -DMI_K4_PIPE=1           entropy coder as a walker wave + a range-coder wave per tile
+#   libmi_rect.so   -DMI_RECT_PART=1         rectangular partitions of 8x8 nodes (check against oracle/_build/liboracle_rect.so)
+set -e
+cd "$(dirname "$0")/.."
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-variable"
+hipcc $F -DMI_K1_QUEUE_KERNEL=1 -o cavif_rs_amd/libmi_queue.so cavif_rs_amd/csrc/mi_avif.hip -lz &
+hipcc $F -DMI_K4_PIPE=1 -o cavif_rs_amd/libmi_pipe.so cavif_rs_amd/csrc/mi_avif.hip -lz &
+hipcc $F -DMI_RECT_PART=1 -o cavif_rs_amd/libmi_rect.so cavif_rs_amd/csrc/mi_avif.hip -lz &
+wait
+make -s -C oracle rect
+ls -la cavif_rs_amd/libmi_*.so oracle/_build/

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU call: parity quick check and single-slot / three-slot bench of the product library and the prepared variants (tools/build_variants.sh first).
+# Prints per variant: MPix/s, tile search ms, entropy ms, output identity.
+L=$PWD/cavif_rs_amd
+line() { python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); st=d['stage_ms_per_step']
+print('$1', d['value'], 'K1', st['tile_search'], 'K4', st['entropy'], 'identity', d['output_identity'])"; }
+for P in 1 3; do
+  python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop 2>&1 | tail -1 | line "default/slots$P"
+  MI_K1_QUEUE=1 MI_AVIF_LIB=$L/libmi_queue.so python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop 2>&1 | tail -1 | line "queue/slots$P"
+  MI_AVIF_LIB=$L/libmi_pipe.so python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop 2>&1 | tail -1 | line "pipe/slots$P"
+done
+for V in queue pipe; do MI_K1_QUEUE=1 MI_AVIF_LIB=$L/libmi_$V.so python tools/gpu_quickcheck.py 2>&1 | tail -8 | grep -c "bytes_equal=True recon_equal=True" | sed "s/^/$V quickcheck ok cases: /"; done
+MI_ORACLE_LIB=$PWD/oracle/_build/liboracle_rect.so MI_AVIF_LIB=$L/libmi_rect.so python tools/gpu_quickcheck.py 2>&1 | tail -8 | grep -c "bytes_equal=True recon_equal=True" | sed "s/^/rect quickcheck ok cases: /"
+MI_AVIF_LIB=$L/libmi_rect.so python bench.py --steps 3 --warmup 1 --pipeline 1 --no-cpu-baseline --no-pcie-loop --no-identity-check 2>&1 | tail -1 | line "rect/slots1 (identity not checked: the bench compares with the default oracle)"
