@@ -5,7 +5,7 @@ L=$PWD/cavif_rs_amd
 line() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); st=d['stage_ms_per_step']
-print('$1', d['value'], 'K1', st['tile_search'], 'K4', st['entropy'], 'identity', d['output_identity'])"; }
+print('$1', d['value'], 'K1', st['tile_search'], 'K4', st['entropy'], 'identity', d.get('output_identity'))"; }
 for P in 1 3; do
   python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop 2>&1 | tail -1 | line "default/slots$P"
   MI_K1_QUEUE=1 MI_AVIF_LIB=$L/libmi_queue.so python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop 2>&1 | tail -1 | line "queue/slots$P"
