@@ -48,8 +48,26 @@
 #define PH(i) do {} while (0)
 #endif
 
-template <int N> struct WaveScratch {            // private to one wavefront
-  static constexpr int CS = N < 32 ? N : 32;
+// -DMI_K1_LDS_DIET=1 (prepared variant, not the default build): the <2,4> kernel in 32 464 B of LDS instead of 40 912 -- a fifth workgroup
+// per CU, or two entropy-coder workgroups beside four searches.  What changes: ONE reconstruction / level buffer per wave (a wave's best
+// candidate so far is parked in the tile's HBM scratch instead of a second LDS buffer), the edge working copies alias the transposition
+// buffer (both are transient inside predict / evaluate), the DC prediction of the one-candidate chroma path is built in `pred`, the level
+// maps live inside the one-candidate struct (re-zeroed at the start of each one-candidate phase, the grouped path dirties them), and the
+// tx-size trial's sub-sources use wave 1's idle `pred`.  Same arithmetic, same decisions.
+#ifndef MI_K1_LDS_DIET
+#define MI_K1_LDS_DIET 0
+#endif
+#define MI_K1_DIET_N(N) (MI_K1_LDS_DIET != 0 && (N) == 16)
+#define MI_K1_PARK_WAVE 1536                       /* parked best of one wave: rec [256] u16 + qc [256] i32 */
+#define MI_K1_PARK_BYTES(N) (MI_K1_DIET_N(N) ? 4 * MI_K1_PARK_WAVE : 0)
+
+// area snapshots of the partition search + (LDS diet) the parked candidates, per (tile, row worker) in HBM
+#define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
+#define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
+#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0) + MI_K1_PARK_BYTES(n))   /* + the 8x8 node's best rectangular / split candidates */
+
+template <int N, bool DIET = MI_K1_DIET_N(N)> struct WaveScratch {            // private to one wavefront
+  static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N;
   uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
   uint16_t pred[N * N], dcp[N * N];
   union {                                          // one candidate at a time (all sizes) or four at a time (4x4 / 8x8, dev_group.h)
@@ -61,6 +79,20 @@ template <int N> struct WaveScratch {            // private to one wavefront
     GroupPredBuf gpred[4];                         // four directional predictions at a time (SATD stages of 4x4 / 8x8 blocks)
   };
   uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
+};
+template <int N> struct WaveScratch<N, true> {
+  static constexpr int CS = N, NBUF = 1, DCP_LEN = 192;
+  uint16_t pred[N * N];
+  union {
+    struct {                                       // one candidate (16x16 blocks; the chroma path with the full mode set)
+      union { int32_t tbuf[N * (N + 1)]; struct { uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16]; }; };
+      int32_t cbuf[CS * CS], qc[1][CS * CS];
+      uint16_t rec[1][N * N];
+      uint8_t lev[LEV_BYTES(CS)];
+    };
+    struct { GroupBuf8 grp[4]; uint16_t dcp[192]; };   // four candidates (4x4 / 8x8); dcp = a plane's DC prediction / the parked best of a round
+    GroupPredBuf gpred[4];
+  };
 };
 template <int N> struct SharedScratch {          // shared by the waves of the tile
   uint16_t ra[3][EDGE_LEN(N)], rl[3][EDGE_LEN(N)];
@@ -80,7 +112,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
   // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
   int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
-  uint16_t ssrc[N * N], spred[(N / 2) * (N / 2)];
+  uint16_t ssrc[MI_K1_DIET_N(N) ? 4 : N * N], spred[(N / 2) * (N / 2)];
   uint8_t nb_top[16][2], nb_left[16][2];
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
   uint16_t split_rec[N <= 16 ? 1 : N * N];
@@ -248,8 +280,8 @@ __device__ inline long long eval_tx(const Ctx<MAXN, NW> k, int plane, int sctx, 
 }
 
 // one wave writes a plane's result back to the frame buffers
-template <int BS>
-__device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
+template <int BS, typename RecPtr, typename QcPtr>
+__device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int c, RecPtr rec, QcPtr qc, int eob, int cul, int dcc) {
   constexpr int n = 4 << BS, CS = n < 32 ? n : 32, n4 = 1 << BS;
   uint16_t *gr = f->rec[plane] + (size_t)(r * 4) * f->stride + c * 4;
   int32_t *gc = f->coef[plane] + (size_t)(r * 4) * f->stride + c * 4;
@@ -258,6 +290,24 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
   fill_map_dev(f->m_lvl[plane], f->mi_stride, r, c, n4, cul);
   fill_map_dev(f->m_dc[plane], f->mi_stride, r, c, n4, dcc);
   if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
+}
+
+// LDS diet: a wave's best candidate so far lives in the tile's HBM scratch (written when a candidate takes the lead, read once by the
+// winning wave at commit; a wave reads back only what it wrote itself, program order suffices).  8-byte units: rec = 64, qc = 128.
+template <int MAXN, int NW> __device__ __forceinline__ uint8_t *park_of(const Ctx<MAXN, NW> k, int W) {
+  return k.snap() + MI_SNAP_BYTES_ALL(MAXN) - MI_K1_PARK_BYTES(MAXN) + W * MI_K1_PARK_WAVE;
+}
+template <int NN, int QN> __device__ __forceinline__ void park_store(uint8_t *park, const LDS uint16_t *rec, const LDS int32_t *qc) {
+  unsigned long long *pr = (unsigned long long *)park, *pq = (unsigned long long *)(park + 512);
+  const LDS unsigned long long *lr = (const LDS unsigned long long *)rec, *lq = (const LDS unsigned long long *)qc;
+  WAVE_SYNC();                                               // a lane copies samples other lanes wrote ...
+  for (int i = LANE; i < NN / 4; i += 64) pr[i] = lr[i];
+  for (int i = LANE; i < QN / 2; i += 64) pq[i] = lq[i];
+  WAVE_SYNC();                                               // ... and the next evaluation overwrites them
+}
+template <typename WS> __device__ __forceinline__ void zero_lev(LDS WS *S) {
+  for (int i = LANE; i < (int)sizeof(S->lev) / 4; i += 64) ((LDS uint32_t *)S->lev)[i] = 0;
+  WAVE_SYNC();
 }
 
 #include "dev_rect.h"
@@ -292,6 +342,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);                                           // DC_PRED (no neighbour) is not smooth
   const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uni32(v_uvU))) || (availL && IS_SMOOTH_(uni32(v_uvL))));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
+  constexpr bool DIET = MI_K1_DIET_N(MAXN);
   PH_BEGIN();
 
   // ---- stage the source block and the raw edges of every plane (plane p by wave p % NW) ----
@@ -497,6 +548,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       }
     }
   }
+  if constexpr (DIET) if (!grouped) zero_lev(S);
   if (!grouped)
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
@@ -520,7 +572,10 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     TxRes tr;
     long long j = eval_tx<MAXN, BS, NW>(k, 0, sctx_y, dctx_y, lpred, txtype, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, S->rec[cur], S->qc[cur], &tr);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
-    if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
+    if (j < my_j) {
+      my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate;
+      if constexpr (DIET) park_store<nn, qn>(park_of(k, W), S->rec[0], S->qc[0]); else cur ^= 1;
+    }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
   PH(6);
@@ -529,6 +584,34 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   int win = 0;
   for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
   const long long best_j = SH->wbest_j[win];
+#if MI_K1_LDS_DIET                                          // same steps; the best of a 16x16 block comes back from the HBM park
+  if (W == win) {
+    auto commit = [&](auto best_rec, auto best_qc) {
+      commit_plane<BS>(f, 0, r, c, best_rec, best_qc, my_tr.eob, my_tr.cul, my_tr.dcc);
+      fill_map_dev(f->m_ymode, ms, r, c, n4, my_mode);
+      fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
+      fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
+      fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
+      fill_map_dev(f->m_txsize, ms, r, c, n4, BS);
+      if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
+      if (LANE == 0) {
+        SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob;
+        SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
+      }
+    };
+    bool done = false;
+    if constexpr (DIET) if (!grouped) { const uint8_t *pk = park_of(k, W); commit((const uint16_t *)pk, (const int32_t *)(pk + 512)); done = true; }
+    if (!done) {
+      const int b = DIET ? 0 : cur ^ 1;                       // buffer holding this wave's best
+      const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
+      if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) {
+        if (parked) { best_rec = (const LDS uint16_t *)S->dcp; best_qc = (const LDS int32_t *)(S->dcp + 64); }
+        else { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
+      }
+      commit(best_rec, best_qc);
+    }
+  }
+#else
   if (W == win) {
     const int b = cur ^ 1;                                  // buffer holding this wave's best
     const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
@@ -548,6 +631,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
     }
   }
+#endif
   PH(7);
   WG_SYNC();
   PH(2);
@@ -573,6 +657,8 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       // size found so far (depth 0 was committed above; a winning depth replaces it), so a deeper trial needs no snapshot.
       LDS int *const sub_tx = (LDS int *)SH->dsd, *const sub_eob = sub_tx + 16, *const sub_cul = sub_tx + 32, *const sub_dcc = sub_tx + 48, *const psv16 = sub_tx + 64;   // dsd / satd are dead after the mode decision
       LDS int *const sfl_r = (LDS int *)SH->satd, *const sfl_b = sfl_r + 4;
+      LDS uint16_t *ssrc = (LDS uint16_t *)SH->ssrc;         // the sub-sources, sub-block after sub-block
+      if constexpr (DIET) ssrc = ((LDS WaveScratch<MAXN> *)(k.base + Ctx<MAXN, NW>::SH_BYTES + Ctx<MAXN, NW>::WS_BYTES))->pred;   // wave 1's pred: idle during the trial (only wave 0 predicts)
       auto trial = [&](auto depth_c) -> bool {
         constexpr int D = decltype(depth_c)::value;
         constexpr int SBS = BS - D, G = 1 << D, hn = n >> D, half = n4 >> D, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
@@ -585,7 +671,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
         // and the decoded flags of the cells right of / below the block that a sub-block's above-right / below-left edge may reach
         for (int q = W; q < G * G; q += NW) {
           const int so = (q / G) * hn * n + (q % G) * hn;
-          for (int idx = LANE; idx < hnn; idx += 64) SH->ssrc[q * hnn + idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
+          for (int idx = LANE; idx < hnn; idx += 64) ssrc[q * hnn + idx] = SH->srcb[0][so + (idx / hn) * n + (idx % hn)];
         }
         if (W == 0) {
           if (LANE < n4) {
@@ -680,7 +766,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
               if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
               else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
               GroupRes gr;
-              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
+              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
                              f->tune_psnr ? -1 : psv_q, pact_q, &gr);
               long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
               if (!live) j = J_INF;
@@ -702,7 +788,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
               else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
               TxRes tr;
               const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
-                                                     SH->ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
+                                                     ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
               if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
             }
           }
@@ -712,7 +798,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
           const long long sub_j = SH->wbest_j[sw];
           if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
-            const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
+            const LDS uint16_t *srec = S->rec[DIET ? 0 : scur ^ 1]; const LDS int32_t *sqc = S->qc[DIET ? 0 : scur ^ 1];
             if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
             const int ro = bi * hn * n + bj * hn;
             for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
@@ -892,6 +978,12 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     if (cfl_allowed) push(UV_CFL_PRED);
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
     constexpr int NPAIR = 2;
+#if MI_K1_LDS_DIET
+    LDS uint16_t *dcb = S->dcp;                              // the plane's DC prediction (CfL)
+    if constexpr (DIET) { dcb = S->pred; zero_lev(S); }      // LDS diet: built in place in `pred`; the grouped evaluations before have used the level maps' memory
+#else
+#define dcb S->dcp
+#endif
     const int pair = ((W >> 1) & 1) ^ 1, active = W < 4;      // pair 0 (two plain candidates) = waves 2, 3: they have the lighter luma share
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
     // pair 0: candidates 0 and the odd ones; pair 1: the even ones from 2 on and CfL (always last) -- the winner rule
@@ -924,11 +1016,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
           lsum = wave_sum_i32(lsum);
           const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
-          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
+          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, dcb);
           long long best_sse = J_INF; int best_idx = 1 << 20;
           if (half == 0) {
             int e0 = 0;
-            for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
+            for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)dcb[idx]; e0 += __mul24(d, d); }
             best_sse = wave_sum_i64((long long)e0); best_idx = -1;
           }
           // scan position aa = 2k is alpha +(k+1), aa = 2k+1 is -(k+1); the scaled luma term of -a is minus that of +a,
@@ -937,7 +1029,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
 #pragma unroll
           for (int a = 0; a < 16; a++) e[a] = 0;
           for (int idx = LANE; idx < nn; idx += 64) {
-            const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
+            const int l = ((int)luma[idx] << 3) - avg, dcv = dcb[idx], sv = SH->srcb[p][idx];
             const int la = iabs_(l), neg = l < 0;
 #pragma unroll
             for (int kq = 0; kq < 8; kq++) {
@@ -977,7 +1069,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
           if (um == UV_CFL_PRED) {
             const int al = p == 1 ? alpha_u : alpha_v;
-            predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->dcp);
+            predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, dcb);
             if (al) {
               // predict_cfl against the LDS copy of the luma reconstruction
               int lsum = 0;
@@ -986,9 +1078,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
               const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
               for (int idx = LANE; idx < nn; idx += 64) {
                 const int l = ((int)SH->luma_rec[idx] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-                S->pred[idx] = (uint16_t)iclamp_((int)S->dcp[idx] + sc, 0, mx);
+                S->pred[idx] = (uint16_t)iclamp_((int)dcb[idx] + sc, 0, mx);
               }
-            } else { for (int i = LANE; i < nn; i += 64) S->pred[i] = S->dcp[i]; }
+            } else if constexpr (!DIET) { for (int i = LANE; i < nn; i += 64) S->pred[i] = dcb[i]; }
             WAVE_SYNC();
           } else {
             predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
@@ -1003,7 +1095,10 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       PH(2);
       if (valid && ok) {
         const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
-        if (j < pb_j) { pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp; ccur ^= 1; }
+        if (j < pb_j) {
+          pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp;
+          if constexpr (DIET) park_store<nn, qn>(park_of(k, W), S->rec[0], S->qc[0]); else ccur ^= 1;
+        }
       }
     }
     if (LANE == 0 && (W & 1) == 0 && W < 4) { SH->pbest_j[pair] = pb_j; SH->pbest_c[pair] = pb_c; }
@@ -1013,8 +1108,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     if ((SH->pbest_j[1] < SH->pbest_j[0] || (SH->pbest_j[1] == SH->pbest_j[0] && SH->pbest_c[1] < SH->pbest_c[0]))) wp = 1;
     const long long best_uv = SH->pbest_j[wp];
     if (active && pair == wp) {
-      const int p = (W & 1) + 1, b = ccur ^ 1;
-      commit_plane<BS>(f, p, r, c, S->rec[b], S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
+      const int p = (W & 1) + 1, b = DIET ? 0 : ccur ^ 1;
+      if constexpr (DIET) { const uint8_t *pk = park_of(k, W); commit_plane<BS>(f, p, r, c, (const uint16_t *)pk, (const int32_t *)(pk + 512), pb_tr.eob, pb_tr.cul, pb_tr.dcc); }
+      else commit_plane<BS>(f, p, r, c, (const LDS uint16_t *)S->rec[b], (const LDS int32_t *)S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
       if (LANE == 0) SH->ceob[p - 1] = pb_tr.eob;
       if (p == 1) {
         const int buv = lut4(cand_pack, pb_c);
@@ -1032,6 +1128,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     total_j += best_uv;
     (void)qn;
   }
+#if !MI_K1_LDS_DIET
+#undef dcb
+#endif
   if (DBG_IS(f, 6)) return 0;
   // ---- skip flag ----
   const int skip = !any_coef;
@@ -1083,9 +1182,6 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
     }
   WG_SYNC();
 }
-#define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
-#define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
-#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0))   /* + the 8x8 node's best rectangular / split candidates */
 
 __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
@@ -1254,6 +1350,8 @@ template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
 }
 
 static_assert(MI_PROFILE || k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit four workgroups per CU (160 KB LDS)");
+static_assert(!MI_K1_LDS_DIET || MI_PROFILE || k1_lds_bytes<2, 4>() <= 32768, "LDS diet: K1 <2,4> in a fifth of the CU's LDS");
+static_assert(!(MI_K1_LDS_DIET && MI_RECT_PART), "the 2:1 block search (dev_rect.h) has not been put on the LDS diet");
 
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU>

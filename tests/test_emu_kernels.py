@@ -69,6 +69,17 @@ def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
     assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
 
 
+def test_emulated_k1_lds_diet_equals_oracle(emu_env):
+    """Groundwork: -DMI_K1_LDS_DIET=1 runs the <2,4> tile search in 32 480 B of LDS per workgroup (40 912 in the product build): one
+    reconstruction / level buffer per wave with the wave's best candidate parked in HBM, edge working copies inside the transposition buffer, level maps
+    inside the one-candidate struct.  Same decisions, same bytes -- in both lane orders (the park is an exchange between the lanes of a wave)."""
+    from tests import emu
+    for extra in ({}, {'MI_EMU_REVERSE': '1'}):
+        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(diet=True), **extra), 'quick', 900)
+        bad = [r['case'] for r in rows if not r['ok']]
+        assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m
