@@ -88,3 +88,12 @@ def test_product_library_is_not_the_emulator():
     with open(encoder.library_path(), 'rb') as fh:
         blob = fh.read()
     assert b'emu_switch' not in blob and b'gfx950' in blob
+    # ... and it is the product build, not one of the prepared variants of tools/build_variants.sh written over it
+    assert b'tile_search_queue_kernel' not in blob, 'cavif_rs_amd/libmi_avif.so was built with -DMI_K1_QUEUE_KERNEL=1'
+    import __graft_entry__ as g
+    csrc = os.path.join(ROOT, 'cavif_rs_amd', 'csrc')
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, 'include', 'mi_avif.h')]
+    stamp = encoder.library_path() + '.stamp'
+    if os.path.exists(stamp) and not os.environ.get('MI_AVIF_LIB'):
+        assert open(stamp).read().strip() == g._digest(srcs, g.HIPCC_FLAGS), 'libmi_avif.so is older than its sources or was built with other flags: python __graft_entry__.py'
+
