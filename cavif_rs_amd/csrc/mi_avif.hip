@@ -186,7 +186,10 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 // (single images: 8 .. 512 tiles against 1024 resident workgroups of the 16x16 class, 256 of the others) gets row workers;
 // MI_K1_WORKERS=n forces n (clamped), =1 switches them off.
 template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
-  const size_t lds = k1_lds_bytes<MAXBS, NW>();
+  // MI_K1_LDS_PAD=n (experiments): n more bytes of LDS per workgroup than the kernel uses -- the occupancy knob of the LDS-diet build: at 32 480 B a
+  // fifth search workgroup fits a CU, padded to 32 769 .. 33 194 B four fit and leave room for two entropy-coder workgroups (15.5 KB each).
+  static const size_t pad = [] { const char *v = getenv("MI_K1_LDS_PAD"); return v ? (size_t)std::max(0, atoi(v)) : (size_t)0; }();
+  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? pad : 0);
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int resident = (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1) * 256;
