@@ -227,7 +227,7 @@ static hipError_t launch_search_queue(int maxbs, bool bottomup, const FrameDev *
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
 static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  const int k4_threads = MI_K4_PIPE ? 128 : 64;                   // MI_K4_PIPE: a walker wave and a range-coder wave per tile (tile_entropy.h)
+  const int k4_threads = MI_K4_THREADS;                   // MI_K4_PIPE: a walker wave and a range-coder wave per tile (tile_entropy.h)
   if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
   else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
   return hipGetLastError();

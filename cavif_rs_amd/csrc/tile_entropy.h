@@ -14,15 +14,25 @@
 // and does nothing but the range arithmetic and the byte output.  Record: bit 31 = literal (value in 0..19, bit count in 20..24), else fl >> 6 in 0..9
 // (512 = the top of the range), fh >> 6 in 10..19, the symbol in 20..23, nsyms - 1 in 24..27.  The producer publishes `head` after every block
 // header / transform block; LDS executes one wave's operations in order, so a consumer that sees head = h finds the records below h written.
+// MI_K4_PIPE == 2: three stages, 2 + MI_K4_ADAPTERS wavefronts per tile.  A CDF's state depends only on the symbols coded through that row, never on the
+// coder state, so the walker (wave 1) does not touch the CDFs at all: it appends `(row, symbol, alphabet)` records (bit 30 set, the row's offset in 0..13).
+// Adapter wave a owns the rows with k4_row_owner() == a: it scans the ring behind the walker, turns each of ITS records into the bounds record above in
+// place (read the row, pick fl / fh, adapt) and publishes how far it has scanned (ctl[4 + a]); the coder (wave 0) consumes up to the slowest adapter.
+// The longest chain is the busiest adapter's share of the symbols (a tile uses ~330 rows, the hottest carries about a third of the symbols).
 #ifndef MI_K4_PIPE
 #define MI_K4_PIPE 0
 #endif
+#ifndef MI_K4_ADAPTERS
+#define MI_K4_ADAPTERS 3
+#endif
+#define MI_K4_THREADS (MI_K4_PIPE == 2 ? 64 * (2 + MI_K4_ADAPTERS) : (MI_K4_PIPE ? 128 : 64))
 #define MI_K4_RING 2048
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
   uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
 #if MI_K4_PIPE
-  LDS uint32_t *ring; LDS volatile uint32_t *ctl;      // ctl[0] = head (producer), ctl[1] = tail (consumer), ctl[2] = done
+  LDS uint32_t *ring; LDS volatile uint32_t *ctl;      // ctl[0] = head (producer), ctl[1] = tail (consumer), ctl[2] = done, ctl[4 + a] = adapter a's position
+  LDS uint16_t *cdf_base;                               // MI_K4_PIPE == 2: row offsets in the records are relative to it
   uint32_t h, tail_seen;                                // producer: records written / the consumer's tail as last read
 #endif
 };
@@ -98,6 +108,10 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 // of a loop) -- one LDS round trip per symbol instead of three dependent ones.
 __device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s_in, LDS uint16_t *icdf, int nsyms_in) {
   const int s = uni32(s_in), nsyms = uni32(nsyms_in);
+#if MI_K4_PIPE == 2
+  pipe_emit(e, 0x40000000u | (uint32_t)uni32((int)(icdf - e->cdf_base)) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24));
+  return;
+#endif
   const int i = LANE;
   const int v = icdf[imin_(i, nsyms)];
   const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(v, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
@@ -121,15 +135,77 @@ __device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, in
 #endif
 }
 #if MI_K4_PIPE
+#if MI_K4_PIPE == 2
+// which adapter wave owns a CDF row (static: a row's symbols must all pass through one wave, in order).  The base-level contexts carry most of the
+// symbols, neighbouring contexts and the same context of neighbouring transform sizes are spread over different adapters.
+__device__ __forceinline__ int k4_row_owner(uint32_t row) {
+  const uint32_t idx = row / 5u;
+  if (row >= (uint32_t)CDF_COEFF_BASE && row < (uint32_t)CDF_COEFF_BASE_EOB) { const uint32_t i2 = (row - (uint32_t)CDF_COEFF_BASE) / 5u; return (int)((i2 % 42u + 2u * (i2 / 42u) + 2u) % (uint32_t)MI_K4_ADAPTERS); }
+  return (int)(idx % (uint32_t)MI_K4_ADAPTERS);
+}
+// adapter wave `a`: scans the records behind the walker; its own rows' records become bounds records in place
+__device__ __forceinline__ void pipe_adapt(RangeEncDev *e, int a) {
+  uint32_t m = 0;
+  for (;;) {
+    uint32_t h = (uint32_t)uni32((int)e->ctl[0]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (h == m) {
+      if (uni32((int)e->ctl[2])) { h = (uint32_t)uni32((int)e->ctl[0]); if (h == m) break; }
+      else { __builtin_amdgcn_s_sleep(2); continue; }
+    }
+    while (m != h) {
+      const uint32_t chunk = (h - m) < 64u ? (h - m) : 64u;
+      const uint32_t v = e->ring[(m + (uint32_t)LANE) & (MI_K4_RING - 1)];
+      for (uint32_t j = 0; j < chunk; j++) {
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j);
+        if (!(rec & 0x40000000u) || (rec & 0x80000000u)) continue;       // literal / bounds record (or a row record its owner has already converted)
+        const uint32_t row = rec & 0xFFFFu;
+        if (k4_row_owner(row) != a) continue;
+        if (rec & 0x20000000u) {                                           // write_partition_symbol at a frame edge: P(split-ish partitions) of the row as it stands, not adapted
+          const int cv = e->cdf_base[row + imin_(LANE, 10)];
+          uint32_t psum = 0;
+          const uint32_t set = (rec & 0x10000u) ? 0x2DCu : 0x17Au;            // has_cols: partitions 2, 3, 4, 6, 7, 9; else 1, 3, 4, 5, 6, 8
+#pragma unroll
+          for (int i2 = 1; i2 < 10; i2++)
+            if ((set >> i2) & 1u) psum += (uint32_t)__builtin_amdgcn_readlane(cv, i2 - 1) - (uint32_t)__builtin_amdgcn_readlane(cv, i2);
+          if (LANE == 0) e->ring[(m + j) & (MI_K4_RING - 1)] = (psum >> 6) | (1u << 20) | (1u << 24);
+          continue;
+        }
+        const int s = (int)((rec >> 20) & 15u), nsyms = (int)((rec >> 24) & 15u) + 1;
+        LDS uint16_t *icdf = e->cdf_base + row;
+        const int i = LANE;
+        const int cv = icdf[imin_(i, nsyms)];
+        const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(cv, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(cv, s);
+        const int cnt = __builtin_amdgcn_readlane(cv, nsyms);
+        const uint32_t fl = s > 0 ? fl0 : 32768u;
+        if (LANE == 0) e->ring[(m + j) & (MI_K4_RING - 1)] = (fl >> 6) | ((fh >> 6) << 10) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24);
+        const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
+        if (i < nsyms - 1) icdf[i] = (uint16_t)(i < s ? cv + ((32768 - cv) >> rate) : cv - (cv >> rate));
+        else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
+        WAVE_SYNC();
+      }
+      m += chunk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (LANE == 0) e->ctl[4 + a] = m;
+    }
+  }
+}
+#endif
 // consumer side (wave 0): pops records until the producer is done, 64 at a time into a register
 __device__ __forceinline__ void pipe_consume(RangeEncDev *e) {
   uint32_t t = 0;
   for (;;) {
+#if MI_K4_PIPE == 2
+    uint32_t h = (uint32_t)uni32((int)e->ctl[4]);                  // as far as the slowest adapter has come
+#pragma unroll
+    for (int a = 1; a < MI_K4_ADAPTERS; a++) { const uint32_t ma = (uint32_t)uni32((int)e->ctl[4 + a]); if ((int)(ma - h) < 0) h = ma; }
+#else
     uint32_t h = (uint32_t)uni32((int)e->ctl[0]);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (h == t) {
-      if (uni32((int)e->ctl[2])) { h = (uint32_t)uni32((int)e->ctl[0]); if (h == t) break; }
-      else { __builtin_amdgcn_s_sleep(4); continue; }
+      if (uni32((int)e->ctl[2]) && (uint32_t)uni32((int)e->ctl[0]) == t) break;      // the walker is done and everything it wrote has been consumed
+      __builtin_amdgcn_s_sleep(4); continue;
     }
     while (t != h) {
       const uint32_t chunk = (h - t) < 64u ? (h - t) : 64u;
@@ -484,12 +560,17 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
   const int ns = bs == BS_8 ? 4 : 10;
   if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
   else if (has_rows || has_cols) {
+#if MI_K4_PIPE == 2
+    // the split-or-not bool at a frame edge is priced from the row's CURRENT state: its owner derives it in coding order (bit 29, bit 16 = has_cols)
+    pipe_emit(&w->ec, 0x60000000u | (uint32_t)uni32((int)(cdf - w->ec.cdf_base)) | (has_cols ? 0x10000u : 0u));
+#else
 #define PP_(i) ((uint32_t)((i) > 0 ? cdf[(i) - 1] : 32768) - cdf[i])
     uint32_t psum;
     if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
     else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
 #undef PP_
     re_bool_dev(&w->ec, 1, (uint32_t)U_(psum));
+#endif
   }
   if (!(has_rows && has_cols)) part = 3;
   K4PH(0);
@@ -582,12 +663,12 @@ template <int CS> struct EntropyLds {
   uint32_t rec_lv[CS * CS];
   uint16_t lr_cdf[4]; int lr_ref[6];
 #if MI_K4_PIPE
-  uint32_t ring[MI_K4_RING]; uint32_t ctl[4];
+  uint32_t ring[MI_K4_RING]; uint32_t ctl[4 + MI_K4_ADAPTERS];
 #endif
 };
 
 template <int MAXBS>
-__global__ __launch_bounds__(MI_K4_PIPE ? 128 : 64) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
+__global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
   constexpr int CS = MAXBS <= 2 ? 16 : 32;
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
   EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
@@ -614,9 +695,13 @@ __global__ __launch_bounds__(MI_K4_PIPE ? 128 : 64) void tile_entropy_kernel(con
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
 #if MI_K4_PIPE
   w.ec.ring = (LDS uint32_t *)L.ring; w.ec.ctl = (LDS volatile uint32_t *)L.ctl;
-  if (threadIdx.x < 4) L.ctl[threadIdx.x] = 0;
-  __syncthreads();                                             // ring control words and (below, producer only) the tile's tables
+  w.ec.cdf_base = (LDS uint16_t *)L.cdf;
+  if (threadIdx.x < 4 + MI_K4_ADAPTERS) L.ctl[threadIdx.x] = 0;
+  __syncthreads();                                             // ring control words, the tile's tables and CDFs
   const int pipe_wave = (int)(threadIdx.x >> 6);
+#if MI_K4_PIPE == 2
+  if (pipe_wave >= 2) { pipe_adapt(&w.ec, pipe_wave - 2); return; }
+#endif
   if (pipe_wave == 0) {                                         // consumer: range arithmetic + byte output only
     pipe_consume(&w.ec);
     if (LANE == 0) {

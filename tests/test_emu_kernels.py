@@ -69,6 +69,17 @@ def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
     assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
 
 
+def test_emulated_k4_three_stage_pipeline_equals_oracle(emu_env):
+    """Groundwork: -DMI_K4_PIPE=2 decouples the three things the entropy coder does per symbol -- the walker wave emits (CDF row, symbol)
+    records without touching a CDF, three adapter waves own disjoint sets of rows and turn their records into bounds in place, the coder wave does the range
+    arithmetic behind the slowest adapter.  Exact because a CDF's state depends only on the symbols coded through that row.  Both lane orders."""
+    from tests import emu
+    for extra in ({}, {'MI_EMU_REVERSE': '1'}):
+        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=2), **extra), 'quick', 900)
+        bad = [r['case'] for r in rows if not r['ok']]
+        assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
+
+
 def test_emulated_k1_lds_diet_equals_oracle(emu_env):
     """Groundwork: -DMI_K1_LDS_DIET=1 runs the <2,4> tile search in 32 480 B of LDS per workgroup (40 912 in the product build): one
     reconstruction / level buffer per wave with the wave's best candidate parked in HBM, edge working copies inside the transposition buffer, level maps
