@@ -23,7 +23,7 @@
 #define MI_K4_PIPE 0
 #endif
 #ifndef MI_K4_ADAPTERS
-#define MI_K4_ADAPTERS 3
+#define MI_K4_ADAPTERS 4
 #endif
 #define MI_K4_THREADS (MI_K4_PIPE == 2 ? 64 * (2 + MI_K4_ADAPTERS) : (MI_K4_PIPE ? 128 : 64))
 #define MI_K4_RING 2048
@@ -136,12 +136,10 @@ __device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, in
 }
 #if MI_K4_PIPE
 #if MI_K4_PIPE == 2
-// which adapter wave owns a CDF row (static: a row's symbols must all pass through one wave, in order).  The base-level contexts carry most of the
-// symbols, neighbouring contexts and the same context of neighbouring transform sizes are spread over different adapters.
+// which adapter wave owns a CDF row (static: a row's symbols must all pass through one wave, in order); every adapter evaluates it for every record
 __device__ __forceinline__ int k4_row_owner(uint32_t row) {
-  const uint32_t idx = row / 5u;
-  if (row >= (uint32_t)CDF_COEFF_BASE && row < (uint32_t)CDF_COEFF_BASE_EOB) { const uint32_t i2 = (row - (uint32_t)CDF_COEFF_BASE) / 5u; return (int)((i2 % 42u + 2u * (i2 / 42u) + 2u) % (uint32_t)MI_K4_ADAPTERS); }
-  return (int)(idx % (uint32_t)MI_K4_ADAPTERS);
+  static_assert((MI_K4_ADAPTERS & (MI_K4_ADAPTERS - 1)) == 0, "the low bits of the row offset pick the adapter");
+  return (int)(row & (uint32_t)(MI_K4_ADAPTERS - 1));   // the hot tables have strides 5 and 3: neighbouring contexts, and the same context of neighbouring transform sizes (210 apart), land on different waves
 }
 // adapter wave `a`: scans the records behind the walker; its own rows' records become bounds records in place
 __device__ __forceinline__ void pipe_adapt(RangeEncDev *e, int a) {
@@ -698,7 +696,7 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
   w.ec.cdf_base = (LDS uint16_t *)L.cdf;
   if (threadIdx.x < 4 + MI_K4_ADAPTERS) L.ctl[threadIdx.x] = 0;
   __syncthreads();                                             // ring control words, the tile's tables and CDFs
-  const int pipe_wave = (int)(threadIdx.x >> 6);
+  const int pipe_wave = uni32((int)(threadIdx.x >> 6));        // wave-uniform: the roles below branch on the scalar unit
 #if MI_K4_PIPE == 2
   if (pipe_wave >= 2) { pipe_adapt(&w.ec, pipe_wave - 2); return; }
 #endif

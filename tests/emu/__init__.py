@@ -12,7 +12,7 @@ LIB_QUEUE = os.path.join(HERE, '_build', 'libmi_avif_emu_queue.so')     # -DMI_K
 
 
 LIB_PIPE = os.path.join(HERE, '_build', 'libmi_avif_emu_pipe.so')       # -DMI_K4_PIPE=1: entropy coder as a walker wave + a range-coder wave per tile
-LIB_PIPE3 = os.path.join(HERE, '_build', 'libmi_avif_emu_pipe3.so')     # -DMI_K4_PIPE=2: walker wave | three CDF-adapter waves | range-coder wave per tile
+LIB_PIPE3 = os.path.join(HERE, '_build', 'libmi_avif_emu_pipe3.so')     # -DMI_K4_PIPE=2: walker wave | four CDF-adapter waves | range-coder wave per tile
 LIB_DIET = os.path.join(HERE, '_build', 'libmi_avif_emu_diet.so')       # -DMI_K1_LDS_DIET=1: the tile search in 32 KB of LDS per workgroup
 
 

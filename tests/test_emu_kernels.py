@@ -71,7 +71,7 @@ def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
 
 def test_emulated_k4_three_stage_pipeline_equals_oracle(emu_env):
     """Groundwork: -DMI_K4_PIPE=2 decouples the three things the entropy coder does per symbol -- the walker wave emits (CDF row, symbol)
-    records without touching a CDF, three adapter waves own disjoint sets of rows and turn their records into bounds in place, the coder wave does the range
+    records without touching a CDF, four adapter waves own disjoint sets of rows and turn their records into bounds in place, the coder wave does the range
     arithmetic behind the slowest adapter.  Exact because a CDF's state depends only on the symbols coded through that row.  Both lane orders."""
     from tests import emu
     for extra in ({}, {'MI_EMU_REVERSE': '1'}):
