@@ -80,6 +80,29 @@ __device__ __forceinline__ void pipe_emit(RangeEncDev *e, uint32_t rec) {
   if (LANE == 0) e->ring[e->h & (MI_K4_RING - 1)] = rec;
   e->h++;
 }
+#if MI_K4_PIPE == 2
+// room for n more records (wave-uniform n <= 64 * 5), then the lanes write theirs side by side (code_coeffs_lane0)
+__device__ __forceinline__ void pipe_reserve(RangeEncDev *e, uint32_t n) {
+  if (e->h + n - e->tail_seen > MI_K4_RING) {
+    pipe_publish(e);
+    for (;;) {
+      const uint32_t t = (uint32_t)uni32((int)e->ctl[1]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      e->tail_seen = t;
+      if (e->h + n - t <= MI_K4_RING) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+}
+// exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl(x, imax_(LANE - d, 0)); if (LANE >= d) x += t; }
+  *total = __builtin_amdgcn_readlane(x, 63);
+  return x - v;
+}
+#endif
 __device__ __forceinline__ void re_encode_core(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms);
 // producer side: the symbol's bounds go to the ring
 __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
@@ -341,6 +364,50 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
     re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
     if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
   }
+#if MI_K4_PIPE == 2
+  // The walker only EMITS records, so a transform block's symbols need no serial loop: lane j takes the j-th position in coding order, counts its
+  // records (base level + up to four base-range symbols; then sign + Golomb literals), an exclusive scan places them, the lanes write side by side.
+  for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
+    const int c = cb + 63 - LANE;                            // levels are coded from the last position down
+    const bool valid = c < eob;
+    const int li = imin_(c, eob - 1);
+    const uint32_t r_lv = w->rec_lv[li]; const uint32_t r_off = w->rec_off[li], r_br = w->rec_br[li];
+    const int level = valid ? (int)(r_lv >> 1) : 0;
+    const int nbr = level > 2 ? imin_(4, (level - 3) / 3 + 1) : 0;
+    int total; const int off = wave_excl_scan_i32(valid ? 1 + nbr : 0, &total);
+    pipe_reserve(e, (uint32_t)total);
+    if (valid) {
+      const uint32_t at = e->h + (uint32_t)off;
+      e->ring[at & (MI_K4_RING - 1)] = 0x40000000u | r_off | (c == eob - 1 ? ((uint32_t)(imin_(level, 3) - 1) << 20) | (2u << 24) : ((uint32_t)imin_(level, 3) << 20) | (3u << 24));
+      int rem = level - 3;
+      for (int k2 = 0; k2 < nbr; k2++) { const int s2 = imin_(rem, 3); e->ring[(at + 1 + (uint32_t)k2) & (MI_K4_RING - 1)] = 0x40000000u | r_br | ((uint32_t)s2 << 20) | (3u << 24); rem -= s2; }
+    }
+    WAVE_SYNC();
+    e->h += (uint32_t)total;
+  }
+  K4PH(4); K4CNT(11, eob);
+  const uint32_t dc_row = (uint32_t)(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE);
+  for (int cb = 0; cb < eob; cb += 64) {
+    const int c = cb + LANE;                                 // signs and Golomb tails from the first position up
+    const uint32_t m = w->rec_lv[imin_(c, eob - 1)];
+    const int a = c < eob ? (int)(m >> 1) : 0, neg = (int)(m & 1);
+    const uint32_t xg = (uint32_t)imax_(a - 14, 1); const int len = 32 - __clz(xg);
+    const int n = a ? 1 + (a > 14 ? (len > 1) + 1 : 0) : 0;
+    int total; const int off = wave_excl_scan_i32(n, &total);
+    pipe_reserve(e, (uint32_t)total);
+    if (a) {
+      uint32_t at = e->h + (uint32_t)off;
+      e->ring[at++ & (MI_K4_RING - 1)] = c == 0 ? (0x40000000u | dc_row | ((uint32_t)neg << 20) | (1u << 24))
+                                                : (neg ? (256u | (1u << 20) | (1u << 24)) : (512u | (256u << 10) | (1u << 24)));   // re_bool_dev(neg, 16384)
+      if (a > 14) {
+        if (len > 1) e->ring[at++ & (MI_K4_RING - 1)] = 0x80000000u | ((uint32_t)(len - 1) << 20);
+        e->ring[at & (MI_K4_RING - 1)] = 0x80000000u | (xg & 0xFFFFFu) | ((uint32_t)len << 20);
+      }
+    }
+    WAVE_SYNC();
+    e->h += (uint32_t)total;
+  }
+#else
   // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
   // The coeff_base (42 contexts) and coeff_br (21 contexts) rows of this (transform size, plane type) live in registers for the
   // duration of the block: lane L < 42 owns base context L, lane 42 + k owns base-range context k (four-symbol alphabets: three
@@ -374,6 +441,7 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
       }
     }
   }
+#endif
   K4PH(5);
 }
 
