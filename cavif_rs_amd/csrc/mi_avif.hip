@@ -230,6 +230,12 @@ static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const Tile
   const int k4_threads = MI_K4_THREADS;                   // MI_K4_PIPE: a walker wave and a range-coder wave per tile (tile_entropy.h)
   if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
   else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+#if MI_K4_PIPE == 3
+  // the walker above has left the tiles' record streams in HBM: adapters (one wave per tile and adapter), then the range coder (one wave per tile)
+  if (maxbs <= 2) hipLaunchKernelGGL((k4_adapt_kernel<2>), dim3(njobs * MI_K4_ADAPTERS), dim3(64), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+  else hipLaunchKernelGGL((k4_adapt_kernel<4>), dim3(njobs * MI_K4_ADAPTERS), dim3(64), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+  hipLaunchKernelGGL(k4_code_kernel, dim3(njobs), dim3(64), 0, s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+#endif
   return hipGetLastError();
 }
 // every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch
@@ -348,7 +354,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_frames, sizeof(FrameDev) * worst.size()));
   HIP_OK(hipMalloc(&b->d_jobs, sizeof(TileJob) * max_tiles));
   b->pre_cap = max_cap;
-  HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * max_cap * 2));
+  HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * MI_K4_PRE_STRIDE(max_cap) * 2));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
   HIP_OK(hipMalloc(&b->d_prof, max_tiles * 128 * 8));
   // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
@@ -586,7 +592,7 @@ int mi_batch_encode_async(mi_batch *b) {
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * b->pre_cap, b->pre_cap, s));
+    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * MI_K4_PRE_STRIDE(b->pre_cap), b->pre_cap, s));
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -928,7 +934,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
-  HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * cap * 2));
+  HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * MI_K4_PRE_STRIDE(cap) * 2));
   FrameDev *d_frame = g.d_frame; TileJob *d_jobs = g.d_jobs; uint16_t *d_pre = g.d_pre;
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));

@@ -13,6 +13,7 @@ LIB_QUEUE = os.path.join(HERE, '_build', 'libmi_avif_emu_queue.so')     # -DMI_K
 
 LIB_PIPE = os.path.join(HERE, '_build', 'libmi_avif_emu_pipe.so')       # -DMI_K4_PIPE=1: entropy coder as a walker wave + a range-coder wave per tile
 LIB_PIPE3 = os.path.join(HERE, '_build', 'libmi_avif_emu_pipe3.so')     # -DMI_K4_PIPE=2: walker wave | four CDF-adapter waves | range-coder wave per tile
+LIB_PIPEK = os.path.join(HERE, '_build', 'libmi_avif_emu_pipek.so')     # -DMI_K4_PIPE=3: the same three stages as three kernels, the record stream in HBM
 LIB_DIET = os.path.join(HERE, '_build', 'libmi_avif_emu_diet.so')       # -DMI_K1_LDS_DIET=1: the tile search in 32 KB of LDS per workgroup
 
 
@@ -21,7 +22,7 @@ def build(force=False, rect=False, queue=False, pipe=False, diet=False):
     csrc = os.path.join(ROOT, 'cavif_rs_amd', 'csrc')
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'),
                                                                os.path.join(ROOT, 'include', 'mi_avif.h')]
-    lib = LIB_RECT if rect else (LIB_QUEUE if queue else ((LIB_PIPE3 if pipe == 2 else LIB_PIPE) if pipe else (LIB_DIET if diet else LIB)))
+    lib = LIB_RECT if rect else (LIB_QUEUE if queue else (({2: LIB_PIPE3, 3: LIB_PIPEK}.get(int(pipe), LIB_PIPE)) if pipe else (LIB_DIET if diet else LIB)))
     if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
         return lib
     os.makedirs(os.path.dirname(lib), exist_ok=True)

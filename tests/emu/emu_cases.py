@@ -18,6 +18,7 @@ oracle.build(); oracle.lib()
 PLANE_CASES = {
     'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0),
               (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: two row workers (K1 waits on the row above)
+    'mini': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 66, False, 2), (48, 40, 10, 1, 121, False, 0), (96, 64, 10, 4, 66, True, 0)],   # the prepared variants (plus the ravif-level RGBA case below)
     'rect': [(129, 101, 10, 4, 121, False, 0), (136, 72, 8, 4, 10, False, 0), (96, 64, 10, 4, 66, True, 0), (72, 40, 10, 1, 121, False, 0)],
     'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
              (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),

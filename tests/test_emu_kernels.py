@@ -64,7 +64,7 @@ def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
     """Groundwork: -DMI_K4_PIPE=1 splits the entropy coder of a tile into a walker wave (contexts, CDF adaptation, symbol bounds into an
     LDS ring) and a range-coder wave; the bytes must not change.  The emulator runs the two waves as fibers that yield to each other while they poll."""
     from tests import emu
-    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=True)), 'quick', 900)
+    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=True)), 'mini', 900)
     bad = [r['case'] for r in rows if not r['ok']]
     assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
 
@@ -75,9 +75,19 @@ def test_emulated_k4_three_stage_pipeline_equals_oracle(emu_env):
     arithmetic behind the slowest adapter.  Exact because a CDF's state depends only on the symbols coded through that row.  Both lane orders."""
     from tests import emu
     for extra in ({}, {'MI_EMU_REVERSE': '1'}):
-        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=2), **extra), 'quick', 900)
+        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=2), **extra), 'mini', 900)
         bad = [r['case'] for r in rows if not r['ok']]
         assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
+
+
+def test_emulated_k4_three_kernel_split_equals_oracle(emu_env):
+    """Groundwork: -DMI_K4_PIPE=3 runs the same three stages as three kernels with the tile's record stream in HBM (walker -> one wave
+    per (tile, adapter) converting its rows' records in place -> range coder): no wave waits for another.  The ravif-level case covers the alpha frame
+    (32-point tables) and the partition bool at the frame edge that is priced from a CDF's current state."""
+    from tests import emu
+    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=3)), 'mini', 900)
+    bad = [r['case'] for r in rows if not r['ok']]
+    assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
 
 
 def test_emulated_k1_lds_diet_equals_oracle(emu_env):
@@ -86,7 +96,7 @@ def test_emulated_k1_lds_diet_equals_oracle(emu_env):
     inside the one-candidate struct.  Same decisions, same bytes -- in both lane orders (the park is an exchange between the lanes of a wave)."""
     from tests import emu
     for extra in ({}, {'MI_EMU_REVERSE': '1'}):
-        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(diet=True), **extra), 'quick', 900)
+        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(diet=True), **extra), 'mini', 900)
         bad = [r['case'] for r in rows if not r['ok']]
         assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
 
