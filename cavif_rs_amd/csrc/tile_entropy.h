@@ -445,10 +445,6 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   }
 #else
   // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
-  // The coeff_base (42 contexts) and coeff_br (21 contexts) rows of this (transform size, plane type) live in registers for the
-  // duration of the block: lane L < 42 owns base context L, lane 42 + k owns base-range context k (four-symbol alphabets: three
-  // CDF entries + the adaptation counter).  A symbol takes its bounds out of the owning lane by v_readlane and that lane adapts
-  // its row in place -- no LDS round trip and no fence per symbol; the rows return to the LDS copy after the last coefficient.
   for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
     const int li = imin_(cb + LANE, eob - 1);
     const uint32_t r_lv = w->rec_lv[li]; const int r_off = w->rec_off[li], r_br = w->rec_br[li];
