@@ -210,15 +210,20 @@ __device__ __forceinline__ bool k4_adapt_record(LDS uint16_t *cdf_base, uint32_t
   WAVE_SYNC();
   return true;
 }
-// one finished record through the range coder
+// one finished record through the range coder.  Works on the record's 10-bit bounds directly and without a branch for the first-symbol case
+// (fl6 = 512 is the top of the range: u = rng, nothing is added to low) -- the same arithmetic as re_encode_core.
+__device__ __forceinline__ void k4_code_bounds(RangeEncDev *e, uint32_t rec) {
+  const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms = ((rec >> 24) & 15u) - ((rec >> 20) & 15u);   // N - s
+  const uint32_t r = e->rng, r8 = r >> 8;
+  const uint32_t v = ((r8 * fh6) >> 1) + 4u * nms;
+  const uint32_t u = fl6 >= 512u ? r : ((r8 * fl6) >> 1) + 4u * nms + 4u;
+  re_normalize_dev(e, e->low + (r - u), u - v);
+}
 __device__ __forceinline__ void k4_code_record(RangeEncDev *e, uint32_t rec) {
-  if (rec & 0x80000000u) {
-    const uint32_t val = rec & 0xFFFFFu; const int nbits = (int)((rec >> 20) & 31);
-    for (int i = nbits - 1; i >= 0; i--) { const int bit = (int)((val >> i) & 1); re_encode_core(e, bit ? 16384u : 32768u, bit ? 0u : 16384u, bit, 2); }
-  } else {
-    const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u;
-    re_encode_core(e, fl6 << 6, fh6 << 6, (int)((rec >> 20) & 15), (int)((rec >> 24) & 15) + 1);
-  }
+  if (rec & 0x80000000u) {                                                // literal: its bits as equiprobable bools, most significant first
+    const uint32_t val = rec & 0xFFFFFu;
+    for (int i = (int)((rec >> 20) & 31) - 1; i >= 0; i--) k4_code_bounds(e, ((val >> i) & 1u) ? (256u | (1u << 20) | (1u << 24)) : (512u | (256u << 10) | (1u << 24)));
+  } else k4_code_bounds(e, rec);
 }
 #endif
 #if MI_K4_PIPE == 2
