@@ -800,7 +800,9 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
   if (LANE < 6) L.lr_ref[LANE] = (LANE & 1) ? 31 : -32;                                                      // Sgrproj_Xqd_Mid
   load_scans_to_lds((LDS uint16_t *)L.scans, CS);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
+#if MI_K4_PIPE != 3                                            // (the three-kernel walker never reads a CDF: the adapters load them)
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
+#endif
 #if MI_K4_PIPE == 3
   static_assert(sizeof(EntropyLds<16>) % 4 == 0, "");
   re_init_dev(&w.ec, k4_pre_of(precarry, pre_cap, job), pre_cap);
