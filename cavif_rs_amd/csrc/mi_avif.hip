@@ -182,14 +182,14 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
+// MI_K1_LDS_PAD=n (experiments): n more bytes of LDS per workgroup than the kernel uses -- the occupancy knob of the LDS-diet build: at 32 480 B a
+// fifth search workgroup fits a CU, padded to 32 769 .. 33 194 B four fit and leave room for two entropy-coder workgroups (15.5 KB each).
+static size_t k1_lds_pad() { static const size_t pad = [] { const char *v = getenv("MI_K1_LDS_PAD"); return v ? (size_t)std::max(0, atoi(v)) : (size_t)0; }(); return pad; }
 // `max_workers`: the smallest snap_rows among the launch's frames.  A launch that does not fill the GPU with one workgroup per tile
 // (single images: 8 .. 512 tiles against 1024 resident workgroups of the 16x16 class, 256 of the others) gets row workers;
 // MI_K1_WORKERS=n forces n (clamped), =1 switches them off.
 template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
-  // MI_K1_LDS_PAD=n (experiments): n more bytes of LDS per workgroup than the kernel uses -- the occupancy knob of the LDS-diet build: at 32 480 B a
-  // fifth search workgroup fits a CU, padded to 32 769 .. 33 194 B four fit and leave room for two entropy-coder workgroups (15.5 KB each).
-  static const size_t pad = [] { const char *v = getenv("MI_K1_LDS_PAD"); return v ? (size_t)std::max(0, atoi(v)) : (size_t)0; }();
-  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? pad : 0);
+  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? k1_lds_pad() : 0);
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int resident = (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1) * 256;
@@ -202,13 +202,17 @@ template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const Fr
 #if MI_K1_QUEUE_KERNEL
 // The same search as a work queue (tile_search.h tile_search_queue_kernel): `items` = the launch's superblocks in dependency order.
 template <int MAXBS, int NW, bool BU> static hipError_t launch_search_queue_t(const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int grid, hipStream_t s) {
-  const size_t lds = k1_lds_bytes<MAXBS, NW>();
+  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? k1_lds_pad() : 0);
   hipError_t e = hipFuncSetAttribute((const void *)tile_search_queue_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((tile_search_queue_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
   return hipGetLastError();
 }
-static int k1_resident(int maxbs) { return (maxbs <= 2 ? MI_K1_WG_PER_CU : 1) * 256; }
+// persistent workgroups of the queue launch; MI_K1_QUEUE_WG_PER_CU=n (experiments, 16x16 class) asks for fewer than the build's launch bound allows
+static int k1_resident(int maxbs) {
+  static const int per_cu = [] { const char *v = getenv("MI_K1_QUEUE_WG_PER_CU"); const int n = v ? atoi(v) : 0; return n > 0 && n < MI_K1_WG_PER_CU ? n : MI_K1_WG_PER_CU; }();
+  return (maxbs <= 2 ? per_cu : 1) * 256;
+}
 static size_t k1_snap_bytes(int maxbs) { return maxbs <= 2 ? MI_SNAP_BYTES_ALL(16) : (maxbs == 3 ? MI_SNAP_BYTES_ALL(32) : MI_SNAP_BYTES_ALL(64)); }
 static hipError_t launch_search_queue(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, hipStream_t s) {
   if (nitems <= 0) return hipSuccess;

@@ -18,6 +18,7 @@ for P in 1 3; do
   MI_K1_LDS_PAD=544 MI_AVIF_LIB=$L/libmi_diet.so timeout 180 python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop $ID 2>&1 | tail -1 | line "diet(96 vgpr, LDS padded to 33 024 B: 4 searches + 2 entropy coders per CU)/slots$P"
   MI_AVIF_LIB=$L/libmi_diet4.so timeout 180 python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop $ID 2>&1 | tail -1 | line "diet4(4 wg/cu, 128 vgpr)/slots$P"
   MI_K1_QUEUE=1 MI_AVIF_LIB=$L/libmi_combo.so timeout 180 python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop $ID 2>&1 | tail -1 | line "combo (queue + diet5 + pipek)/slots$P"
+  MI_K1_QUEUE=1 MI_K1_QUEUE_WG_PER_CU=4 MI_K1_LDS_PAD=544 MI_AVIF_LIB=$L/libmi_combo.so timeout 180 python bench.py --steps 4 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop $ID 2>&1 | tail -1 | line "combo, 4 searches per CU + room for the entropy kernels/slots$P"
 done
 for V in queue pipe pipe3 pipek diet diet4 combo; do MI_K1_QUEUE=1 MI_AVIF_LIB=$L/libmi_$V.so timeout 180 python tools/gpu_quickcheck.py 2>&1 | tail -8 | grep -c "bytes_equal=True recon_equal=True" | sed "s/^/$V quickcheck ok cases: /"; done
 MI_ORACLE_LIB=$PWD/oracle/_build/liboracle_rect.so MI_AVIF_LIB=$L/libmi_rect.so timeout 180 python tools/gpu_quickcheck.py 2>&1 | tail -8 | grep -c "bytes_equal=True recon_equal=True" | sed "s/^/rect quickcheck ok cases: /"
