@@ -45,6 +45,36 @@ def hbm_traffic_bytes(kernel, cfg):
         return None
 
 
+def _synth_to_cache(job):
+    """One synthetic image into the .npy cache (worker process): the generator is 0.6 s of numpy per 1080p image."""
+    path, w, h, idx = job
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from cavif_rs_amd.synth import synth_image
+    tmp = '%s.%d.tmp.npy' % (path, os.getpid())
+    np.save(tmp, synth_image(w, h, index=idx))
+    os.replace(tmp, path)
+    return path
+
+
+def synth_images(w, h, indices):
+    """The synthetic inputs `synth_image(w, h, index=i)`, generated on all host cores and kept as .npy files under
+    $MI_SYNTH_CACHE (default /tmp/mi_synth_cache) so that repeated runs on one box do not regenerate them."""
+    import numpy as np
+    d = os.environ.get('MI_SYNTH_CACHE', '/tmp/mi_synth_cache')
+    os.makedirs(d, exist_ok=True)
+    paths = {i: os.path.join(d, 'synth_%dx%d_%05d.npy' % (w, h, i)) for i in indices}
+    missing = [(paths[i], w, h, i) for i in indices if not os.path.exists(paths[i])]
+    if len(missing) > 2:
+        import multiprocessing as mp
+        with mp.get_context('spawn').Pool(max(1, min(os.cpu_count() or 1, 16, len(missing)))) as pool:
+            pool.map(_synth_to_cache, missing)
+    else:
+        for job in missing:
+            _synth_to_cache(job)
+    return {i: np.load(paths[i]) for i in indices}
+
+
 def _oracle_worker(job):
     idx, w, h, speed, quality, depth = job
     sys.path.insert(0, ROOT)
@@ -191,9 +221,10 @@ def main():
     first = None
     # slot s of rank r holds images (r * slots + s) * B ... + B - 1: every slot (and every rank) encodes different pictures.
     # The pictures are written into the batches' pinned host staging once; H2D happens per step (second loop) or here (first loop).
+    imgs = synth_images(w, h, [(rank * depth_q + s_) * B + i for s_ in range(depth_q) for i in range(B)])
     for s_, bt in enumerate(batches):
         for i in range(B):
-            img = synth_image(w, h, index=(rank * depth_q + s_) * B + i)
+            img = imgs[(rank * depth_q + s_) * B + i]
             if s_ == 0 and i == 0:
                 first = img
             bt.pinned_input(i)[...] = img

@@ -49,9 +49,7 @@ struct FrameDev {
   int tile_cols;
   // Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent)
   const uint32_t *act, *svar8, *svar4; int tune_psnr;
-  uint8_t *snap;             // area snapshots, per (tile, row worker): MI_SNAP_BYTES_ALL
-  int *sb_prog;              // K1 row workers: superblocks finished per (frame SB row, tile column); zeroed before every encode
-  int snap_rows;             // row workers a tile has snapshot room for (>= the launch's workers per tile)
+  int *sb_prog;              // K1 work queue: superblocks finished per (frame SB row, tile column); zeroed before every encode
   int dbg;                   // debug bisect level (0 = off; probe builds only)
   const uint16_t *cost;      // static rate table [CDF_TOTAL] (cost per symbol in 1/512 bit, same flat layout as the CDF context)
   // ---- tail: frame-level stages and the entropy coder ----

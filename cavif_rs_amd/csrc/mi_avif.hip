@@ -77,16 +77,6 @@ static size_t zeroed_bytes(const FramePlan &p);
 
 static int lr_units_host(uint32_t size) { const int n = ((int)size + 32) / 64; return n < 1 ? 1 : n; }
 static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + (size_t)p.sb_rows * p.tiles.cols * sizeof(int); }
-// Row workers per tile the tile search may use (tile_search.h): no more than the tile's superblock rows, nor than the two-superblock lag
-// lets run side by side, nor MI_K1_MAX_WORKERS; the frame's snapshot area is sized for it.
-#define MI_K1_MAX_WORKERS 16
-static int frame_max_workers(const FramePlan &p) {
-  int rows = 1, cols = 1;
-  for (int i = 0; i < p.tiles.rows; i++) rows = std::max(rows, std::min(p.tiles.row_start[i + 1], p.sb_rows) - p.tiles.row_start[i]);
-  for (int i = 0; i < p.tiles.cols; i++) cols = std::max(cols, std::min(p.tiles.col_start[i + 1], p.sb_cols) - p.tiles.col_start[i]);
-  return std::max(1, std::min(MI_K1_MAX_WORKERS, std::min(rows, (cols + 1) / 2)));
-}
-
 static void plan_geometry(FramePlan &p) {
   const mi_av1_config &c = p.cfg;
   p.np = c.chroma == 1 ? 1 : 3;
@@ -129,8 +119,6 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
     d.lr_type = take(nlr); d.lr_set = take(nlr); d.lr_xqd = (int8_t *)take(nlr * 2);
     d.lr_cand = p.cfg.lrf ? take(nlr * 16 * sizeof(LrCand)) : nullptr;
   }
-  d.snap_rows = frame_max_workers(p);
-  d.snap = take((size_t)p.ntiles * d.snap_rows * MI_SNAP_BYTES_ALL(4 << p.maxbs));
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
@@ -182,79 +170,61 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
 
-// MI_K1_LDS_PAD=n (experiments): n more bytes of LDS per workgroup than the kernel uses -- the occupancy knob of the LDS-diet build: at 32 480 B a
-// fifth search workgroup fits a CU, padded to 32 769 .. 33 194 B four fit and leave room for two entropy-coder workgroups (15.5 KB each).
-static size_t k1_lds_pad() { static const size_t pad = [] { const char *v = getenv("MI_K1_LDS_PAD"); return v ? (size_t)std::max(0, atoi(v)) : (size_t)0; }(); return pad; }
-// `max_workers`: the smallest snap_rows among the launch's frames.  A launch that does not fill the GPU with one workgroup per tile
-// (single images: 8 .. 512 tiles against 1024 resident workgroups of the 16x16 class, 256 of the others) gets row workers;
-// MI_K1_WORKERS=n forces n (clamped), =1 switches them off.
-template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
-  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? k1_lds_pad() : 0);
-  hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  const int resident = (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1) * 256;
-  static const int forced = [] { const char *v = getenv("MI_K1_WORKERS"); return v ? atoi(v) : 0; }();
-  int workers = forced > 0 ? forced : resident / std::max(njobs, 1);
-  workers = std::max(1, std::min(workers, max_workers));
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(njobs * workers), dim3(64 * NW), lds, s, d_frames, d_jobs, njobs, workers);
+// ---- K1 launch: the tile search as a work queue of superblocks (tile_search.h) ----
+// Persistent workgroups: as many as the device holds at once for this instantiation (asked from the runtime, not assumed), capped by the number of items.
+template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+  const size_t lds = k1_lds_bytes<MAXBS, NW>();
+  static int resident[MI_MAX_DEVICES];                    // per instantiation and device; 0 = not asked yet
+  if (resident[device] == 0) {
+    hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_search_kernel<MAXBS, NW, BU>, 64 * NW, lds);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    resident[device] = std::max(1, per_cu) * std::max(1, cus);
+  }
+  const int grid = std::min(nitems, resident[device]);
+  if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
   return hipGetLastError();
-}
-#if MI_K1_QUEUE_KERNEL
-// The same search as a work queue (tile_search.h tile_search_queue_kernel): `items` = the launch's superblocks in dependency order.
-template <int MAXBS, int NW, bool BU> static hipError_t launch_search_queue_t(const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int grid, hipStream_t s) {
-  const size_t lds = k1_lds_bytes<MAXBS, NW>() + (NW == 4 && MAXBS == 2 ? k1_lds_pad() : 0);
-  hipError_t e = hipFuncSetAttribute((const void *)tile_search_queue_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((tile_search_queue_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
-  return hipGetLastError();
-}
-// persistent workgroups of the queue launch; MI_K1_QUEUE_WG_PER_CU=n (experiments, 16x16 class) asks for fewer than the build's launch bound allows
-static int k1_resident(int maxbs) {
-  static const int per_cu = [] { const char *v = getenv("MI_K1_QUEUE_WG_PER_CU"); const int n = v ? atoi(v) : 0; return n > 0 && n < MI_K1_WG_PER_CU ? n : MI_K1_WG_PER_CU; }();
-  return (maxbs <= 2 ? per_cu : 1) * 256;
 }
 static size_t k1_snap_bytes(int maxbs) { return maxbs <= 2 ? MI_SNAP_BYTES_ALL(16) : (maxbs == 3 ? MI_SNAP_BYTES_ALL(32) : MI_SNAP_BYTES_ALL(64)); }
-static hipError_t launch_search_queue(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const uint32_t *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, hipStream_t s) {
-  if (nitems <= 0) return hipSuccess;
-  const int grid = std::min(nitems, k1_resident(maxbs));
+// every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch; the
+// jobs must all belong to frames of the same block-size class (one instantiation per class).  grid_out != nullptr: only report the grid.
+static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+  if (nitems <= 0) { if (grid_out) *grid_out = 0; return hipSuccess; }
   if (bottomup) {
-    if (maxbs <= 2) return launch_search_queue_t<2, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
-    if (maxbs == 3) return launch_search_queue_t<3, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
-    return launch_search_queue_t<4, 1, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+    return launch_search_t<4, 1, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
   }
-  if (maxbs <= 2) return launch_search_queue_t<2, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
-  if (maxbs == 3) return launch_search_queue_t<3, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
-  return launch_search_queue_t<4, 1, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid, s);
+  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+  return launch_search_t<4, 1, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);     // 64x64 blocks: alpha (4:0:0) frames only
 }
-#endif
 // jobs must all belong to frames of the same block-size class
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
 static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  const int k4_threads = MI_K4_THREADS;                   // MI_K4_PIPE: a walker wave and a range-coder wave per tile (tile_entropy.h)
+  const int k4_threads = MI_K4_THREADS;
   if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
   else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
-#if MI_K4_PIPE == 3
-  // the walker above has left the tiles' record streams in HBM: adapters (one wave per tile and adapter), then the range coder (one wave per tile)
-  if (maxbs <= 2) hipLaunchKernelGGL((k4_adapt_kernel<2>), dim3(njobs * MI_K4_ADAPTERS), dim3(64), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
-  else hipLaunchKernelGGL((k4_adapt_kernel<4>), dim3(njobs * MI_K4_ADAPTERS), dim3(64), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
-  hipLaunchKernelGGL(k4_code_kernel, dim3(njobs), dim3(64), 0, s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
-#endif
   return hipGetLastError();
 }
-// every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch
-static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, int max_workers, hipStream_t s) {
-  if (njobs <= 0) return hipSuccess;
-  if (bottomup) {
-    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, njobs, max_workers, s);
-    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, njobs, max_workers, s);
-    return launch_search_t<4, 1, true>(d_frames, d_jobs, njobs, max_workers, s);
-  }
-  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, njobs, max_workers, s);
-  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, njobs, max_workers, s);
-  return launch_search_t<4, 1, false>(d_frames, d_jobs, njobs, max_workers, s);     // 64x64 blocks: alpha (4:0:0) frames only
-}
 
+// The work list of a set of tile jobs (grouped by block-size class, class_begin[2..5]) and the device objects a queue launch needs: the items, the claim
+// counters (self-resetting: the last workgroup to leave a launch zeroes its pair), one snapshot area per persistent workgroup.
+struct FramePlan;
+struct SearchQueue {
+  std::vector<SbItem> items; int q_begin[6] = { 0, 0, 0, 0, 0, 0 };
+  SbItem *d_items = nullptr; SbItem *h_items = nullptr; size_t items_cap = 0; int *d_next = nullptr; uint8_t *d_snap = nullptr; size_t snap_bytes = 0;
+  void free_device() {
+    if (d_items) (void)hipFree(d_items); if (h_items) (void)hipHostFree(h_items); if (d_next) (void)hipFree(d_next); if (d_snap) (void)hipFree(d_snap);
+    d_items = nullptr; h_items = nullptr; d_next = nullptr; d_snap = nullptr; items_cap = 0; snap_bytes = 0;
+  }
+};
 }  // namespace mi
 namespace mi {
 // The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
@@ -273,6 +243,45 @@ static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_m
   return hipGetLastError();
 }
 
+}  // namespace mi
+
+namespace mi {
+// Builds the launch's work list -- per block-size class, the superblocks of the class's tiles in (2 * row + column, job) order; jobs are indexed inside
+// their class segment of d_jobs -- and enqueues one queue launch per class on `s`.
+static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
+  q.items.clear();
+  size_t snap_need = 0;
+  const bool bottomup = !frames.empty() && frames[0].cfg.encode_bottomup != 0;
+  for (int cls = 2; cls <= 4; cls++) {
+    q.q_begin[cls] = (int)q.items.size();
+    std::vector<std::vector<SbItem>> by_key;
+    for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
+      const TileJob &tj = jobs[j]; const FramePlan &p = frames[tj.frame];
+      const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
+      const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
+      if ((int)by_key.size() < 2 * rows + cols) by_key.resize(2 * rows + cols);
+      for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) by_key[2 * r + c].push_back(SbItem{ (uint32_t)(j - class_begin[cls]), (uint16_t)r, (uint16_t)c });
+    }
+    for (auto &v : by_key) q.items.insert(q.items.end(), v.begin(), v.end());
+    const int nitems = (int)q.items.size() - q.q_begin[cls];
+    int grid = 0;
+    HIP_OK(launch_search(cls, bottomup, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
+    snap_need = std::max(snap_need, (size_t)grid * k1_snap_bytes(cls));
+  }
+  q.q_begin[5] = (int)q.items.size();
+  if (q.items.size() > q.items_cap) {
+    if (q.d_items) (void)hipFree(q.d_items); if (q.h_items) (void)hipHostFree(q.h_items);
+    q.d_items = nullptr; q.h_items = nullptr; q.items_cap = q.items.size() + q.items.size() / 8;
+    HIP_OK(hipMalloc(&q.d_items, q.items_cap * sizeof(SbItem))); HIP_OK(hipHostMalloc(&q.h_items, q.items_cap * sizeof(SbItem)));
+  }
+  if (!q.d_next) { HIP_OK(hipMalloc(&q.d_next, 16 * sizeof(int))); HIP_OK(hipMemsetAsync(q.d_next, 0, 16 * sizeof(int), s)); }   // once: every launch leaves its pair zeroed
+  if (snap_need > q.snap_bytes) { if (q.d_snap) (void)hipFree(q.d_snap); q.d_snap = nullptr; q.snap_bytes = snap_need; HIP_OK(hipMalloc(&q.d_snap, snap_need)); }
+  memcpy(q.h_items, q.items.data(), q.items.size() * sizeof(SbItem));
+  HIP_OK(hipMemcpyAsync(q.d_items, q.h_items, q.items.size() * sizeof(SbItem), hipMemcpyHostToDevice, s));
+  for (int cls = 2; cls <= 4; cls++)
+    HIP_OK(launch_search(cls, bottomup, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
+  return MI_OK;
+}
 }  // namespace mi
 
 using namespace mi;
@@ -294,9 +303,7 @@ struct mi_batch {
   int *h_alpha = nullptr; FrameDev *h_frames = nullptr; TileJob *h_jobs = nullptr;   // pinned: alpha flags (D2H), frame descriptors and tile jobs (H2D sources)
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
   std::vector<TileJob> jobs;
-  // MI_K1_QUEUE=1: the tile search as a work queue -- the superblocks of each block-size class in dependency order, the claim counters, one snapshot area per
-  // persistent workgroup (allocated on first use)
-  std::vector<uint32_t> q_items; uint32_t *d_q_items = nullptr; size_t q_items_cap = 0; int *d_q_next = nullptr; uint8_t *d_q_snap = nullptr; size_t q_snap_bytes = 0;
+  SearchQueue queue;                                               // the tile search's work list and its device objects (allocated on first use)
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
   hipEvent_t ev[8]{}; double stage_ms[8]{};
   bool planned = false, in_flight = false;
@@ -329,9 +336,7 @@ static void batch_free_device(mi_batch *b) {
   if (b->d_precarry) (void)hipFree(b->d_precarry); b->d_precarry = nullptr;
   if (b->d_offsets) (void)hipFree(b->d_offsets); b->d_offsets = nullptr;
   if (b->d_prof) (void)hipFree(b->d_prof); b->d_prof = nullptr;
-  if (b->d_q_items) (void)hipFree(b->d_q_items); b->d_q_items = nullptr;
-  if (b->d_q_next) (void)hipFree(b->d_q_next); b->d_q_next = nullptr;
-  if (b->d_q_snap) (void)hipFree(b->d_q_snap); b->d_q_snap = nullptr;
+  b->queue.free_device();
   if (b->d_packed) (void)hipFree(b->d_packed); b->d_packed = nullptr;
   if (b->h_packed) (void)hipHostFree(b->h_packed); b->h_packed = nullptr;
   if (b->h_lens) (void)hipHostFree(b->h_lens); b->h_lens = nullptr;
@@ -358,9 +363,9 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_frames, sizeof(FrameDev) * worst.size()));
   HIP_OK(hipMalloc(&b->d_jobs, sizeof(TileJob) * max_tiles));
   b->pre_cap = max_cap;
-  HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * MI_K4_PRE_STRIDE(max_cap) * 2));
+  HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * (size_t)max_cap * 2));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
-  HIP_OK(hipMalloc(&b->d_prof, max_tiles * 128 * 8));
+  HIP_OK(hipMalloc(&b->d_prof, std::max<size_t>(max_tiles, 2048) * 128 * 8));   // profiling builds: per tile job (K4) / per persistent workgroup (K1)
   // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
   // usual case a few per cent of it: start at 1/16 and let mi_batch_wait grow the pair when a run needs more.
   b->packed_max = std::min<size_t>(packed, (size_t)1 << 31);
@@ -555,48 +560,14 @@ int mi_batch_encode_async(mi_batch *b) {
   { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
     hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
   HIP_OK(hipEventRecord(b->ev[1], s));
-#if MI_K1_QUEUE_KERNEL
-  static const bool use_queue = [] { const char *v = getenv("MI_K1_QUEUE"); return v && atoi(v) > 0; }();
-  if (use_queue) {
-    // one item per superblock of every tile, per class in (2 * row + column, job) order; jobs are indexed inside their class segment of d_jobs
-    b->q_items.clear();
-    int q_begin[6] = { 0, 0, 0, 0, 0, 0 }; size_t snap_need = 0;
-    for (int cls = 2; cls <= 4; cls++) {
-      q_begin[cls] = (int)b->q_items.size();
-      std::vector<std::pair<uint32_t, uint32_t>> keyed;
-      for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
-        const TileJob &tj = b->jobs[j]; const FramePlan &p = b->frames[tj.frame];
-        const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
-        const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
-        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) keyed.push_back({ (uint32_t)(2 * r + c), MI_QITEM(j - class_begin[cls], r, c) });
-      }
-      std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c2) { return a.first < c2.first; });
-      for (auto &kv : keyed) b->q_items.push_back(kv.second);
-      if (!keyed.empty()) snap_need = std::max(snap_need, (size_t)std::min<int>((int)keyed.size(), k1_resident(cls)) * k1_snap_bytes(cls));
-    }
-    q_begin[5] = (int)b->q_items.size();
-    if (b->q_items.size() > b->q_items_cap) { if (b->d_q_items) (void)hipFree(b->d_q_items); b->q_items_cap = b->q_items.size(); HIP_OK(hipMalloc(&b->d_q_items, b->q_items_cap * 4)); }
-    if (!b->d_q_next) HIP_OK(hipMalloc(&b->d_q_next, 8 * sizeof(int)));
-    if (snap_need > b->q_snap_bytes) { if (b->d_q_snap) (void)hipFree(b->d_q_snap); b->q_snap_bytes = snap_need; HIP_OK(hipMalloc(&b->d_q_snap, snap_need)); }
-    HIP_OK(hipMemcpyAsync(b->d_q_items, b->q_items.data(), b->q_items.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_OK(hipMemsetAsync(b->d_q_next, 0, 8 * sizeof(int), s));
-    for (int cls = 2; cls <= 4; cls++)
-      HIP_OK(launch_search_queue(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], b->d_q_items + q_begin[cls], q_begin[cls + 1] - q_begin[cls],
-                                 b->d_q_next + cls, b->d_q_snap, s));
-  } else
-#endif
-  for (int cls = 2; cls <= 4; cls++) {
-    int max_workers = MI_K1_MAX_WORKERS;
-    for (auto &p : b->frames) if (std::max(p.maxbs, 2) == cls) max_workers = std::min(max_workers, p.dev.snap_rows);
-    HIP_OK(launch_search(cls, b->frames[0].cfg.encode_bottomup != 0, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], max_workers, s));
-  }
+  if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
   // ---- K2a/K2 deblock (level search + filter), K3 CDEF
   HIP_OK(hipEventRecord(b->ev[2], s));
   HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * MI_K4_PRE_STRIDE(b->pre_cap), b->pre_cap, s));
+    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap, s));
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -919,8 +890,8 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   p.arena_bytes = carve(p, nullptr, cap);
   // every device allocation and the stream are owned by this guard: all return paths release them
   struct Guard {
-    hipStream_t s = nullptr; uint8_t *arena = nullptr; FrameDev *d_frame = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_pre = nullptr;
-    ~Guard() { if (d_frame) (void)hipFree(d_frame); if (d_jobs) (void)hipFree(d_jobs); if (d_pre) (void)hipFree(d_pre); if (arena) (void)hipFree(arena); if (s) (void)hipStreamDestroy(s); }
+    hipStream_t s = nullptr; uint8_t *arena = nullptr; FrameDev *d_frame = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_pre = nullptr; SearchQueue queue;
+    ~Guard() { queue.free_device(); if (d_frame) (void)hipFree(d_frame); if (d_jobs) (void)hipFree(d_jobs); if (d_pre) (void)hipFree(d_pre); if (arena) (void)hipFree(arena); if (s) (void)hipStreamDestroy(s); }
   } g;
   HIP_OK(hipStreamCreate(&g.s));
   hipStream_t s = g.s;
@@ -938,13 +909,18 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
-  HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * MI_K4_PRE_STRIDE(cap) * 2));
+  HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * (size_t)cap * 2));
   FrameDev *d_frame = g.d_frame; TileJob *d_jobs = g.d_jobs; uint16_t *d_pre = g.d_pre;
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
   hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
-  HIP_OK(launch_search(p.maxbs, p.cfg.encode_bottomup != 0, d_frame, d_jobs, njobs, p.dev.snap_rows, s));
+  {
+    int class_begin[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int cls = std::max(p.maxbs, 2) + 1; cls <= 5; cls++) class_begin[cls] = njobs;
+    std::vector<FramePlan> one(1, p);
+    if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
+  }
   HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
   HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
   HIP_OK(hipGetLastError());

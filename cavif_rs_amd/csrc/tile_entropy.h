@@ -9,46 +9,17 @@
 #include "dev_rate.h"
 #include "restoration.h"
 
-// MI_K4_PIPE (build option, measured next round -- DESIGN.md section 9): two wavefronts per tile.  Wave 1 walks the tile exactly as the single
-// wave does -- contexts, CDF rows, adaptation -- but instead of range-coding a symbol it appends its bounds to a ring in LDS; wave 0 pops the records
-// and does nothing but the range arithmetic and the byte output.  Record: bit 31 = literal (value in 0..19, bit count in 20..24), else fl >> 6 in 0..9
-// (512 = the top of the range), fh >> 6 in 10..19, the symbol in 20..23, nsyms - 1 in 24..27.  The producer publishes `head` after every block
-// header / transform block; LDS executes one wave's operations in order, so a consumer that sees head = h finds the records below h written.
-// MI_K4_PIPE == 2: three stages, 2 + MI_K4_ADAPTERS wavefronts per tile.  A CDF's state depends only on the symbols coded through that row, never on the
-// coder state, so the walker (wave 1) does not touch the CDFs at all: it appends `(row, symbol, alphabet)` records (bit 30 set, the row's offset in 0..13).
-// Adapter wave a owns the rows with k4_row_owner() == a: it scans the ring behind the walker, turns each of ITS records into the bounds record above in
-// place (read the row, pick fl / fh, adapt) and publishes how far it has scanned (ctl[4 + a]); the coder (wave 0) consumes up to the slowest adapter.
-// The longest chain is the busiest adapter's share of the symbols (a tile uses ~330 rows, the hottest carries about a third of the symbols).
-#ifndef MI_K4_PIPE
-#define MI_K4_PIPE 0
-#endif
-#ifndef MI_K4_ADAPTERS
-#define MI_K4_ADAPTERS 4
-#endif
-#define MI_K4_THREADS (MI_K4_PIPE == 2 ? 64 * (2 + MI_K4_ADAPTERS) : (MI_K4_PIPE == 1 ? 128 : 64))
-// MI_K4_PIPE == 3: the same three stages as three KERNELS, the record stream of a tile in HBM instead of an LDS ring -- no wave ever waits for another:
-// tile_entropy_kernel (walker, one wave per tile) writes the records and their count, k4_adapt_kernel (one wave per (tile, adapter)) converts its rows'
-// records in place, k4_code_kernel (one wave per tile) range-codes the finished stream.  The stream lives behind the tile's pre-carry units:
-// per tile [cap u16 pre-carry | MI_K4_SCAP(cap) u32 records | count], MI_K4_PRE_STRIDE(cap) u16 units apart.
-#define MI_K4_SCAP(cap) (MI_K4_PIPE == 3 ? 2u * (uint32_t)(cap) : 0u)                      /* records per tile: 4 per sample of the tile */
-#define MI_K4_PRE_STRIDE(cap) ((size_t)(cap) + (MI_K4_PIPE == 3 ? 2 * (size_t)MI_K4_SCAP(cap) + 8 : 0))
-#define MI_K4_RING 2048
+// Three pipelined forms of this kernel (walker wave + range-coder wave; walker | four CDF-adapter waves | coder through an LDS ring; the same
+// three stages as three kernels with the record stream in HBM) were measured on the MI355X in round 3 and all lost against the single wave
+// (43.5 ms per 1024 tiles: 44.0 / 46.0 / 75.9 ms, profiles/r03_variants_ab.txt); they are not in the tree.
+#define MI_K4_THREADS 64
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;
   uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
-#if MI_K4_PIPE
-  LDS uint32_t *ring; LDS volatile uint32_t *ctl;      // ctl[0] = head (producer), ctl[1] = tail (consumer), ctl[2] = done, ctl[4 + a] = adapter a's position
-  LDS uint16_t *cdf_base;                               // MI_K4_PIPE >= 2: row offsets in the records are relative to it
-  uint32_t *stream; uint32_t scap;                      // MI_K4_PIPE == 3: the tile's record stream in HBM
-  uint32_t h, tail_seen;                                // producer: records written / the consumer's tail as last read
-#endif
 };
 
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
   e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9;
-#if MI_K4_PIPE
-  e->h = 0; e->tail_seen = 0;
-#endif
 }
 __device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) {
   if (e->offs < e->cap && LANE == 0) e->pre[e->offs] = v;   // offs counts every unit, stored or not: overflow <=> offs > cap at the end (re_finish_dev)
@@ -68,69 +39,8 @@ __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, u
   }
   e->low = low << d; e->rng = rng << d; e->cnt = s;
 }
-#if MI_K4_PIPE == 3
-__device__ __forceinline__ void pipe_publish(RangeEncDev *) {}
-__device__ __forceinline__ void pipe_reserve(RangeEncDev *, uint32_t) {}
-__device__ __forceinline__ void pipe_store(RangeEncDev *e, uint32_t at, uint32_t rec) { if (at < e->scap) e->stream[at] = rec; }   // a stream that overflows is reported through its count
-__device__ __forceinline__ void pipe_emit(RangeEncDev *e, uint32_t rec) { if (LANE == 0) pipe_store(e, e->h, rec); e->h++; }
-#elif MI_K4_PIPE
-__device__ __forceinline__ void pipe_store(RangeEncDev *e, uint32_t at, uint32_t rec) { e->ring[at & (MI_K4_RING - 1)] = rec; }
-__device__ __forceinline__ void pipe_publish(RangeEncDev *e) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (LANE == 0) e->ctl[0] = e->h;
-}
-__device__ __forceinline__ void pipe_emit(RangeEncDev *e, uint32_t rec) {
-  if (e->h - e->tail_seen >= MI_K4_RING) {                       // wave-uniform: the ring looks full -- publish, then wait for the consumer
-    pipe_publish(e);
-    for (;;) {
-      const uint32_t t = (uint32_t)uni32((int)e->ctl[1]);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      e->tail_seen = t;
-      if (e->h - t < MI_K4_RING) break;
-      __builtin_amdgcn_s_sleep(4);
-    }
-  }
-  if (LANE == 0) e->ring[e->h & (MI_K4_RING - 1)] = rec;
-  e->h++;
-}
-#endif
-#if MI_K4_PIPE
-#if MI_K4_PIPE == 2
-// room for n more records (wave-uniform n <= 64 * 5), then the lanes write theirs side by side (code_coeffs_lane0)
-__device__ __forceinline__ void pipe_reserve(RangeEncDev *e, uint32_t n) {
-  if (e->h + n - e->tail_seen > MI_K4_RING) {
-    pipe_publish(e);
-    for (;;) {
-      const uint32_t t = (uint32_t)uni32((int)e->ctl[1]);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      e->tail_seen = t;
-      if (e->h + n - t <= MI_K4_RING) break;
-      __builtin_amdgcn_s_sleep(4);
-    }
-  }
-}
-#endif
-#if MI_K4_PIPE >= 2
-// exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl(x, imax_(LANE - d, 0)); if (LANE >= d) x += t; }
-  *total = __builtin_amdgcn_readlane(x, 63);
-  return x - v;
-}
-#endif
-__device__ __forceinline__ void re_encode_core(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms);
-// producer side: the symbol's bounds go to the ring
-__device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
-  pipe_emit(e, (fl >> 6) | ((fh >> 6) << 10) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24));
-}
-__device__ __forceinline__ void re_encode_core(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
-  uint32_t l = e->low; uint32_t r = e->rng;
-#else
 __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
   uint32_t l = e->low; uint32_t r = e->rng;
-#endif
   const int N = nsyms - 1;
   if (fl < 32768) {
     const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4 * (uint32_t)(N - (s - 1));
@@ -148,10 +58,6 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 // of a loop) -- one LDS round trip per symbol instead of three dependent ones.
 __device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s_in, LDS uint16_t *icdf, int nsyms_in) {
   const int s = uni32(s_in), nsyms = uni32(nsyms_in);
-#if MI_K4_PIPE >= 2
-  pipe_emit(e, 0x40000000u | (uint32_t)uni32((int)(icdf - e->cdf_base)) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24));
-  return;
-#endif
   const int i = LANE;
   const int v = icdf[imin_(i, nsyms)];
   const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(v, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
@@ -168,127 +74,8 @@ __device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit_in, uint32_t
 }
 __device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, int nbits_in) {
   const uint32_t v = (uint32_t)uni32((int)v_in); const int nbits = uni32(nbits_in);
-#if MI_K4_PIPE
-  if (nbits > 0) pipe_emit(e, 0x80000000u | (v & 0xFFFFFu) | ((uint32_t)nbits << 20));
-#else
   for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
-#endif
 }
-#if MI_K4_PIPE
-#if MI_K4_PIPE >= 2
-// which adapter wave owns a CDF row (static: a row's symbols must all pass through one wave, in order); every adapter evaluates it for every record
-__device__ __forceinline__ int k4_row_owner(uint32_t row) {
-  static_assert((MI_K4_ADAPTERS & (MI_K4_ADAPTERS - 1)) == 0, "the low bits of the row offset pick the adapter");
-  return (int)(row & (uint32_t)(MI_K4_ADAPTERS - 1));   // the hot tables have strides 5 and 3: neighbouring contexts, and the same context of neighbouring transform sizes (210 apart), land on different waves
-}
-// One record through adapter `a` (wave-uniform `rec`): true when it is one of its rows' records -- *out = the bounds record that replaces it, the row adapted.
-__device__ __forceinline__ bool k4_adapt_record(LDS uint16_t *cdf_base, uint32_t rec, int a, uint32_t *out) {
-  if (!(rec & 0x40000000u) || (rec & 0x80000000u)) return false;         // literal / bounds record (or a row record its owner has already converted)
-  const uint32_t row = rec & 0xFFFFu;
-  if (k4_row_owner(row) != a) return false;
-  if (rec & 0x20000000u) {                                               // write_partition_symbol at a frame edge: P(split-ish partitions) of the row as it stands, not adapted
-    const int cv = cdf_base[row + imin_(LANE, 10)];
-    uint32_t psum = 0;
-    const uint32_t set = (rec & 0x10000u) ? 0x2DCu : 0x17Au;              // has_cols: partitions 2, 3, 4, 6, 7, 9; else 1, 3, 4, 5, 6, 8
-#pragma unroll
-    for (int i2 = 1; i2 < 10; i2++)
-      if ((set >> i2) & 1u) psum += (uint32_t)__builtin_amdgcn_readlane(cv, i2 - 1) - (uint32_t)__builtin_amdgcn_readlane(cv, i2);
-    *out = (psum >> 6) | (1u << 20) | (1u << 24);
-    return true;
-  }
-  const int s = (int)((rec >> 20) & 15u), nsyms = (int)((rec >> 24) & 15u) + 1;
-  LDS uint16_t *icdf = cdf_base + row;
-  const int i = LANE;
-  const int cv = icdf[imin_(i, nsyms)];
-  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(cv, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(cv, s);
-  const int cnt = __builtin_amdgcn_readlane(cv, nsyms);
-  const uint32_t fl = s > 0 ? fl0 : 32768u;
-  *out = (fl >> 6) | ((fh >> 6) << 10) | ((uint32_t)s << 20) | ((uint32_t)(nsyms - 1) << 24);
-  const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
-  if (i < nsyms - 1) icdf[i] = (uint16_t)(i < s ? cv + ((32768 - cv) >> rate) : cv - (cv >> rate));
-  else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
-  WAVE_SYNC();
-  return true;
-}
-// one finished record through the range coder.  Works on the record's 10-bit bounds directly and without a branch for the first-symbol case
-// (fl6 = 512 is the top of the range: u = rng, nothing is added to low) -- the same arithmetic as re_encode_core.
-__device__ __forceinline__ void k4_code_bounds(RangeEncDev *e, uint32_t rec) {
-  const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms = ((rec >> 24) & 15u) - ((rec >> 20) & 15u);   // N - s
-  const uint32_t r = e->rng, r8 = r >> 8;
-  const uint32_t v = ((r8 * fh6) >> 1) + 4u * nms;
-  const uint32_t u = fl6 >= 512u ? r : ((r8 * fl6) >> 1) + 4u * nms + 4u;
-  re_normalize_dev(e, e->low + (r - u), u - v);
-}
-__device__ __forceinline__ void k4_code_record(RangeEncDev *e, uint32_t rec) {
-  if (rec & 0x80000000u) {                                                // literal: its bits as equiprobable bools, most significant first
-    const uint32_t val = rec & 0xFFFFFu;
-    for (int i = (int)((rec >> 20) & 31) - 1; i >= 0; i--) k4_code_bounds(e, ((val >> i) & 1u) ? (256u | (1u << 20) | (1u << 24)) : (512u | (256u << 10) | (1u << 24)));
-  } else k4_code_bounds(e, rec);
-}
-#endif
-#if MI_K4_PIPE == 2
-// adapter wave `a`: scans the records behind the walker; its own rows' records become bounds records in place
-__device__ __forceinline__ void pipe_adapt(RangeEncDev *e, int a) {
-  uint32_t m = 0;
-  for (;;) {
-    uint32_t h = (uint32_t)uni32((int)e->ctl[0]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (h == m) {
-      if (uni32((int)e->ctl[2])) { h = (uint32_t)uni32((int)e->ctl[0]); if (h == m) break; }
-      else { __builtin_amdgcn_s_sleep(2); continue; }
-    }
-    while (m != h) {
-      const uint32_t chunk = (h - m) < 64u ? (h - m) : 64u;
-      const uint32_t v = e->ring[(m + (uint32_t)LANE) & (MI_K4_RING - 1)];
-      for (uint32_t j = 0; j < chunk; j++) {
-        uint32_t out;
-        if (k4_adapt_record(e->cdf_base, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j), a, &out) && LANE == 0) e->ring[(m + j) & (MI_K4_RING - 1)] = out;
-      }
-      m += chunk;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (LANE == 0) e->ctl[4 + a] = m;
-    }
-  }
-}
-#endif
-#if MI_K4_PIPE == 1 || MI_K4_PIPE == 2
-// consumer side (wave 0): pops records until the producer is done, 64 at a time into a register
-__device__ __forceinline__ void pipe_consume(RangeEncDev *e) {
-  uint32_t t = 0;
-  for (;;) {
-#if MI_K4_PIPE == 2
-    uint32_t h = (uint32_t)uni32((int)e->ctl[4]);                  // as far as the slowest adapter has come
-#pragma unroll
-    for (int a = 1; a < MI_K4_ADAPTERS; a++) { const uint32_t ma = (uint32_t)uni32((int)e->ctl[4 + a]); if ((int)(ma - h) < 0) h = ma; }
-#else
-    uint32_t h = (uint32_t)uni32((int)e->ctl[0]);
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (h == t) {
-      if (uni32((int)e->ctl[2]) && (uint32_t)uni32((int)e->ctl[0]) == t) break;      // the walker is done and everything it wrote has been consumed
-      __builtin_amdgcn_s_sleep(4); continue;
-    }
-    while (t != h) {
-      const uint32_t chunk = (h - t) < 64u ? (h - t) : 64u;
-      const uint32_t v = e->ring[(t + (uint32_t)LANE) & (MI_K4_RING - 1)];
-      for (uint32_t j = 0; j < chunk; j++) {
-        const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j);
-        if (rec & 0x80000000u) {
-          const uint32_t val = rec & 0xFFFFFu; const int nbits = (int)((rec >> 20) & 31);
-          for (int i = nbits - 1; i >= 0; i--) { const int bit = (int)((val >> i) & 1); re_encode_core(e, bit ? 16384u : 32768u, bit ? 0u : 16384u, bit, 2); }
-        } else {
-          const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u;
-          re_encode_core(e, fl6 << 6, fh6 << 6, (int)((rec >> 20) & 15), (int)((rec >> 24) & 15) + 1);
-        }
-      }
-      t += chunk;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (LANE == 0) e->ctl[1] = t;
-    }
-  }
-}
-#endif
-#endif
 // returns number of bytes; out must hold them.  (lane 0)
 __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
   unsigned long long l = e->low; int c = e->cnt; int s = 10;
@@ -405,50 +192,6 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
     re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
     if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
   }
-#if MI_K4_PIPE >= 2
-  // The walker only EMITS records, so a transform block's symbols need no serial loop: lane j takes the j-th position in coding order, counts its
-  // records (base level + up to four base-range symbols; then sign + Golomb literals), an exclusive scan places them, the lanes write side by side.
-  for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
-    const int c = cb + 63 - LANE;                            // levels are coded from the last position down
-    const bool valid = c < eob;
-    const int li = imin_(c, eob - 1);
-    const uint32_t r_lv = w->rec_lv[li]; const uint32_t r_off = w->rec_off[li], r_br = w->rec_br[li];
-    const int level = valid ? (int)(r_lv >> 1) : 0;
-    const int nbr = level > 2 ? imin_(4, (level - 3) / 3 + 1) : 0;
-    int total; const int off = wave_excl_scan_i32(valid ? 1 + nbr : 0, &total);
-    pipe_reserve(e, (uint32_t)total);
-    if (valid) {
-      const uint32_t at = e->h + (uint32_t)off;
-      pipe_store(e, at, 0x40000000u | r_off | (c == eob - 1 ? ((uint32_t)(imin_(level, 3) - 1) << 20) | (2u << 24) : ((uint32_t)imin_(level, 3) << 20) | (3u << 24)));
-      int rem = level - 3;
-      for (int k2 = 0; k2 < nbr; k2++) { const int s2 = imin_(rem, 3); pipe_store(e, at + 1 + (uint32_t)k2, 0x40000000u | r_br | ((uint32_t)s2 << 20) | (3u << 24)); rem -= s2; }
-    }
-    WAVE_SYNC();
-    e->h += (uint32_t)total;
-  }
-  K4PH(4); K4CNT(11, eob);
-  const uint32_t dc_row = (uint32_t)(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE);
-  for (int cb = 0; cb < eob; cb += 64) {
-    const int c = cb + LANE;                                 // signs and Golomb tails from the first position up
-    const uint32_t m = w->rec_lv[imin_(c, eob - 1)];
-    const int a = c < eob ? (int)(m >> 1) : 0, neg = (int)(m & 1);
-    const uint32_t xg = (uint32_t)imax_(a - 14, 1); const int len = 32 - __clz(xg);
-    const int n = a ? 1 + (a > 14 ? (len > 1) + 1 : 0) : 0;
-    int total; const int off = wave_excl_scan_i32(n, &total);
-    pipe_reserve(e, (uint32_t)total);
-    if (a) {
-      uint32_t at = e->h + (uint32_t)off;
-      pipe_store(e, at++, c == 0 ? (0x40000000u | dc_row | ((uint32_t)neg << 20) | (1u << 24))
-                                 : (neg ? (256u | (1u << 20) | (1u << 24)) : (512u | (256u << 10) | (1u << 24))));   // re_bool_dev(neg, 16384)
-      if (a > 14) {
-        if (len > 1) pipe_store(e, at++, 0x80000000u | ((uint32_t)(len - 1) << 20));
-        pipe_store(e, at, 0x80000000u | (xg & 0xFFFFFu) | ((uint32_t)len << 20));
-      }
-    }
-    WAVE_SYNC();
-    e->h += (uint32_t)total;
-  }
-#else
   // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
   for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
     const int li = imin_(cb + LANE, eob - 1);
@@ -478,7 +221,6 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
       }
     }
   }
-#endif
   K4PH(5);
 }
 
@@ -533,9 +275,6 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
     re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   K4PH(1); K4CNT(8, 1);
-#if MI_K4_PIPE
-  pipe_publish(&w->ec);
-#endif
   if (skip) return;                                    // wave-uniform
   // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
   for (int p = 0; p < w->np; p++) {
@@ -564,9 +303,6 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
       txb_ctx_dev(f, t, p, rr, cc, txs, BS, &sctx2, &dctx);
       K4PH(2);
       code_coeffs_lane0(w, eob, p, txs, txtype, sctx2, dctx, off, sym, ns);
-#if MI_K4_PIPE
-      pipe_publish(&w->ec);
-#endif
     }
   }
   WAVE_SYNC();
@@ -663,17 +399,12 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
   const int ns = bs == BS_8 ? 4 : 10;
   if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
   else if (has_rows || has_cols) {
-#if MI_K4_PIPE >= 2
-    // the split-or-not bool at a frame edge is priced from the row's CURRENT state: its owner derives it in coding order (bit 29, bit 16 = has_cols)
-    pipe_emit(&w->ec, 0x60000000u | (uint32_t)uni32((int)(cdf - w->ec.cdf_base)) | (has_cols ? 0x10000u : 0u));
-#else
 #define PP_(i) ((uint32_t)((i) > 0 ? cdf[(i) - 1] : 32768) - cdf[i])
     uint32_t psum;
     if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
     else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
 #undef PP_
     re_bool_dev(&w->ec, 1, (uint32_t)U_(psum));
-#endif
   }
   if (!(has_rows && has_cols)) part = 3;
   K4PH(0);
@@ -765,16 +496,7 @@ template <int CS> struct EntropyLds {
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
   uint16_t lr_cdf[4]; int lr_ref[6];
-#if MI_K4_PIPE == 1 || MI_K4_PIPE == 2
-  uint32_t ring[MI_K4_RING]; uint32_t ctl[4 + MI_K4_ADAPTERS];
-#endif
 };
-#if MI_K4_PIPE == 3
-// where a tile keeps its pre-carry units, its record stream and the stream's length (MI_K4_PRE_STRIDE)
-__device__ __forceinline__ uint16_t *k4_pre_of(uint16_t *precarry, uint32_t pre_cap, int job) { return precarry + (size_t)job * MI_K4_PRE_STRIDE(pre_cap); }
-__device__ __forceinline__ uint32_t *k4_stream_of(uint16_t *precarry, uint32_t pre_cap, int job) { return (uint32_t *)(k4_pre_of(precarry, pre_cap, job) + pre_cap); }
-__device__ __forceinline__ uint32_t *k4_len_of(uint16_t *precarry, uint32_t pre_cap, int job) { return k4_stream_of(precarry, pre_cap, job) + MI_K4_SCAP(pre_cap); }
-#endif
 
 template <int MAXBS>
 __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
@@ -800,34 +522,8 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
   if (LANE < 6) L.lr_ref[LANE] = (LANE & 1) ? 31 : -32;                                                      // Sgrproj_Xqd_Mid
   load_scans_to_lds((LDS uint16_t *)L.scans, CS);
   w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
-#if MI_K4_PIPE != 3                                            // (the three-kernel walker never reads a CDF: the adapters load them)
   for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
-#endif
-#if MI_K4_PIPE == 3
-  static_assert(sizeof(EntropyLds<16>) % 4 == 0, "");
-  re_init_dev(&w.ec, k4_pre_of(precarry, pre_cap, job), pre_cap);
-  w.ec.cdf_base = (LDS uint16_t *)L.cdf; w.ec.stream = k4_stream_of(precarry, pre_cap, job); w.ec.scap = MI_K4_SCAP(pre_cap);
-#else
   re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
-#endif
-#if MI_K4_PIPE == 1 || MI_K4_PIPE == 2
-  w.ec.ring = (LDS uint32_t *)L.ring; w.ec.ctl = (LDS volatile uint32_t *)L.ctl;
-  w.ec.cdf_base = (LDS uint16_t *)L.cdf;
-  if (threadIdx.x < 4 + MI_K4_ADAPTERS) L.ctl[threadIdx.x] = 0;
-  __syncthreads();                                             // ring control words, the tile's tables and CDFs
-  const int pipe_wave = uni32((int)(threadIdx.x >> 6));        // wave-uniform: the roles below branch on the scalar unit
-#if MI_K4_PIPE == 2
-  if (pipe_wave >= 2) { pipe_adapt(&w.ec, pipe_wave - 2); return; }
-#endif
-  if (pipe_wave == 0) {                                         // consumer: range arithmetic + byte output only
-    pipe_consume(&w.ec);
-    if (LANE == 0) {
-      uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
-      f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
-    }
-    return;
-  }
-#endif
 #if MI_PROFILE == 2
   for (int i = 0; i < 16; i++) w.prof[i] = 0;
   w.pt = clock64();
@@ -838,18 +534,6 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
     for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
       write_superblock<MAXBS>(&w, r, c);
   WAVE_SYNC();
-#if MI_K4_PIPE == 3
-  if (LANE == 0) {                                              // the stream's length (all ones: it did not fit), the walker's share of the tile clock
-    *k4_len_of(precarry, pre_cap, job) = w.ec.h <= w.ec.scap ? w.ec.h : 0xFFFFFFFFu;
-    f->tile_clk[(size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4 + 2] = clk0;
-  }
-  return;
-#elif MI_K4_PIPE
-  pipe_publish(&w.ec);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (LANE == 0) L.ctl[2] = 1;
-  return;
-#endif
   if (LANE == 0) {
     const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
     (void)ti;
@@ -862,55 +546,3 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
   }
 }
 
-#if MI_K4_PIPE == 3
-// Stage 2 as a kernel: one wavefront per (tile, adapter).  It holds the tile's CDFs in LDS (the same layout as the walker's, so the record's row offsets apply),
-// scans the tile's record stream 64 records at a time and overwrites the records of ITS rows with their bounds.  The adapters of a tile never touch the
-// same record or the same row; what another adapter has or has not converted yet is invisible to this one (either way "not mine").
-template <int MAXBS>
-__global__ __launch_bounds__(64) void k4_adapt_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
-  constexpr int CS = MAXBS <= 2 ? 16 : 32;
-  extern __shared__ __align__(16) uint8_t k4_smem[];
-  EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
-  const int job = (int)(blockIdx.x / MI_K4_ADAPTERS), a = (int)(blockIdx.x % MI_K4_ADAPTERS);
-  if (job >= njobs) return;
-  const FrameDev *f = frames + jobs[job].frame;
-  if (frame_idle(f)) return;
-  const uint32_t n = (uint32_t)uni32((int)*k4_len_of(precarry, pre_cap, job));
-  if (n == 0xFFFFFFFFu) return;
-  uint32_t *stream = k4_stream_of(precarry, pre_cap, job);
-  for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
-  if (LANE < 4) L.lr_cdf[LANE] = (uint16_t)(LANE == 0 ? 32768 - 9413 : (LANE == 1 ? 32768 - 22581 : 0));
-  WAVE_SYNC();
-  for (uint32_t m = 0; m < n; m += 64) {
-    const uint32_t chunk = (n - m) < 64u ? (n - m) : 64u;
-    const uint32_t v = stream[imin_((int)(m + (uint32_t)LANE), (int)n - 1)];
-    for (uint32_t j = 0; j < chunk; j++) {
-      uint32_t out;
-      if (k4_adapt_record((LDS uint16_t *)L.cdf, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j), a, &out) && LANE == 0) stream[m + j] = out;
-    }
-  }
-}
-// Stage 3 as a kernel: one wavefront per tile, the range arithmetic and the byte output over the finished stream.
-__global__ __launch_bounds__(64) void k4_code_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
-  const int job = blockIdx.x;
-  if (job >= njobs) return;
-  const TileJob tj = jobs[job];
-  const FrameDev *f = frames + tj.frame;
-  if (frame_idle(f)) return;                                    // the walker has written the tile's length (0)
-  const int ti = tj.tile_row * f->tile_cols + tj.tile_col;
-  const uint32_t n = (uint32_t)uni32((int)*k4_len_of(precarry, pre_cap, job));
-  if (n == 0xFFFFFFFFu) { if (LANE == 0) f->tile_len[ti] = 0xFFFFFFFFu; return; }
-  const uint32_t *stream = k4_stream_of(precarry, pre_cap, job);
-  RangeEncDev e;
-  re_init_dev(&e, k4_pre_of(precarry, pre_cap, job), pre_cap);
-  for (uint32_t t = 0; t < n; t += 64) {
-    const uint32_t chunk = (n - t) < 64u ? (n - t) : 64u;
-    const uint32_t v = stream[imin_((int)(t + (uint32_t)LANE), (int)n - 1)];
-    for (uint32_t j = 0; j < chunk; j++) k4_code_record(&e, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j));
-  }
-  if (LANE == 0) {
-    f->tile_len[ti] = re_finish_dev(&e, f->tile_out + (size_t)ti * f->tile_out_cap, f->tile_out_cap);
-    f->tile_clk[(size_t)ti * 4 + 3] = wall_clock64();
-  }
-}
-#endif

@@ -48,25 +48,12 @@
 #define PH(i) do {} while (0)
 #endif
 
-// -DMI_K1_LDS_DIET=1 (prepared variant, not the default build): the <2,4> kernel in 32 464 B of LDS instead of 40 912 -- a fifth workgroup
-// per CU, or two entropy-coder workgroups beside four searches.  What changes: ONE reconstruction / level buffer per wave (a wave's best
-// candidate so far is parked in the tile's HBM scratch instead of a second LDS buffer), the edge working copies alias the transposition
-// buffer (both are transient inside predict / evaluate), the DC prediction of the one-candidate chroma path is built in `pred`, the level
-// maps live inside the one-candidate struct (re-zeroed at the start of each one-candidate phase, the grouped path dirties them), and the
-// tx-size trial's sub-sources use wave 1's idle `pred`.  Same arithmetic, same decisions.
-#ifndef MI_K1_LDS_DIET
-#define MI_K1_LDS_DIET 0
-#endif
-#define MI_K1_DIET_N(N) (MI_K1_LDS_DIET != 0 && (N) == 16)
-#define MI_K1_PARK_WAVE 1536                       /* parked best of one wave: rec [256] u16 + qc [256] i32 */
-#define MI_K1_PARK_BYTES(N) (MI_K1_DIET_N(N) ? 4 * MI_K1_PARK_WAVE : 0)
-
-// area snapshots of the partition search + (LDS diet) the parked candidates, per (tile, row worker) in HBM
+// area snapshots of the partition search, one area per resident workgroup in HBM
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 #define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
-#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0) + MI_K1_PARK_BYTES(n))   /* + the 8x8 node's best rectangular / split candidates */
+#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0))   /* + the 8x8 node's best rectangular / split candidates */
 
-template <int N, bool DIET = MI_K1_DIET_N(N)> struct WaveScratch {            // private to one wavefront
+template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N;
   uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
   uint16_t pred[N * N], dcp[N * N];
@@ -79,20 +66,6 @@ template <int N, bool DIET = MI_K1_DIET_N(N)> struct WaveScratch {            //
     GroupPredBuf gpred[4];                         // four directional predictions at a time (SATD stages of 4x4 / 8x8 blocks)
   };
   uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
-};
-template <int N> struct WaveScratch<N, true> {
-  static constexpr int CS = N, NBUF = 1, DCP_LEN = 192;
-  uint16_t pred[N * N];
-  union {
-    struct {                                       // one candidate (16x16 blocks; the chroma path with the full mode set)
-      union { int32_t tbuf[N * (N + 1)]; struct { uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16]; }; };
-      int32_t cbuf[CS * CS], qc[1][CS * CS];
-      uint16_t rec[1][N * N];
-      uint8_t lev[LEV_BYTES(CS)];
-    };
-    struct { GroupBuf8 grp[4]; uint16_t dcp[192]; };   // four candidates (4x4 / 8x8); dcp = a plane's DC prediction / the parked best of a round
-    GroupPredBuf gpred[4];
-  };
 };
 template <int N> struct SharedScratch {          // shared by the waves of the tile
   uint16_t ra[3][EDGE_LEN(N)], rl[3][EDGE_LEN(N)];
@@ -112,12 +85,12 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
   // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
   int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
-  uint16_t ssrc[MI_K1_DIET_N(N) ? 4 : N * N], spred[(N / 2) * (N / 2)];
+  uint16_t ssrc[N * N], spred[(N / 2) * (N / 2)];
   uint8_t nb_top[16][2], nb_left[16][2];
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
   uint16_t split_rec[N <= 16 ? 1 : N * N];
   TileB tile; uint8_t *snap;                       // the tile's bounds (mi units) and its snapshot area (per-tile constants of Ctx)
-  int q_item;                                      // tile_search_queue_kernel: the work item the workgroup has just claimed
+  int q_item;                                      // the work item the workgroup has just claimed
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -292,24 +265,6 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
   if (LANE == 0) f->m_eob[plane][r * f->mi_stride + c] = (uint16_t)eob;
 }
 
-// LDS diet: a wave's best candidate so far lives in the tile's HBM scratch (written when a candidate takes the lead, read once by the
-// winning wave at commit; a wave reads back only what it wrote itself, program order suffices).  8-byte units: rec = 64, qc = 128.
-template <int MAXN, int NW> __device__ __forceinline__ uint8_t *park_of(const Ctx<MAXN, NW> k, int W) {
-  return k.snap() + MI_SNAP_BYTES_ALL(MAXN) - MI_K1_PARK_BYTES(MAXN) + W * MI_K1_PARK_WAVE;
-}
-template <int NN, int QN> __device__ __forceinline__ void park_store(uint8_t *park, const LDS uint16_t *rec, const LDS int32_t *qc) {
-  unsigned long long *pr = (unsigned long long *)park, *pq = (unsigned long long *)(park + 512);
-  const LDS unsigned long long *lr = (const LDS unsigned long long *)rec, *lq = (const LDS unsigned long long *)qc;
-  WAVE_SYNC();                                               // a lane copies samples other lanes wrote ...
-  for (int i = LANE; i < NN / 4; i += 64) pr[i] = lr[i];
-  for (int i = LANE; i < QN / 2; i += 64) pq[i] = lq[i];
-  WAVE_SYNC();                                               // ... and the next evaluation overwrites them
-}
-template <typename WS> __device__ __forceinline__ void zero_lev(LDS WS *S) {
-  for (int i = LANE; i < (int)sizeof(S->lev) / 4; i += 64) ((LDS uint32_t *)S->lev)[i] = 0;
-  WAVE_SYNC();
-}
-
 #include "dev_rect.h"
 
 // `budget`: the caller only needs to know whether the block's cost stays below it (split trials: cost of the
@@ -342,7 +297,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);                                           // DC_PRED (no neighbour) is not smooth
   const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uni32(v_uvU))) || (availL && IS_SMOOTH_(uni32(v_uvL))));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
-  constexpr bool DIET = MI_K1_DIET_N(MAXN);
   PH_BEGIN();
 
   // ---- stage the source block and the raw edges of every plane (plane p by wave p % NW) ----
@@ -548,7 +502,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       }
     }
   }
-  if constexpr (DIET) if (!grouped) zero_lev(S);
   if (!grouped)
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
@@ -574,7 +527,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
     if (j < my_j) {
       my_j = j; my_e = e; my_mode = m; my_delta = delta; my_tx = txtype; my_tr = tr; my_mrate = mode_rate;
-      if constexpr (DIET) park_store<nn, qn>(park_of(k, W), S->rec[0], S->qc[0]); else cur ^= 1;
+      cur ^= 1;
     }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
@@ -584,34 +537,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   int win = 0;
   for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
   const long long best_j = SH->wbest_j[win];
-#if MI_K1_LDS_DIET                                          // same steps; the best of a 16x16 block comes back from the HBM park
-  if (W == win) {
-    auto commit = [&](auto best_rec, auto best_qc) {
-      commit_plane<BS>(f, 0, r, c, best_rec, best_qc, my_tr.eob, my_tr.cul, my_tr.dcc);
-      fill_map_dev(f->m_ymode, ms, r, c, n4, my_mode);
-      fill_map_dev((uint8_t *)f->m_angle_y, ms, r, c, n4, (uint8_t)(int8_t)my_delta);
-      fill_map_dev(f->m_txtype, ms, r, c, n4, my_tr.eob ? my_tx : DCT_DCT);
-      fill_map_dev(f->m_bsize, ms, r, c, n4, BS);
-      fill_map_dev(f->m_txsize, ms, r, c, n4, BS);
-      if (f->np > 1) for (int i = LANE; i < nn; i += 64) SH->luma_rec[i] = best_rec[i];
-      if (LANE == 0) {
-        SH->lm_mode = my_mode; SH->lm_delta = my_delta; SH->lm_tx = my_tx; SH->lm_eob = my_tr.eob;
-        SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
-      }
-    };
-    bool done = false;
-    if constexpr (DIET) if (!grouped) { const uint8_t *pk = park_of(k, W); commit((const uint16_t *)pk, (const int32_t *)(pk + 512)); done = true; }
-    if (!done) {
-      const int b = DIET ? 0 : cur ^ 1;                       // buffer holding this wave's best
-      const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
-      if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) {
-        if (parked) { best_rec = (const LDS uint16_t *)S->dcp; best_qc = (const LDS int32_t *)(S->dcp + 64); }
-        else { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
-      }
-      commit(best_rec, best_qc);
-    }
-  }
-#else
   if (W == win) {
     const int b = cur ^ 1;                                  // buffer holding this wave's best
     const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
@@ -631,7 +556,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9;
     }
   }
-#endif
   PH(7);
   WG_SYNC();
   PH(2);
@@ -658,7 +582,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
       LDS int *const sub_tx = (LDS int *)SH->dsd, *const sub_eob = sub_tx + 16, *const sub_cul = sub_tx + 32, *const sub_dcc = sub_tx + 48, *const psv16 = sub_tx + 64;   // dsd / satd are dead after the mode decision
       LDS int *const sfl_r = (LDS int *)SH->satd, *const sfl_b = sfl_r + 4;
       LDS uint16_t *ssrc = (LDS uint16_t *)SH->ssrc;         // the sub-sources, sub-block after sub-block
-      if constexpr (DIET) ssrc = ((LDS WaveScratch<MAXN> *)(k.base + Ctx<MAXN, NW>::SH_BYTES + Ctx<MAXN, NW>::WS_BYTES))->pred;   // wave 1's pred: idle during the trial (only wave 0 predicts)
       auto trial = [&](auto depth_c) -> bool {
         constexpr int D = decltype(depth_c)::value;
         constexpr int SBS = BS - D, G = 1 << D, hn = n >> D, half = n4 >> D, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
@@ -798,7 +721,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
           const long long sub_j = SH->wbest_j[sw];
           if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
-            const LDS uint16_t *srec = S->rec[DIET ? 0 : scur ^ 1]; const LDS int32_t *sqc = S->qc[DIET ? 0 : scur ^ 1];
+            const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
             if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
             const int ro = bi * hn * n + bj * hn;
             for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
@@ -978,12 +901,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     if (cfl_allowed) push(UV_CFL_PRED);
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
     constexpr int NPAIR = 2;
-#if MI_K1_LDS_DIET
-    LDS uint16_t *dcb = S->dcp;                              // the plane's DC prediction (CfL)
-    if constexpr (DIET) { dcb = S->pred; zero_lev(S); }      // LDS diet: built in place in `pred`; the grouped evaluations before have used the level maps' memory
-#else
-#define dcb S->dcp
-#endif
     const int pair = ((W >> 1) & 1) ^ 1, active = W < 4;      // pair 0 (two plain candidates) = waves 2, 3: they have the lighter luma share
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
     // pair 0: candidates 0 and the odd ones; pair 1: the even ones from 2 on and CfL (always last) -- the winner rule
@@ -1016,11 +933,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
           lsum = wave_sum_i32(lsum);
           const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
-          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, dcb);
+          predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
           long long best_sse = J_INF; int best_idx = 1 << 20;
           if (half == 0) {
             int e0 = 0;
-            for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)dcb[idx]; e0 += __mul24(d, d); }
+            for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
             best_sse = wave_sum_i64((long long)e0); best_idx = -1;
           }
           // scan position aa = 2k is alpha +(k+1), aa = 2k+1 is -(k+1); the scaled luma term of -a is minus that of +a,
@@ -1029,7 +946,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
 #pragma unroll
           for (int a = 0; a < 16; a++) e[a] = 0;
           for (int idx = LANE; idx < nn; idx += 64) {
-            const int l = ((int)luma[idx] << 3) - avg, dcv = dcb[idx], sv = SH->srcb[p][idx];
+            const int l = ((int)luma[idx] << 3) - avg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
             const int la = iabs_(l), neg = l < 0;
 #pragma unroll
             for (int kq = 0; kq < 8; kq++) {
@@ -1069,7 +986,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
           if (um == UV_CFL_PRED) {
             const int al = p == 1 ? alpha_u : alpha_v;
-            predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, dcb);
+            predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->dcp);
             if (al) {
               // predict_cfl against the LDS copy of the luma reconstruction
               int lsum = 0;
@@ -1078,9 +995,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
               const int avg = round2_(lsum, 2 * log2w), mx = (1 << f->bd) - 1;
               for (int idx = LANE; idx < nn; idx += 64) {
                 const int l = ((int)SH->luma_rec[idx] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-                S->pred[idx] = (uint16_t)iclamp_((int)dcb[idx] + sc, 0, mx);
+                S->pred[idx] = (uint16_t)iclamp_((int)S->dcp[idx] + sc, 0, mx);
               }
-            } else if constexpr (!DIET) { for (int i = LANE; i < nn; i += 64) S->pred[i] = dcb[i]; }
+            } else { for (int i = LANE; i < nn; i += 64) S->pred[i] = S->dcp[i]; }
             WAVE_SYNC();
           } else {
             predict_block(f, x, y, log2w, availL, availU, um, delta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred);
@@ -1097,7 +1014,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
         const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (j < pb_j) {
           pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp;
-          if constexpr (DIET) park_store<nn, qn>(park_of(k, W), S->rec[0], S->qc[0]); else ccur ^= 1;
+          ccur ^= 1;
         }
       }
     }
@@ -1108,9 +1025,8 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     if ((SH->pbest_j[1] < SH->pbest_j[0] || (SH->pbest_j[1] == SH->pbest_j[0] && SH->pbest_c[1] < SH->pbest_c[0]))) wp = 1;
     const long long best_uv = SH->pbest_j[wp];
     if (active && pair == wp) {
-      const int p = (W & 1) + 1, b = DIET ? 0 : ccur ^ 1;
-      if constexpr (DIET) { const uint8_t *pk = park_of(k, W); commit_plane<BS>(f, p, r, c, (const uint16_t *)pk, (const int32_t *)(pk + 512), pb_tr.eob, pb_tr.cul, pb_tr.dcc); }
-      else commit_plane<BS>(f, p, r, c, (const LDS uint16_t *)S->rec[b], (const LDS int32_t *)S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
+      const int p = (W & 1) + 1, b = ccur ^ 1;
+      commit_plane<BS>(f, p, r, c, (const LDS uint16_t *)S->rec[b], (const LDS int32_t *)S->qc[b], pb_tr.eob, pb_tr.cul, pb_tr.dcc);
       if (LANE == 0) SH->ceob[p - 1] = pb_tr.eob;
       if (p == 1) {
         const int buv = lut4(cand_pack, pb_c);
@@ -1128,9 +1044,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     total_j += best_uv;
     (void)qn;
   }
-#if !MI_K1_LDS_DIET
-#undef dcb
-#endif
   if (DBG_IS(f, 6)) return 0;
   // ---- skip flag ----
   const int skip = !any_coef;
@@ -1350,103 +1263,38 @@ template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
 }
 
 static_assert(MI_PROFILE || k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit four workgroups per CU (160 KB LDS)");
-static_assert(!MI_K1_LDS_DIET || MI_PROFILE || k1_lds_bytes<2, 4>() <= 32768, "LDS diet: K1 <2,4> in a fifth of the CU's LDS");
-static_assert(!(MI_K1_LDS_DIET && MI_RECT_PART), "the 2:1 block search (dev_rect.h) has not been put on the LDS diet");
 
+// ---- the launch: a work queue of superblocks ----
+// Persistent workgroups (as many as fit the GPU, or one per item when there are fewer) claim superblocks from one list per launch.  An item is
+// (tile job, superblock row, superblock column inside the tile); the list is sorted by 2 * row + column (then by job), so everything an item waits
+// for -- its left neighbour and the superblock two to the right in the row above (its above-right neighbour must be final) -- sits earlier in the
+// list and has been claimed by a workgroup that is running or done: no deadlock, whatever the number of resident workgroups.  Legal because the
+// search prices against static rate tables: a superblock depends on its left / above / above-right neighbours' reconstruction, mode info and decoded
+// flags only; the block order inside a superblock and every decision are those of a serial walk of the tile.  A row's counter in f->sb_prog counts
+// its finished superblocks (they finish in column order because each waits for its left neighbour); release / acquire at device scope.
+// Measured on the MI355X (profiles/r03_variants_ab.txt): 1024 tiles of a 32 x 1080p batch, one workgroup per tile 159.5 ms, this queue 139.2 ms
+// (no resident slot idles while its tile's neighbours are still at work); it also replaces the row workers single images used to get.
+struct SbItem { uint32_t job; uint16_t sbr, sbc; };
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU>
-// `workers` workgroups per tile (row workers, x265-WPP / libaom row-mt style): worker g searches the tile's superblock rows g, g + workers, ...
-// and starts a superblock once the row above is two superblocks ahead (its above-right neighbour is final).  Legal because the search
-// prices against static rate tables: a superblock depends on its left / above / above-right neighbours' reconstruction, mode info and
-// decoded flags only; the block order inside a superblock and every decision are unchanged.  Progress per (frame SB row, tile column)
-// goes through f->sb_prog with release / acquire at device scope.  Workers of a tile sit next to each other in the grid (the one a
-// worker waits for always has a lower block id and was dispatched first).  workers == 1: one workgroup per tile, no waiting.
-__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, int workers) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
+                                                                                                          const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
   constexpr int MAXN = 4 << MAXBS;
   extern __shared__ __align__(16) uint8_t smem[];
-  const int job = blockIdx.x / workers, wk = blockIdx.x - job * workers;
-  if (job >= njobs) return;
-  const TileJob tj = jobs[job];
-  const FrameDev *gf = frames + tj.frame;
-  if (frame_idle(gf)) return;
   using K = Ctx<MAXN, NW>;
   K k;
   k.base = (LDS uint8_t *)smem;
   k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);
   LDS uint16_t *lsc = (LDS uint16_t *)(smem + K::LS_OFF);
   LDS FrameDev *lf = (LDS FrameDev *)(smem + K::F_OFF);
-  // the frame descriptor, the scan tables and the coefficient slices of the rate table are staged in LDS once per tile
-  for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];   // only the head: K1 never reads the tail through `lf`
+  // the scan tables once per workgroup; the frame descriptor head and the coefficient slices of the rate table whenever the frame changes
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
-  for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;        // level-map padding stays zero for the whole tile
-  load_coef_cost(k.cc_base(), gf->cost, MAXBS, threadIdx.x, 64 * NW);
-  if (threadIdx.x == 0) {
-    LDS TileB *t = &k.sh()->tile;
-    t->mi_row_start = gf->tile_row_start[tj.tile_row] * 16; t->mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, gf->mi_rows);
-    t->mi_col_start = gf->tile_col_start[tj.tile_col] * 16; t->mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, gf->mi_cols);
-    k.sh()->snap = gf->snap + ((size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * gf->snap_rows + wk) * MI_SNAP_BYTES_ALL(MAXN);
-  }
-  WG_SYNC();
-  const LDS FrameDev *f = lf;
+  for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;        // level-map padding stays zero for the workgroup's life
+  if (threadIdx.x == 0) k.sh()->snap = snap_pool + (size_t)blockIdx.x * MI_SNAP_BYTES_ALL(MAXN);
 #if MI_PROFILE
   if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x] = 0;
+  const FrameDev *prof_f = nullptr;
 #endif
-  WG_SYNC();
-  if (DBG_IS(f, 1)) return;
-  const unsigned long long clk0 = wall_clock64();
-  const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
-  const int ncols = (col1 - col0 + 15) >> 4;
-  for (int r = row0 + 16 * wk; r < row1; r += 16 * workers) {
-    int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;       // this row's counter; the row above: prog - tile_cols
-    for (int c = col0, ci = 0; c < col1; c += 16, ci++) {
-      if (workers > 1 && r > row0) {
-        if (threadIdx.x == 0) {
-          const int need = imin_(ci + 2, ncols);
-          while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
-        }
-        WG_SYNC();
-      }
-      if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
-      if (workers > 1) {
-        WG_SYNC();                                                                   // every wave's stores of this superblock are issued
-        if (threadIdx.x == 0) __hip_atomic_store(prog, ci + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  if (threadIdx.x == 0 && wk == 0) { unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[0] = clk0; tc[1] = wall_clock64(); }
-#if MI_PROFILE
-  WG_SYNC();
-  if (gf->prof_out && threadIdx.x < 128) gf->prof_out[(size_t)job * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];
-#endif
-}
-
-// ---- K1 as a work queue (build with -DMI_K1_QUEUE_KERNEL=1, run with MI_K1_QUEUE=1; measured next round) ----
-// A compile-time option because a second kernel calling the partition walker stops the compiler from inlining the walker into tile_search_kernel,
-// which would change the code that was benchmarked.
-#ifndef MI_K1_QUEUE_KERNEL
-#define MI_K1_QUEUE_KERNEL 0
-#endif
-#if MI_K1_QUEUE_KERNEL
-// Persistent workgroups claim superblocks from one list per launch: item = (tile job, superblock row, superblock column inside the tile), sorted by
-// 2 * row + column (then by job), so everything an item waits for -- its left neighbour and the superblock two to the right in the row above -- sits
-// earlier in the list and has been claimed by a workgroup that is running or done: no deadlock, whatever the number of resident workgroups.  A row's
-// counter in f->sb_prog counts its finished superblocks (they finish in column order because each waits for its left neighbour).  Same decisions, same
-// bytes as one workgroup per tile; what changes is that no resident slot idles while its tile's neighbours are still at work.
-#define MI_QITEM(job, sbr, sbc) (((uint32_t)(job) << 12) | ((uint32_t)(sbr) << 6) | (uint32_t)(sbc))
-template <int MAXBS, int NW, bool BU>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_queue_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
-                                                                                                                const uint32_t *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
-  constexpr int MAXN = 4 << MAXBS;
-  extern __shared__ __align__(16) uint8_t smem[];
-  using K = Ctx<MAXN, NW>;
-  K k;
-  k.base = (LDS uint8_t *)smem;
-  k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);
-  LDS uint16_t *lsc = (LDS uint16_t *)(smem + K::LS_OFF);
-  LDS FrameDev *lf = (LDS FrameDev *)(smem + K::F_OFF);
-  if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
-  for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;
-  if (threadIdx.x == 0) k.sh()->snap = snap_pool + (size_t)blockIdx.x * MI_SNAP_BYTES_ALL(MAXN);
   int cur_frame = -1, cur_job = -1;
   for (;;) {
     WG_SYNC();                                                             // everyone is done with the previous item (and has read q_item)
@@ -1454,13 +1302,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     WG_SYNC();
     const int it = k.sh()->q_item;
     if (it >= nitems) break;
-    const uint32_t item = items[it];
-    const int job = (int)(item >> 12), sbr = (int)((item >> 6) & 63), sbc = (int)(item & 63);
+    const SbItem item = items[it];
+    const int job = (int)item.job, sbr = item.sbr, sbc = item.sbc;
     const TileJob tj = jobs[job];
     const FrameDev *gf = frames + tj.frame;
     if (frame_idle(gf)) continue;
-    if (tj.frame != cur_frame) {                                           // the frame descriptor head and the coefficient slices of its rate table
-      for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];
+    if (tj.frame != cur_frame) {
+      for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];   // only the head: K1 never reads the tail through `lf`
       load_coef_cost(k.cc_base(), gf->cost, MAXBS, threadIdx.x, 64 * NW);
       cur_frame = tj.frame;
     }
@@ -1473,17 +1321,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
       cur_job = job;
     }
     WG_SYNC();
-    const int row0 = k.t()->mi_row_start, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
-    const int ncols = (col1 - col0 + 15) >> 4, r = row0 + 16 * sbr, c = col0 + 16 * sbc;
-    int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;
-    if (threadIdx.x == 0) {
-      if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sbc) __builtin_amdgcn_s_sleep(8);
-      if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8); }
+    const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
+    const int ncols = (col1 - col0 + 15) >> 4, nrows = (row1 - row0 + 15) >> 4, r = row0 + 16 * sbr, c = col0 + 16 * sbc;
+    int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;        // this row's counter; the row above: prog - tile_cols
+    if (sbc > 0 || sbr > 0) {
+      // Polling with relaxed loads (they bypass the non-coherent cache levels by themselves) and ONE acquire once both conditions hold: an acquire
+      // per poll invalidates this XCD's L2 every few hundred cycles for as long as any workgroup waits, under the feet of the ones at work.
+      if (threadIdx.x == 0) {
+        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc) __builtin_amdgcn_s_sleep(16);
+        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16); }
+      }
+      WG_SYNC();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    WG_SYNC();
+    unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * 4;
+    if (threadIdx.x == 0 && sbr == 0 && sbc == 0) tc[0] = wall_clock64();
     if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
-    WG_SYNC();
-    if (threadIdx.x == 0) __hip_atomic_store(prog, sbc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    WG_SYNC();                                                             // every wave's stores of this superblock are issued
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(prog, sbc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (sbr == nrows - 1 && sbc == ncols - 1) tc[1] = wall_clock64();
+    }
+#if MI_PROFILE
+    prof_f = gf;
+#endif
   }
+  // the last workgroup to leave zeroes the launch's counter pair (claims, departures) for the next launch: no memset per encode
+  if (threadIdx.x == 0 && atomicAdd(next_item + 1, 1) == (int)gridDim.x - 1) { next_item[1] = 0; next_item[0] = 0; }
+#if MI_PROFILE
+  WG_SYNC();
+  if (prof_f && prof_f->prof_out && threadIdx.x < 128) prof_f->prof_out[(size_t)blockIdx.x * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];
+#endif
 }
-#endif  // MI_K1_QUEUE_KERNEL

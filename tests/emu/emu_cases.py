@@ -17,8 +17,7 @@ oracle.build(); oracle.lib()
 
 PLANE_CASES = {
     'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0),
-              (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: two row workers (K1 waits on the row above)
-    'mini': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 66, False, 2), (48, 40, 10, 1, 121, False, 0), (96, 64, 10, 4, 66, True, 0)],   # the prepared variants (plus the ravif-level RGBA case below)
+              (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: the work queue's waits on the left neighbour and the row above
     'rect': [(129, 101, 10, 4, 121, False, 0), (136, 72, 8, 4, 10, False, 0), (96, 64, 10, 4, 66, True, 0), (72, 40, 10, 1, 121, False, 0)],
     'full': [(64, 64, 8, 4, 121, False, 0), (64, 64, 8, 10, 121, False, 0), (128, 85, 8, 10, 121, False, 0), (129, 101, 10, 4, 121, False, 0), (200, 120, 10, 1, 121, False, 0),
              (200, 136, 10, 1, 66, True, 0), (256, 200, 10, 4, 66, True, 0), (300, 270, 10, 4, 121, False, 4), (136, 72, 8, 6, 200, False, 0), (136, 72, 8, 4, 10, False, 0),
@@ -36,7 +35,7 @@ for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
 
 if which == 'rect':
     sys.exit(0 if ok_all else 1)
-if which == 'queue':                               # batch API: several images, colour + alpha frames, bottom-up order (MI_K1_QUEUE=1 in the environment)
+if which == 'batch':                               # batch API: several images, colour + alpha frames, bottom-up order (work lists spanning frames and block-size classes)
     from cavif_rs_amd.synth import synth_image
     ok_all = True
     for (w, h, speed, q, depth, alpha, nimg) in [(200, 136, 4, 80.0, 10, False, 3), (136, 100, 4, 60.0, 8, True, 2), (72, 72, 2, 80.0, 10, False, 1)]:
@@ -47,7 +46,7 @@ if which == 'queue':                               # batch API: several images, 
         t = time.time(); b.encode()
         ok = all(b.get(i).avif_file == oracle.ravif_encode(im, quality=q, alpha_quality=90.0, speed=speed, depth=depth)[0] for i, im in enumerate(imgs))
         ok_all &= ok
-        print(json.dumps({'case': 'queue batch %dx%d s%d n%d alpha%d' % (w, h, speed, nimg, int(alpha)), 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
+        print(json.dumps({'case': 'batch %dx%d s%d n%d alpha%d' % (w, h, speed, nimg, int(alpha)), 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
         b.close()
     sys.exit(0 if ok_all else 1)
 # ravif level: RGBA with a used alpha channel, UnassociatedClean (dirty-alpha kernels + front end + colour and alpha frames + container)

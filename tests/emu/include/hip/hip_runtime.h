@@ -112,4 +112,8 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = e
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+// a small "device": 3 compute units x 2 resident workgroups, so that persistent-workgroup launches see fewer workgroups than work items
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); })

@@ -50,55 +50,11 @@ def test_emulated_rect_partition_kernels_equal_rect_oracle(oracle):
     assert rows and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
-def test_emulated_k1_work_queue_equals_oracle(oracle):
-    """Groundwork: the tile search as a work queue of superblocks (-DMI_K1_QUEUE_KERNEL=1, MI_K1_QUEUE=1) makes the same decisions:
-    batches of colour and colour + alpha images, top-down and bottom-up, equal the oracle byte for byte under the emulator's thread pool."""
-    from tests import emu
-    env = dict(os.environ, MI_AVIF_LIB=emu.build(queue=True), MI_K1_QUEUE='1')
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'emu_cases.py'), ROOT, 'queue'], env=env, capture_output=True, text=True, timeout=1200)
-    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+def test_emulated_batch_api_equals_oracle(emu_env):
+    """The batch entry points under the emulator's thread pool: work lists that span several frames (colour and colour + alpha images, two block-size
+    classes in one encode, top-down and bottom-up order) equal the oracle byte for byte."""
+    p, rows = _run(emu_env, 'batch', 1200)
     assert len(rows) == 3 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
-
-
-def test_emulated_k4_wave_pipeline_equals_oracle(emu_env):
-    """Groundwork: -DMI_K4_PIPE=1 splits the entropy coder of a tile into a walker wave (contexts, CDF adaptation, symbol bounds into an
-    LDS ring) and a range-coder wave; the bytes must not change.  The emulator runs the two waves as fibers that yield to each other while they poll."""
-    from tests import emu
-    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=True)), 'mini', 900)
-    bad = [r['case'] for r in rows if not r['ok']]
-    assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
-
-
-def test_emulated_k4_three_stage_pipeline_equals_oracle(emu_env):
-    """Groundwork: -DMI_K4_PIPE=2 decouples the three things the entropy coder does per symbol -- the walker wave emits (CDF row, symbol)
-    records without touching a CDF, four adapter waves own disjoint sets of rows and turn their records into bounds in place, the coder wave does the range
-    arithmetic behind the slowest adapter.  Exact because a CDF's state depends only on the symbols coded through that row.  Both lane orders."""
-    from tests import emu
-    for extra in ({}, {'MI_EMU_REVERSE': '1'}):
-        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=2), **extra), 'mini', 900)
-        bad = [r['case'] for r in rows if not r['ok']]
-        assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
-
-
-def test_emulated_k4_three_kernel_split_equals_oracle(emu_env):
-    """Groundwork: -DMI_K4_PIPE=3 runs the same three stages as three kernels with the tile's record stream in HBM (walker -> one wave
-    per (tile, adapter) converting its rows' records in place -> range coder): no wave waits for another.  The ravif-level case covers the alpha frame
-    (32-point tables) and the partition bool at the frame edge that is priced from a CDF's current state."""
-    from tests import emu
-    p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(pipe=3)), 'mini', 900)
-    bad = [r['case'] for r in rows if not r['ok']]
-    assert rows and not bad and p.returncode == 0, (bad, p.stderr[-2000:])
-
-
-def test_emulated_k1_lds_diet_equals_oracle(emu_env):
-    """Groundwork: -DMI_K1_LDS_DIET=1 runs the <2,4> tile search in 32 480 B of LDS per workgroup (40 912 in the product build): one
-    reconstruction / level buffer per wave with the wave's best candidate parked in HBM, edge working copies inside the transposition buffer, level maps
-    inside the one-candidate struct.  Same decisions, same bytes -- in both lane orders (the park is an exchange between the lanes of a wave)."""
-    from tests import emu
-    for extra in ({}, {'MI_EMU_REVERSE': '1'}):
-        p, rows = _run(dict(emu_env, MI_AVIF_LIB=emu.build(diet=True), **extra), 'mini', 900)
-        bad = [r['case'] for r in rows if not r['ok']]
-        assert rows and not bad and p.returncode == 0, (extra, bad, p.stderr[-2000:])
 
 
 def test_product_library_is_not_the_emulator():
@@ -109,8 +65,6 @@ def test_product_library_is_not_the_emulator():
     with open(encoder.library_path(), 'rb') as fh:
         blob = fh.read()
     assert b'emu_switch' not in blob and b'gfx950' in blob
-    # ... and it is the product build, not one of the prepared variants of tools/build_variants.sh written over it
-    assert b'tile_search_queue_kernel' not in blob, 'cavif_rs_amd/libmi_avif.so was built with -DMI_K1_QUEUE_KERNEL=1'
     import __graft_entry__ as g
     csrc = os.path.join(ROOT, 'cavif_rs_amd', 'csrc')
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, 'include', 'mi_avif.h')]
