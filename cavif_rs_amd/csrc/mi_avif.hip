@@ -184,6 +184,9 @@ template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const Fr
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) return e;
     resident[device] = std::max(1, per_cu) * std::max(1, cus);
+#ifdef MI_TUNING_KNOBS                                  // probe builds only: MI_K1_GRID_PER_CU=n asks for fewer persistent workgroups per CU than fit
+    if (const char *v = getenv("MI_K1_GRID_PER_CU")) { const int n = atoi(v); if (n > 0 && n < per_cu) resident[device] = n * std::max(1, cus); }
+#endif
   }
   const int grid = std::min(nitems, resident[device]);
   if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool

@@ -30,6 +30,7 @@
 #ifndef MI_PROFILE
 #define MI_PROFILE 0
 #endif
+#define MI_PROF_MAXN 16                             /* profiling builds time the 16x16-class launch */
 // bisect hooks (MI_DEBUG_LEVEL): probe builds only (-DMI_DEBUG_HOOKS=1); release builds carry no debug branches in K1
 #ifndef MI_DEBUG_HOOKS
 #define MI_DEBUG_HOOKS 0
@@ -97,6 +98,10 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
 };
 
 struct TxRes { int eob, cul, dcc; long long sse; uint32_t rate; };
+#if MI_PROFILE
+extern __shared__ __align__(16) uint8_t mi_prof_smem_[];             // the workgroup's LDS block starts with its SharedScratch (any MAXN: prof is the last member)
+template <int N> __device__ __forceinline__ LDS unsigned long long &mi_prof_slot_n(int w, int i) { return ((LDS SharedScratch<N> *)mi_prof_smem_)->prof[w][i]; }
+#endif
 
 // What the block search needs to find its working set.  Everything lives in the workgroup's LDS block at offsets fixed by
 // (MAXN, NW) -- shared scratch, per-wave scratch, scan tables, coefficient cost slices, the frame descriptor head -- so the
@@ -590,6 +595,13 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
         const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
         int sub_any = 0;
+#if MI_PROFILE
+        const unsigned long long tr_t0_ = clock64();
+        auto tr_done_ = [&]() { if (LANE == 0) SH->prof[W][BS == 1 ? 31 : (D == 1 ? 29 : 30)] += clock64() - tr_t0_; };
+#else
+        auto tr_done_ = []() {};
+#endif
+        PH(13);
         // ---- stage 0, all waves: the sub-sources; wave 0: outer neighbour contexts, the 4x4 source variances (depth 2 of a 16x16 block)
         // and the decoded flags of the cells right of / below the block that a sub-block's above-right / below-left edge may reach
         for (int q = W; q < G * G; q += NW) {
@@ -613,11 +625,12 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           }
         }
         WG_SYNC();
+        PH(22);
 #pragma unroll 1
         for (int q = 0; q < G * G; q++) {
           // costs only grow: once the split can neither beat the best transform size so far nor stay below the caller's budget
           // (then the best so far is above the budget too and the caller discards this block) the rest is skipped
-          if (j_split >= budget && luma_j >= budget) return true;   // wave-uniform
+          if (j_split >= budget && luma_j >= budget) { tr_done_(); return true; }   // wave-uniform
           if (!(j_split < luma_j)) break;
           const int bi = q / G, bj = q % G;
           const int sx = x + bj * hn, sy = y + bi * hn;
@@ -649,7 +662,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
             WAVE_SYNC();
             predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, spred);
           }
+          PH(23);
           WG_SYNC();
+          PH(24);
           // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs) from the staged neighbour contexts
           int ssc, sdc;
           {
@@ -680,7 +695,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           }
           long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
           if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
-            const int g = GROUP_ID, e = W * 4 + g;
+            // five tx types (the reduced set): the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1 -- a wave whose rows mix
+            // identity, DCT and ADST walks all three 1-D networks one after the other under exec masks
+            const int g = GROUP_ID, e = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 64)) : W * 4 + g;
             const int psv_q = hn == 4 ? (n == 8 ? SH->psv4[q] : psv16[q]) : SH->psv[bi * pcp + bj];
             const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
             if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
@@ -716,7 +733,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
             }
           }
           if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+          PH(25);
           WG_SYNC();
+          PH(26);
           int sw = 0;
           for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
           const long long sub_j = SH->wbest_j[sw];
@@ -729,6 +748,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
             if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
           }
           WG_SYNC();
+          PH(27);
           sub_any |= sub_eob[q] > 0;
           j_split += sub_j;
         }
@@ -753,6 +773,8 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           }
         }
         WG_SYNC();
+        PH(28);
+        tr_done_();
         return false;
       };
       if (trial(std::integral_constant<int, 1>{})) return luma_j;
@@ -1060,40 +1082,56 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   return total_j;
 }
 
-// ---- area snapshot (NONE-vs-SPLIT comparison), kept in the tile's HBM scratch; whole workgroup ----
+// ---- area snapshot (NONE-vs-SPLIT comparison), kept in the workgroup's HBM scratch; whole workgroup ----
+// Wave p copies plane p (reconstruction + levels, four samples per lane: 8- and 16-byte accesses), the last wave the 17 mode-info byte maps (one
+// row of the area per lane, the map's pointer picked out of the LDS frame descriptor) and the eob maps.  m_decoded is not part of a snapshot.
+template <int BYTES> __device__ __forceinline__ void copy_row_(void *dst, const void *src) {
+  if constexpr (BYTES == 1) *(uint8_t *)dst = *(const uint8_t *)src;
+  else if constexpr (BYTES == 2) *(uint16_t *)dst = *(const uint16_t *)src;
+  else if constexpr (BYTES == 4) *(uint32_t *)dst = *(const uint32_t *)src;
+  else if constexpr (BYTES == 8) *(uint2 *)dst = *(const uint2 *)src;
+  else { for (int i = 0; i < BYTES / 16; i++) ((uint4 *)dst)[i] = ((const uint4 *)src)[i]; }
+}
+static_assert(offsetof(FrameDev, m_eob) - offsetof(FrameDev, m_bsize) == 18 * sizeof(void *), "area_copy_dev indexes m_bsize .. m_dc[2] as one array of 18 map pointers");
 template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDev *f, uint8_t *snap, int r, int c, int save) {
-  constexpr int n = 4 << BS, n4 = 1 << BS, T = 64 * NW;
-  uint16_t *srec = (uint16_t *)snap;                         // [3][n*n]
-  int32_t *scoef = (int32_t *)(snap + 3 * n * n * 2);        // [3][n*n]
+  constexpr int n = 4 << BS, n4 = 1 << BS, Q = n / 4;
+#if MI_PROFILE
+  const unsigned long long ac_t0_ = clock64();
+#define mi_prof_slot(w, i) mi_prof_slot_n<MI_PROF_MAXN>(w, i)
+#endif
   uint8_t *smaps = snap + 3 * n * n * 6;                     // 17 byte-maps [n4*n4]
-  uint16_t *seob = (uint16_t *)(smaps + 18 * n4 * n4);       // [3][n4*n4] (2-byte aligned)
-  const int tid = threadIdx.x;
-  for (int p = 0; p < f->np; p++) {
-    uint16_t *gr = f->rec[p] + (size_t)(r * 4) * f->stride + c * 4;
-    int32_t *gc = f->coef[p] + (size_t)(r * 4) * f->stride + c * 4;
-    for (int idx = tid; idx < n * n; idx += T) {
-      const int o = (idx / n) * f->stride + (idx % n);
-      if (save) { srec[p * n * n + idx] = gr[o]; scoef[p * n * n + idx] = gc[o]; }
-      else { gr[o] = srec[p * n * n + idx]; gc[o] = scoef[p * n * n + idx]; }
+  uint8_t *seob = smaps + 18 * n4 * n4;                      // [3][n4*n4] uint16
+  const int W = NW > 1 ? WAVE_ID : 0, np = f->np, rs = f->stride, ms = f->mi_stride;
+  for (int p = W; p < np; p += NW) {
+    uint16_t *gr = f->rec[p] + (size_t)(r * 4) * rs + c * 4;
+    int32_t *gc = f->coef[p] + (size_t)(r * 4) * rs + c * 4;
+    uint2 *srec = (uint2 *)(snap + (size_t)p * n * n * 2);
+    uint4 *scoef = (uint4 *)(snap + 3 * n * n * 2 + (size_t)p * n * n * 4);
+    for (int u = LANE; u < n * Q; u += 64) {
+      const int o = (u / Q) * rs + 4 * (u % Q);
+      if (save) { srec[u] = *(const uint2 *)(gr + o); scoef[u] = *(const uint4 *)(gc + o); }
+      else { *(uint2 *)(gr + o) = srec[u]; *(uint4 *)(gc + o) = scoef[u]; }
     }
   }
-  uint8_t *maps[17] = { f->m_bsize, f->m_skip, f->m_ymode, f->m_uvmode, f->m_txtype, f->m_cfl_sign, f->m_cfl_au, f->m_cfl_av,
-                        (uint8_t *)f->m_angle_y, (uint8_t *)f->m_angle_uv, f->m_lvl[0], f->m_lvl[1], f->m_lvl[2], f->m_dc[0], f->m_dc[1], f->m_dc[2], f->m_txsize };
-#pragma unroll
-  for (int m = 0; m < 17; m++) {
-    if (f->np == 1 && (m == 11 || m == 12 || m == 14 || m == 15)) continue;
-    uint8_t *g = maps[m];
-    for (int i = tid; i < n4 * n4; i += T) {
-      const int o = (r + i / n4) * f->mi_stride + c + (i % n4);
-      if (save) smaps[m * n4 * n4 + i] = g[o]; else g[o] = smaps[m * n4 * n4 + i];
+  if (W == NW - 1) {
+    const LDS unsigned long long *mp = (const LDS unsigned long long *)&f->m_bsize;     // 18 pointers: ... m_cfl_av, m_decoded (skipped), m_txsize, angles, m_lvl[3], m_dc[3]
+    for (int u = LANE; u < 17 * n4; u += 64) {
+      const int m = u / n4, row = u - m * n4, mi = m + (m >= 8);
+      if (np == 1 && (mi == 13 || mi == 14 || mi == 16 || mi == 17)) continue;             // 4:0:0: no chroma context maps
+      uint8_t *g = (uint8_t *)mp[mi] + (r + row) * ms + c, *sp = smaps + m * n4 * n4 + row * n4;
+      if (save) copy_row_<n4>(sp, g); else copy_row_<n4>(g, sp);
+    }
+    const LDS unsigned long long *ep = (const LDS unsigned long long *)&f->m_eob[0];
+    for (int u = LANE; u < np * n4; u += 64) {
+      const int p = u / n4, row = u - p * n4;
+      uint8_t *g = (uint8_t *)((uint16_t *)ep[p] + (r + row) * ms + c), *sp = seob + (p * n4 * n4 + row * n4) * 2;
+      if (save) copy_row_<2 * n4>(sp, g); else copy_row_<2 * n4>(g, sp);
     }
   }
-  for (int p = 0; p < f->np; p++)
-    for (int i = tid; i < n4 * n4; i += T) {
-      const int o = (r + i / n4) * f->mi_stride + c + (i % n4);
-      if (save) seob[p * n4 * n4 + i] = f->m_eob[p][o]; else f->m_eob[p][o] = seob[p * n4 * n4 + i];
-    }
   WG_SYNC();
+#if MI_PROFILE
+  if (LANE == 0) mi_prof_slot(WAVE_ID, 14) += clock64() - ac_t0_;    // (profiling builds) the walker's area copies
+#endif
 }
 
 __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
@@ -1296,7 +1334,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   const FrameDev *prof_f = nullptr;
 #endif
   int cur_frame = -1, cur_job = -1;
+#if MI_PROFILE
+  const unsigned long long k_t0_ = clock64(); unsigned long long w_acc_ = 0;
+#endif
   for (;;) {
+#if MI_PROFILE
+    const unsigned long long w_t0_ = clock64();
+#endif
     WG_SYNC();                                                             // everyone is done with the previous item (and has read q_item)
     if (threadIdx.x == 0) k.sh()->q_item = atomicAdd(next_item, 1);
     WG_SYNC();
@@ -1336,6 +1380,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     }
     unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * 4;
     if (threadIdx.x == 0 && sbr == 0 && sbc == 0) tc[0] = wall_clock64();
+#if MI_PROFILE
+    w_acc_ += clock64() - w_t0_;
+#endif
     if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
     WG_SYNC();                                                             // every wave's stores of this superblock are issued
     if (threadIdx.x == 0) {
@@ -1349,6 +1396,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   // the last workgroup to leave zeroes the launch's counter pair (claims, departures) for the next launch: no memset per encode
   if (threadIdx.x == 0 && atomicAdd(next_item + 1, 1) == (int)gridDim.x - 1) { next_item[1] = 0; next_item[0] = 0; }
 #if MI_PROFILE
+  if (LANE == 0) { k.sh()->prof[WAVE_ID][0] = w_acc_; k.sh()->prof[WAVE_ID][15] = clock64() - k_t0_; }   // claim + dependency waits; the workgroup's life
   WG_SYNC();
   if (prof_f && prof_f->prof_out && threadIdx.x < 128) prof_f->prof_out[(size_t)blockIdx.x * 128 + threadIdx.x] = ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x];
 #endif

@@ -72,6 +72,8 @@ template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(
 #define __hip_atomic_store(ptr, v, order, scope) __atomic_store_n((ptr), (v), (order))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
 struct uchar4 { unsigned char x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
 inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{ x, y, z, w }; }
 
 // ---- HIP runtime stand-ins: one "device", synchronous streams ----
