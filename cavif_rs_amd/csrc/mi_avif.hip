@@ -209,11 +209,10 @@ static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_fram
 }
 // jobs must all belong to frames of the same block-size class
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
-static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, hipStream_t s) {
+static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, uint32_t *d_recbuf, uint32_t rec_cap, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  const int k4_threads = MI_K4_THREADS;
-  if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
-  else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(k4_threads), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap);
+  if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(MI_K4_THREADS), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+  else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(MI_K4_THREADS), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
   return hipGetLastError();
 }
 
@@ -302,6 +301,7 @@ struct mi_batch {
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
   uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
+  uint32_t *d_recbuf = nullptr; uint32_t rec_cap = 0;             // K4's symbol records: three rotating superblock buffers per tile
   uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0, packed_max = 0; unsigned long long *d_prof = nullptr;
   int *h_alpha = nullptr; FrameDev *h_frames = nullptr; TileJob *h_jobs = nullptr;   // pinned: alpha flags (D2H), frame descriptors and tile jobs (H2D sources)
   uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
@@ -337,6 +337,7 @@ static void batch_free_device(mi_batch *b) {
   if (b->d_frames) (void)hipFree(b->d_frames); b->d_frames = nullptr;
   if (b->d_jobs) (void)hipFree(b->d_jobs); b->d_jobs = nullptr;
   if (b->d_precarry) (void)hipFree(b->d_precarry); b->d_precarry = nullptr;
+  if (b->d_recbuf) (void)hipFree(b->d_recbuf); b->d_recbuf = nullptr;
   if (b->d_offsets) (void)hipFree(b->d_offsets); b->d_offsets = nullptr;
   if (b->d_prof) (void)hipFree(b->d_prof); b->d_prof = nullptr;
   b->queue.free_device();
@@ -367,6 +368,8 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_jobs, sizeof(TileJob) * max_tiles));
   b->pre_cap = max_cap;
   HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * (size_t)max_cap * 2));
+  { int max_np = 1; for (auto &p : worst) max_np = std::max(max_np, p.np); b->rec_cap = MI_K4_SB_RECORDS(max_np); }
+  HIP_OK(hipMalloc(&b->d_recbuf, (size_t)max_tiles * 3 * (size_t)b->rec_cap * 4));
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
   HIP_OK(hipMalloc(&b->d_prof, std::max<size_t>(max_tiles, 2048) * 128 * 8));   // profiling builds: per tile job (K4) / per persistent workgroup (K1)
   // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
@@ -570,7 +573,8 @@ int mi_batch_encode_async(mi_batch *b) {
   // ---- K4 entropy coding
   HIP_OK(hipEventRecord(b->ev[4], s));
   for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap, s));
+    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap,
+                          b->d_recbuf + (size_t)class_begin[cls] * 3 * (size_t)b->rec_cap, b->rec_cap, s));
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -893,8 +897,8 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   p.arena_bytes = carve(p, nullptr, cap);
   // every device allocation and the stream are owned by this guard: all return paths release them
   struct Guard {
-    hipStream_t s = nullptr; uint8_t *arena = nullptr; FrameDev *d_frame = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_pre = nullptr; SearchQueue queue;
-    ~Guard() { queue.free_device(); if (d_frame) (void)hipFree(d_frame); if (d_jobs) (void)hipFree(d_jobs); if (d_pre) (void)hipFree(d_pre); if (arena) (void)hipFree(arena); if (s) (void)hipStreamDestroy(s); }
+    hipStream_t s = nullptr; uint8_t *arena = nullptr; FrameDev *d_frame = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_pre = nullptr; uint32_t *d_rec = nullptr; SearchQueue queue;
+    ~Guard() { queue.free_device(); if (d_frame) (void)hipFree(d_frame); if (d_jobs) (void)hipFree(d_jobs); if (d_pre) (void)hipFree(d_pre); if (d_rec) (void)hipFree(d_rec); if (arena) (void)hipFree(arena); if (s) (void)hipStreamDestroy(s); }
   } g;
   HIP_OK(hipStreamCreate(&g.s));
   hipStream_t s = g.s;
@@ -913,6 +917,8 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
   HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * (size_t)cap * 2));
+  const uint32_t rec_cap = MI_K4_SB_RECORDS(p.np);
+  HIP_OK(hipMalloc(&g.d_rec, (size_t)jobs.size() * 3 * (size_t)rec_cap * 4));
   FrameDev *d_frame = g.d_frame; TileJob *d_jobs = g.d_jobs; uint16_t *d_pre = g.d_pre;
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
@@ -925,7 +931,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
     if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
   }
   HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
-  HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, s));
+  HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, g.d_rec, rec_cap, s));
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);
   HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));

@@ -1,8 +1,14 @@
-// tile_entropy.h -- kernel K4: the tile's final bitstream.  One wavefront per tile walks the mode-info
-// maps that K1 left in HBM (partition tree, modes, tx types, quantised levels) in AV1 coding order and
-// range-codes them with adaptive CDFs held in LDS (spec 5.11 syntax, 8.2 symbol coder, 8.3 CDF selection).
-// The walk is inherently serial per tile; the wave's lanes cooperate on staging each transform block's
-// levels + context map into LDS and on the CDF adaptation, lane 0 drives the range coder.
+// tile_entropy.h -- kernel K4: the tile's final bitstream (spec 5.11 syntax, 8.2 symbol coder, 8.3 CDF selection).
+// One workgroup per tile, a pipeline of wavefronts over the tile's superblocks:
+//   producer (wave 0)      walks the mode-info maps K1 left in HBM in AV1 coding order and lays every symbol down as a 32-bit record --
+//                          (CDF row, symbol, alphabet) or a literal -- in the superblock's record buffer; a transform block's coefficient
+//                          symbols are written by all lanes at once (contexts depend on the level map only, exclusive scans place them);
+//   adapters (MI_K4_ADAPTERS waves)  own disjoint sets of CDF rows (a row's state depends only on the symbols coded through that row, never on
+//                          the coder state): each turns ITS records into bounds records in place (read the row, pick fl / fh, adapt);
+//   coder (last wave)      does nothing but the range arithmetic and the byte output over the finished records.
+// While the coder works on superblock k the adapters convert k + 1 and the producer writes k + 2; one workgroup barrier per superblock.
+// A tile's serial chain used to be ~100 instructions per symbol on one wave (a lone wave issues a dependent instruction every ~7 cycles:
+// 46 ms per 1080p tile); it is now the busiest stage's share.
 // rav1e equivalents (absent from /root/reference): src/ec.rs (WriterBase), src/context/*.rs.
 #pragma once
 #include "dev_common.h"
@@ -14,16 +20,22 @@
 // (43.5 ms per 1024 tiles: 44.0 / 46.0 / 75.9 ms, profiles/r03_variants_ab.txt); they are not in the tree.
 #define MI_K4_THREADS 64
 struct RangeEncDev {
-  uint16_t *pre; uint32_t cap, offs;
+  uint16_t *pre; uint32_t cap, offs;     // pre-carry units in HBM; offs counts every unit flushed so far, stored or not (overflow <=> the total exceeds cap)
   uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
+  int ov, on;                            // the last `on` (< 64) units, lane k of `ov` = unit k: a select per unit, one coalesced store per 64
 };
 
 __device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
-  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9;
+  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->ov = 0; e->on = 0;
 }
-__device__ __forceinline__ void re_put16(RangeEncDev *e, uint16_t v) {
-  if (e->offs < e->cap && LANE == 0) e->pre[e->offs] = v;   // offs counts every unit, stored or not: overflow <=> offs > cap at the end (re_finish_dev)
-  e->offs++;
+__device__ __forceinline__ void re_flush_units(RangeEncDev *e) {          // whole wave
+  const uint32_t at = e->offs + (uint32_t)LANE;
+  if (LANE < e->on && at < e->cap) e->pre[at] = (uint16_t)e->ov;
+  e->offs += (uint32_t)e->on; e->on = 0;
+}
+__device__ __forceinline__ void re_put16(RangeEncDev *e, uint32_t v) {     // wave-uniform v
+  e->ov = LANE == e->on ? (int)(v & 0xFFFFu) : e->ov;       // (v_writelane has no clang builtin: compare + select)
+  if (++e->on == 64) re_flush_units(e);
 }
 __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, uint32_t rng) {
   int c = e->cnt;
@@ -32,51 +44,139 @@ __device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, u
   if (s >= 0) {
     c += 16;
     uint32_t m = (1u << c) - 1;
-    if (s >= 8) { re_put16(e, (uint16_t)(low >> c)); low &= m; c -= 8; m >>= 8; }
-    re_put16(e, (uint16_t)(low >> c));
+    if (s >= 8) { re_put16(e, low >> c); low &= m; c -= 8; m >>= 8; }
+    re_put16(e, low >> c);
     s = c + d - 24;
     low &= m;
   }
   e->low = low << d; e->rng = rng << d; e->cnt = s;
 }
+// one symbol with the bounds fl (32768 for the first symbol of the alphabet) and fh; no branch: u = rng leaves `low` where it is
 __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
-  uint32_t l = e->low; uint32_t r = e->rng;
-  const int N = nsyms - 1;
-  if (fl < 32768) {
-    const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4 * (uint32_t)(N - (s - 1));
-    const uint32_t v = (((r >> 8) * (fh >> 6)) >> 1) + 4 * (uint32_t)(N - s);
-    l += r - u; r = u - v;
-  } else {
-    r -= (((r >> 8) * (fh >> 6)) >> 1) + 4 * (uint32_t)(N - s);
+  const uint32_t r = e->rng, r8 = r >> 8, nms = (uint32_t)(nsyms - 1 - s);
+  const uint32_t v = ((r8 * (fh >> 6)) >> 1) + 4u * nms;
+  const uint32_t u = fl < 32768u ? ((r8 * (fl >> 6)) >> 1) + 4u * nms + 4u : r;
+  re_normalize_dev(e, e->low + (r - u), u - v);
+}
+// ---- symbol records ----
+//   adaptive symbol  bits 31..30 = 00: bits 0..15 the CDF row's offset, 16..19 the symbol, 20..23 alphabet size - 1;
+//                    bit 29: instead of a symbol, the "is it split" bool of a partition node at the frame edge, priced from the row as it stands
+//                    (bit 16 = has_cols), resolved by the row's adapter in coding order
+//   bounds           bits 31..30 = 01: bits 0..9 fl >> 6 (512 = the top of the range), 10..19 fh >> 6, 20..23 alphabet size - 1 - symbol
+//   literal          bit 31: bits 0..19 the value, 20..24 the bit count (equiprobable bools, most significant first)
+#define K4_REC(off, s, ns) ((uint32_t)(off) | ((uint32_t)(s) << 16) | ((uint32_t)((ns) - 1) << 20))
+#define K4_PEDGE(off, has_cols) ((uint32_t)(off) | ((uint32_t)(has_cols) << 16) | 0x20000000u)
+#define K4_LIT(v, nb) (0x80000000u | (uint32_t)(v) | ((uint32_t)(nb) << 20))
+#define K4_BOUNDS(fl6, fh6, nms) (0x40000000u | (uint32_t)(fl6) | ((uint32_t)(fh6) << 10) | ((uint32_t)(nms) << 20))
+#ifndef MI_K4_ADAPTERS
+#define MI_K4_ADAPTERS 2
+#endif
+#define MI_K4_THREADS (64 * (2 + MI_K4_ADAPTERS))
+// records a superblock can need at most: per coefficient the base level, four base-range symbols, the sign and two Golomb literals; per transform
+// block five header symbols; per block sixteen; the partition nodes and the restoration units
+#define MI_K4_SB_RECORDS(np) ((uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512))
+// which adapter owns a CDF row: the low bits of its offset (the hot tables have strides 5 and 3: neighbouring contexts and the same context of
+// neighbouring transform sizes land on different waves)
+__device__ __forceinline__ int k4_row_owner(uint32_t row) {
+  static_assert((MI_K4_ADAPTERS & (MI_K4_ADAPTERS - 1)) == 0, "the low bits of the row offset pick the adapter");
+  return (int)(row & (uint32_t)(MI_K4_ADAPTERS - 1));
+}
+// exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl(x, imax_(LANE - d, 0)); if (LANE >= d) x += t; }
+  *total = __builtin_amdgcn_readlane(x, 63);
+  return x - v;
+}
+__device__ __forceinline__ unsigned long long k4_ballot(bool p) {
+#ifdef MI_EMU_BALLOT
+  return MI_EMU_BALLOT(p);
+#else
+  return __builtin_amdgcn_ballot_w64(p);
+#endif
+}
+// Adapter `a` over one superblock's records: only its own rows' records are visited (ballot of the chunk, lowest set bit first).  The row sits in a
+// register (lane i = entry i, lane nsyms = the adaptation counter) and stays there while consecutive records name it.
+__device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, int n_in, int a) {
+  const int n = uni32(n_in), i = LANE;
+  int row = -1, v = 0;
+  for (int cb = 0; cb < n; cb += 64) {
+    const uint32_t rv = cb + i < n ? buf[cb + i] : 0x80000000u;
+    const bool mine = (rv >> 30) == 0u && k4_row_owner(rv & 0xFFFFu) == a;
+    unsigned long long todo = k4_ballot(mine);
+    uint32_t outv = rv;
+    while (todo) {
+      const int j = __builtin_ctzll(todo); todo &= todo - 1;
+      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)rv, j);
+      const int r = (int)(rec & 0xFFFFu);
+      uint32_t out;
+      if (rec & 0x20000000u) {                              // partition node at the frame edge: P(the partitions that split this way), not adapted
+        const int cv = cdf[r + imin_(i, 10)];
+        uint32_t psum = 0;
+        const uint32_t set = (rec & 0x10000u) ? 0x2DCu : 0x17Au;              // has_cols: partitions 2, 3, 4, 6, 7, 9; else 1, 3, 4, 5, 6, 8
+#pragma unroll
+        for (int q = 1; q < 10; q++) if ((set >> q) & 1u) psum += (uint32_t)__builtin_amdgcn_readlane(cv, q - 1) - (uint32_t)__builtin_amdgcn_readlane(cv, q);
+        out = K4_BOUNDS(psum >> 6, 0, 0);
+      } else {
+        const int s = (int)((rec >> 16) & 15u), nsyms = (int)((rec >> 20) & 15u) + 1;
+        if (r != row) { v = cdf[r + imin_(i, nsyms)]; row = r; }
+        const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(v, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
+        const int cnt = __builtin_amdgcn_readlane(v, nsyms);
+        out = K4_BOUNDS(s > 0 ? fl0 >> 6 : 512u, fh >> 6, nsyms - 1 - s);
+        // spec 8.3.2, one step for every entry: rate = 3 + (cnt > 15) + (cnt > 31) + min(floor(log2(nsyms)), 2); cnt <= 32.  Written without a branch:
+        // entries below the symbol move up by (32768 - v) >> rate, the others down by v >> rate; entry nsyms - 1 stays, entry nsyms counts.
+        const int rate = 4 + (nsyms > 3) + (cnt >> 4);
+        const bool below = i < s;
+        const int t = below ? 32768 - v : v, sh = t >> rate;
+        const int moved = below ? v + sh : v - sh;
+        const int va = i == nsyms ? imin_(cnt + 1, 32) : (i < nsyms - 1 ? moved : v);
+        if (i <= nsyms) cdf[r + i] = (uint16_t)va;            // (entry nsyms - 1 is rewritten unchanged)
+        v = va;
+      }
+      outv = i == j ? out : outv;
+    }
+    if (mine) buf[cb + i] = outv;
   }
-  re_normalize_dev(e, l, r);
 }
-// encode + adapt.  The coder state (low, rng, cnt, offs) is wave-uniform and every operand that reaches it goes through
-// v_readfirstlane / v_readlane, so the compiler keeps it in SGPRs and the range arithmetic runs on the scalar unit.  The CDF row
-// is read ONCE, lane i holding entry i (entry nsyms = the adaptation counter): the symbol's two bounds and the counter come
-// out of that register by v_readlane, the same register feeds lane i's adaptation (spec 8.3.2 update rule, one step instead
-// of a loop) -- one LDS round trip per symbol instead of three dependent ones.
-__device__ __forceinline__ void re_symbol_dev(RangeEncDev *e, int s_in, LDS uint16_t *icdf, int nsyms_in) {
-  const int s = uni32(s_in), nsyms = uni32(nsyms_in);
-  const int i = LANE;
-  const int v = icdf[imin_(i, nsyms)];
-  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane(v, imax_(s - 1, 0)), fh = (uint32_t)__builtin_amdgcn_readlane(v, s);
-  const int cnt = __builtin_amdgcn_readlane(v, nsyms);
-  re_encode_q15_dev(e, s > 0 ? fl0 : 32768u, fh, s, nsyms);
-  const int rate = 3 + (cnt > 15) + (cnt > 31) + imin_((32 - __clz(nsyms)) - 1, 2);
-  if (i < nsyms - 1) icdf[i] = (uint16_t)(i < s ? v + ((32768 - v) >> rate) : v - (v >> rate));
-  else if (i == nsyms) icdf[nsyms] = (uint16_t)(cnt + (cnt < 32));
-  WAVE_SYNC();
+// The coder over one superblock's finished records: range arithmetic and byte output only, on the scalar unit.
+__device__ __forceinline__ uint32_t k4_smul(uint32_t a, uint32_t b) {        // (the compiler would route a provably-24-bit uniform product through the vector unit)
+#ifdef MI_EMU_BALLOT
+  return a * b;
+#else
+  uint32_t r; asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r;
+#endif
 }
-__device__ __forceinline__ void re_bool_dev(RangeEncDev *e, int bit_in, uint32_t icdf0) {
-  const int bit = uni32(bit_in);
-  re_encode_q15_dev(e, bit ? icdf0 : 32768, bit ? 0 : icdf0, bit, 2);
+__device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, int n_in) {
+  const int n = uni32(n_in);
+  uint32_t rv = n > 0 ? buf[imin_(LANE, n - 1)] : 0u;
+  for (int cb = 0; cb < n; cb += 64) {
+    const uint32_t cur = rv;
+    if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
+    const int m = imin_(64, n - cb);
+    for (int j = 0; j < m; j++) {
+      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, j);
+      const uint32_t r = e->rng, r8 = r >> 8;
+      if (rec >> 31) {
+        const uint32_t val = rec & 0xFFFFFu;
+        for (int b = (int)((rec >> 20) & 31u) - 1; b >= 0; b--) {
+          const uint32_t rr = e->rng, hv = ((rr >> 8) << 7) + 4u;                 // the boundary of the two equiprobable halves
+          if ((val >> b) & 1u) re_normalize_dev(e, e->low + (rr - hv), hv); else re_normalize_dev(e, e->low, rr - hv);
+        }
+      } else {
+        const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms4 = (rec >> 18) & 60u;      // 4 * (alphabet size - 1 - symbol)
+        const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
+        const uint32_t u = fl6 >= 512u ? r : (k4_smul(r8, fl6) >> 1) + nms4 + 4u;
+        re_normalize_dev(e, e->low + (r - u), u - v);
+      }
+    }
+  }
 }
-__device__ __forceinline__ void re_literal_dev(RangeEncDev *e, uint32_t v_in, int nbits_in) {
-  const uint32_t v = (uint32_t)uni32((int)v_in); const int nbits = uni32(nbits_in);
-  for (int i = nbits - 1; i >= 0; i--) re_bool_dev(e, (int)((v >> i) & 1), 16384);
-}
-// returns number of bytes; out must hold them.  (lane 0)
+
+// Flushes the coder and resolves the carries of the pre-carry units into `out`; returns the number of bytes (0xFFFFFFFF: a buffer overflowed).
+// Whole wave: the 16-bit units form one big base-256 number (bits 8.. of a unit belong to the byte above it), normalised 64 units at a time from
+// the least significant end with a carry-lookahead scan over the lanes (generate: the byte sum reaches 256, propagate: it is 255) -- exactly the
+// bytes of the unit-by-unit loop `carry += pre[i]; out[i] = carry & 255; carry >>= 8` without its thousands of dependent global round trips.
 __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
   unsigned long long l = e->low; int c = e->cnt; int s = 10;
   const unsigned long long m = 0x3FFF;
@@ -90,30 +190,54 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
       x &= n; s -= 8; c -= 8; n >>= 8;
     } while (s > 0);
   }
+  re_flush_units(e);
   const uint32_t nb = e->offs;
   if (nb > e->cap || nb > out_cap) return 0xFFFFFFFFu;
-  uint32_t carry = 0;
-  for (uint32_t i = nb; i-- > 0;) { carry = e->pre[i] + carry; out[i] = (uint8_t)carry; carry >>= 8; }
+  __threadfence();                                         // the unit stores, read back below in another lane order
+  WAVE_SYNC();
+  int cin = 0, ein = 0;                                    // carry into the chunk's last byte; the high bits of the unit right after the chunk
+  for (int top = (int)nb; top > 0; top -= 64) {            // lane i <-> unit top - 64 + i (lane 63 the least significant)
+    const int idx = top - 64 + LANE;
+    const int p = idx >= 0 ? (int)e->pre[idx] : 0;
+    const int hi = p >> 8;
+    int en = __shfl(hi, imin_(LANE + 1, 63));
+    if (LANE == 63) en = ein;
+    const int t = (p & 0xFF) + en;
+    int G = t >= 256, P = t == 255;                        // (generate, propagate) of the lanes LANE .. 63, by doubling
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int g2 = __shfl(G, imin_(LANE + d, 63)), p2 = __shfl(P, imin_(LANE + d, 63));
+      if (LANE + d < 64) { G |= P & g2; P &= p2; }
+    }
+    const int gx = __shfl(G, imin_(LANE + 1, 63)), px = __shfl(P, imin_(LANE + 1, 63));
+    const int ci = LANE == 63 ? cin : (gx | (px & cin));
+    if (idx >= 0) out[idx] = (uint8_t)(t + ci);
+    cin = __builtin_amdgcn_readlane(G | (P & cin), 0); ein = __builtin_amdgcn_readlane(hi, 0);
+  }
   return nb;
 }
 
-struct TileWriter {
-  const FrameDev *f; TileB t; RangeEncDev ec; LDS uint16_t *cdf;   // cdf: LDS [CDF_TOTAL]
+struct TileWriter {                                                 // the producer's state
+  const FrameDev *f; TileB t;
+  uint32_t *out; uint32_t n, cap;                                   // the superblock's record buffer (HBM), records written so far, its capacity
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
-  LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient records of the current transform block
-  LDS uint16_t *lr_cdf; LDS int *lr_ref;                           // switchable restoration_type CDF (3 symbols + counter), RefSgrXqd[plane][2]
+  LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient context rows / levels of the current transform block
+  LDS int *lr_ref;                                                  // RefSgrXqd[plane][2]
   int cdef_pending;                                                 // the 64x64 superblock being walked has not signalled its cdef_idx yet
   int sb_cols_tile;
-  // Frame scalars that steer the walk, pinned to SGPRs once per tile (MI_K4_UNIFORM): a value that reaches a branch through a vector
-  // load is "divergent" to the compiler, the coder state behind such a branch becomes a per-lane value and the range arithmetic moves
-  // to the vector unit under exec masks.  Every control value the walk loads (skip, modes, transform sizes, eob, block sizes,
-  // restoration types) goes through v_readfirstlane for the same reason.
+  // Frame scalars that steer the walk, pinned to SGPRs once per tile: every control value the walk loads (skip, modes, transform sizes, eob,
+  // block sizes, restoration types) goes through v_readfirstlane as well, so that the record counter and the walk's branches stay scalar.
   int np, mi_rows, mi_cols, ms, tx_mode_select, enable_cdef, cdef_bits, enable_restoration, sb_cols, fw, fh;
   struct TxCfg { int reduced_tx_set, base_q_idx; } txc;
 #if MI_PROFILE == 2
   unsigned long long prof[16], pt;
 #endif
 };
+// the producer's emitters (wave-uniform arguments; lane 0 stores)
+__device__ __forceinline__ void k4_put(TileWriter *w, uint32_t rec) { if (LANE == 0 && w->n < w->cap) w->out[w->n] = rec; w->n++; }
+__device__ __forceinline__ void k4_sym(TileWriter *w, int s, int off, int ns) { k4_put(w, K4_REC(uni32(off), uni32(s), uni32(ns))); }
+__device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) { const int nb = uni32(nbits); if (nb > 0) k4_put(w, K4_LIT((uint32_t)uni32((int)v), nb)); }
+#define CDF_LR_SWITCHABLE CDF_TOTAL                                 /* the switchable restoration_type row (3 symbols + counter) sits behind the tables in LDS */
 // K4 phase timers (probe builds, -DMI_PROFILE=2): cycles per phase and event counts, flushed into wave 3's slots of the tile's K1 record
 #ifndef MI_PROFILE
 #define MI_PROFILE 0
@@ -134,14 +258,14 @@ struct TileWriter {
 #define U_(v) ((int)(v))
 #endif
 
-// Code one transform block's coefficients (levels + padded level map already staged in LDS).
-// Two phases: (P) every lane derives the CDF rows (contexts) of its own scan positions -- they depend only on the
-// level map, not on the coder state -- and leaves (cdf offset, level, sign) records in LDS; (S) the wave walks
-// the records in coding order and drives the adaptive range coder, wave-uniform.
+// One transform block's symbols (levels + padded level map already staged in LDS).  (P) every lane derives the CDF rows (contexts) of its own
+// scan positions -- they depend only on the level map -- into LDS; (R) the records in coding order: the header symbols (lane 0), then per scan
+// position from eob - 1 down to 0 the base level and its base-range symbols, then per position from 0 up the sign and the Golomb tail;
+// exclusive scans place each lane's records and the lanes write them side by side.
 __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int plane, int txs, int txtype, int skip_ctx, int dc_ctx,
                                                   int tx_off, int tx_sym, int tx_ns) {
   const int eob = uni32(eob_in);
-  RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf; const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
+  const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
 #if MI_RECT_PART
   const bool rect = txs > 4;                              // 5 = 4x8, 6 = 8x4 (dev_rect.h)
   const int bwl = rect ? (txs == 5 ? 2 : 3) : imin_(5, 2 + txs), bhl = rect ? (txs == 5 ? 3 : 2) : bwl, n = 1 << bwl, nh = 1 << bhl;
@@ -150,7 +274,7 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, nh = n, bhl = bwl;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
 #endif
-  re_symbol_dev(e, eob == 0, cdf + CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
+  k4_sym(w, eob == 0, CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
   K4CNT(9, 1); K4CNT(10, eob == 0);
   if (eob == 0) { K4PH(3); return; }
   // ---- (P) contexts, lane-parallel
@@ -183,45 +307,44 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   }
   WAVE_SYNC();
   K4PH(3);
-  // ---- (S) serial coding
-  if (tx_off >= 0) re_symbol_dev(e, tx_sym, cdf + tx_off, tx_ns);
-  const int eob_pt = eob_to_pt(eob), eob_multi = bwl + bhl - 4;
-  re_symbol_dev(e, eob_pt - 1, cdf + eob_pt_cdf(eob_multi, pt, cls), 5 + eob_multi);
-  if (eob_pt >= 3) {
-    const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
-    re_symbol_dev(e, hi, cdf + CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
-    if (nb > 1) re_literal_dev(e, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
-  }
-  // the records of 64 scan positions at a time sit in a register (lane j = position cb + j) and are picked by v_readlane
-  for (int cb = (eob - 1) & ~63; cb >= 0; cb -= 64) {
-    const int li = imin_(cb + LANE, eob - 1);
-    const uint32_t r_lv = w->rec_lv[li]; const int r_off = w->rec_off[li], r_br = w->rec_br[li];
-    for (int c = imin_(eob - 1, cb + 63); c >= cb; c--) {
-      const int j = c - cb;
-      const int level = (int)((uint32_t)__builtin_amdgcn_readlane((int)r_lv, j) >> 1);
-      const int boff = __builtin_amdgcn_readlane(r_off, j);
-      if (c == eob - 1) re_symbol_dev(e, imin_(level, 3) - 1, cdf + boff, 3);
-      else re_symbol_dev(e, imin_(level, 3), cdf + boff, 4);
-      if (level > 2) {
-        const int bl = __builtin_amdgcn_readlane(r_br, j);
-        int rem = level - 3;
-        for (int idx = 0; idx < 4; idx++) { const int s = imin_(rem, 3); re_symbol_dev(e, s, cdf + bl, 4); rem -= s; if (s < 3) break; }
-      }
+  // ---- (R) records
+  if (tx_off >= 0) k4_sym(w, tx_sym, tx_off, tx_ns);
+  {
+    const int eob_pt = eob_to_pt(eob), eob_multi = bwl + bhl - 4;
+    k4_sym(w, eob_pt - 1, eob_pt_cdf(eob_multi, pt, cls), 5 + eob_multi);
+    if (eob_pt >= 3) {
+      const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+      k4_sym(w, hi, CDF_EOB_EXTRA + ((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE, 2);
+      if (nb > 1) k4_lit(w, (uint32_t)rem & ((1u << (nb - 1)) - 1), nb - 1);
     }
   }
-  K4PH(4); K4CNT(11, eob);
+  uint32_t *recs = w->out; const uint32_t cap = w->cap;
+  uint32_t nrec = w->n;
+  for (int top = eob - 1; top >= 0; top -= 64) {             // lane L takes position top - L: lane order = coding order
+    const int c = top - LANE;
+    int cnt = 0, level = 0, off = 0, boff = 0;
+    if (c >= 0) { level = (int)(w->rec_lv[c] >> 1); off = w->rec_off[c]; boff = w->rec_br[c]; cnt = 1 + (level > 2 ? imin_(4, (level - 3) / 3 + 1) : 0); }
+    int tot; const uint32_t at = nrec + (uint32_t)wave_excl_scan_i32(cnt, &tot);
+    if (c >= 0 && at + (uint32_t)cnt <= cap) {
+      recs[at] = c == eob - 1 ? K4_REC(off, imin_(level, 3) - 1, 3) : K4_REC(off, imin_(level, 3), 4);
+      int rem = level - 3;
+      for (int q = 1; q < cnt; q++) { const int s2 = imin_(rem, 3); recs[at + q] = K4_REC(boff, s2, 4); rem -= s2; }
+    }
+    nrec += (uint32_t)tot;
+  }
   for (int cb = 0; cb < eob; cb += 64) {
-    const uint32_t r_lv = w->rec_lv[imin_(cb + LANE, eob - 1)];
-    for (int c = cb; c < imin_(eob, cb + 64); c++) {
-      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)r_lv, c - cb); const int a = (int)(m >> 1), neg = (int)(m & 1);
-      if (a) {
-        if (c == 0) re_symbol_dev(e, neg, cdf + CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, 2);
-        else re_bool_dev(e, neg, 16384);
-        if (a > 14) { const uint32_t xg = (uint32_t)(a - 14); const int len = 32 - __clz(xg); re_literal_dev(e, 0, len - 1); re_literal_dev(e, xg, len); }
-      }
+    const int c = cb + LANE;
+    int cnt = 0, a = 0, neg = 0, len = 0;
+    if (c < eob) { const uint32_t m = w->rec_lv[c]; a = (int)(m >> 1); neg = (int)(m & 1); if (a > 14) len = 32 - __clz(a - 14); cnt = (a ? 1 : 0) + (a > 14 ? (len > 1 ? 2 : 1) : 0); }
+    int tot; uint32_t at = nrec + (uint32_t)wave_excl_scan_i32(cnt, &tot);
+    if (a && at + (uint32_t)cnt <= cap) {
+      recs[at++] = c == 0 ? K4_REC(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, neg, 2) : K4_LIT(neg, 1);
+      if (a > 14) { if (len > 1) recs[at++] = K4_LIT(0, len - 1); recs[at] = K4_LIT((uint32_t)(a - 14), len); }
     }
+    nrec += (uint32_t)tot;
   }
-  K4PH(5);
+  w->n = nrec;
+  K4PH(4); K4CNT(11, eob);
 }
 
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
@@ -240,28 +363,28 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_ay = U_(l_ay), v_cdef = U_(l_cdef);
   const int uvmode = U_(l_uvmode), v_auv = U_(l_auv), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
   {
-    RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
+    const int cdf = 0;                                   // CDF rows are named by their offset in the tables
     const int sctx = (availU ? v_skU : 0) + (availL ? v_skL : 0);
-    re_symbol_dev(e, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
+    k4_sym(w, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
     if (!skip && w->enable_cdef) {
-      if (w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, w->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
+      if (w->cdef_pending) { w->cdef_pending = 0; k4_lit(w, (uint32_t)v_cdef, w->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
     const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
-    re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
+    k4_sym(w, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
     if (BS >= BS_8 && ymode >= V_PRED && ymode <= D67_PRED)
-      re_symbol_dev(e, v_ay + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
+      k4_sym(w, v_ay + 3, cdf + CDF_ANGLE + (ymode - V_PRED) * CDF_ANGLE_STRIDE, 7);
     if (w->np > 1) {
       const int um = uvmode;
-      if (BS <= BS_32) re_symbol_dev(e, um, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
-      else re_symbol_dev(e, um, cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
+      if (BS <= BS_32) k4_sym(w, um, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
+      else k4_sym(w, um, cdf + CDF_UV_NOCFL + ymode * CDF_UV_NOCFL_STRIDE, 13);
       if (um == UV_CFL_PRED) {
         const int js = v_js, su = (js + 1) / 3, sv = (js + 1) % 3;
-        re_symbol_dev(e, js, cdf + CDF_CFL_SIGN, 8);
-        if (su) re_symbol_dev(e, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
-        if (sv) re_symbol_dev(e, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
+        k4_sym(w, js, cdf + CDF_CFL_SIGN, 8);
+        if (su) k4_sym(w, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
+        if (sv) k4_sym(w, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
       }
       if (BS >= BS_8 && um >= V_PRED && um <= D67_PRED)
-        re_symbol_dev(e, v_auv + 3, cdf + CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE, 7);
+        k4_sym(w, v_auv + 3, cdf + CDF_ANGLE + (um - V_PRED) * CDF_ANGLE_STRIDE, 7);
     }
   }
   // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
@@ -272,7 +395,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
 #else
     const int actx = availU && (4 << v_txU) >= maxw, lctx = availL && (4 << v_txL) >= maxw;
 #endif
-    re_symbol_dev(&w->ec, BS - txs_y, w->cdf + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
+    k4_sym(w, BS - txs_y, CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   K4PH(1); K4CNT(8, 1);
   if (skip) return;                                    // wave-uniform
@@ -323,23 +446,23 @@ template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *
   if (w->np > 1) { l_uvmode = f->m_uvmode[mi]; l_js = f->m_cfl_sign[mi]; l_au = f->m_cfl_au[mi]; l_av = f->m_cfl_av[mi]; }
   const int skip = U_(l_skip), ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
   const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_cdef = U_(l_cdef), uvmode = U_(l_uvmode), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
-  RangeEncDev *e = &w->ec; LDS uint16_t *cdf = w->cdf;
-  re_symbol_dev(e, skip, cdf + CDF_SKIP + ((availU ? v_skU : 0) + (availL ? v_skL : 0)) * CDF_SKIP_STRIDE, 2);
-  if (!skip && w->enable_cdef && w->cdef_pending) { w->cdef_pending = 0; re_literal_dev(e, (uint32_t)v_cdef, w->cdef_bits); }
+  const int cdf = 0;
+  k4_sym(w, skip, cdf + CDF_SKIP + ((availU ? v_skU : 0) + (availL ? v_skL : 0)) * CDF_SKIP_STRIDE, 2);
+  if (!skip && w->enable_cdef && w->cdef_pending) { w->cdef_pending = 0; k4_lit(w, (uint32_t)v_cdef, w->cdef_bits); }
   const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
-  re_symbol_dev(e, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
+  k4_sym(w, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
   if (w->np > 1) {
-    re_symbol_dev(e, uvmode, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
+    k4_sym(w, uvmode, cdf + CDF_UV_CFL + ymode * CDF_UV_CFL_STRIDE, 14);
     if (uvmode == UV_CFL_PRED) {
       const int js = v_js, su = (js + 1) / 3, sv = (js + 1) % 3;
-      re_symbol_dev(e, js, cdf + CDF_CFL_SIGN, 8);
-      if (su) re_symbol_dev(e, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
-      if (sv) re_symbol_dev(e, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
+      k4_sym(w, js, cdf + CDF_CFL_SIGN, 8);
+      if (su) k4_sym(w, v_au, cdf + CDF_CFL_ALPHA + ((su - 1) * 3 + sv) * CDF_CFL_ALPHA_STRIDE, 16);
+      if (sv) k4_sym(w, v_av, cdf + CDF_CFL_ALPHA + ((sv - 1) * 3 + su) * CDF_CFL_ALPHA_STRIDE, 16);
     }
   }
   if (w->tx_mode_select) {
     const int actx = availU && dim_wl(v_txU) >= WL, lctx = availL && dim_hl(v_txL) >= HL;
-    re_symbol_dev(e, txs_y == BSR ? 0 : 1, cdf + CDF_TX_SIZE + (actx + lctx) * CDF_TX_SIZE_STRIDE, 2);
+    k4_sym(w, txs_y == BSR ? 0 : 1, cdf + CDF_TX_SIZE + (actx + lctx) * CDF_TX_SIZE_STRIDE, 2);
   }
   if (skip) return;
   for (int p = 0; p < w->np; p++) {
@@ -395,17 +518,10 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
 #endif
-  LDS uint16_t *cdf = w->cdf + CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
+  const int cdf = CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
   const int ns = bs == BS_8 ? 4 : 10;
-  if (has_rows && has_cols) re_symbol_dev(&w->ec, part, cdf, ns);
-  else if (has_rows || has_cols) {
-#define PP_(i) ((uint32_t)((i) > 0 ? cdf[(i) - 1] : 32768) - cdf[i])
-    uint32_t psum;
-    if (has_cols) psum = PP_(2) + PP_(3) + PP_(4) + PP_(6) + PP_(7) + PP_(9);
-    else psum = PP_(1) + PP_(3) + PP_(4) + PP_(5) + PP_(6) + PP_(8);
-#undef PP_
-    re_bool_dev(&w->ec, 1, (uint32_t)U_(psum));
-  }
+  if (has_rows && has_cols) k4_sym(w, part, cdf, ns);
+  else if (has_rows || has_cols) k4_put(w, K4_PEDGE(uni32(cdf), has_cols));   // the bool's probability comes from the row's state at this point of the stream: its adapter's job
   if (!(has_rows && has_cols)) part = 3;
   K4PH(0);
   return part;
@@ -421,16 +537,16 @@ __device__ __forceinline__ void write_lr_sb(TileWriter *w, int r, int c) {
   for (int p = 0; p < w->np; p++) for (int ur = urs; ur < ure; ur++) for (int uc = ucs; uc < uce; uc++) {
     const int ui = p * n + ur * ucols + uc;
     const int type = U_(f->lr_type[ui]);
-    re_symbol_dev(&w->ec, type ? 2 : 0, w->lr_cdf, 3);
+    k4_sym(w, type ? 2 : 0, CDF_LR_SWITCHABLE, 3);
     if (!type) continue;
     const int set = U_(f->lr_set[ui]);
-    re_literal_dev(&w->ec, (uint32_t)set, 4);
+    k4_lit(w, (uint32_t)set, 4);
     int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
     for (int i = 0; i < 2; i++) {
       const int v = U_(f->lr_xqd[ui * 2 + i]);
       if (i == 0 ? r0 : r1) {
         uint32_t bits; const int nb = lr_subexp_code(v, i == 0 ? -96 : -32, i == 0 ? 32 : 96, w->lr_ref[p * 2 + i], &bits);
-        re_literal_dev(&w->ec, bits, nb);
+        k4_lit(w, bits, nb);
       }
       WAVE_SYNC();
       if (LANE == 0) w->lr_ref[p * 2 + i] = v;
@@ -483,66 +599,102 @@ template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter
   }
 }
 
-// <= 128 registers per lane, so that an entropy wave fits the slot one finished search workgroup frees on a SIMD and
-// batch A's entropy coding can run next to batch B's search instead of waiting for its tail
-// (dynamic LDS: with a compile-time LDS size that caps the occupancy the compiler pads the VGPR allocation to 176)
-// LDS sized by the largest block the launch can meet (MAXBS 2: 16x16 -> 15.5 KB, so two entropy workgroups fit the LDS one
-// finished search workgroup frees; MAXBS 4: 32x32 coded coefficients -> 28 KB)
+// LDS sized by the largest block the launch can meet (MAXBS 2: 16x16 -> 15.6 KB; MAXBS 4: 32x32 coded coefficients -> 28 KB); dynamic, so
+// that the compiler does not pad the register allocation to the occupancy a compile-time LDS size implies
 template <int CS> struct EntropyLds {
-  uint16_t cdf[CDF_TOTAL];
+  uint16_t cdf[CDF_TOTAL + 8];            // the tables, then the switchable restoration_type row (CDF_LR_SWITCHABLE)
   int32_t qc[CS * CS];
   uint8_t lev[(CS + 4) * (CS + 4) + 4];
   uint16_t scans[SCAN_LDS_ENTRIES(CS)];
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
-  uint16_t lr_cdf[4]; int lr_ref[6];
+  int lr_ref[6];
+  uint32_t nrec[3];                        // records in the three rotating superblock buffers
 };
 
+// recbuf: per tile job three record buffers of rec_cap entries (producer -> adapters -> coder, rotating per superblock)
 template <int MAXBS>
-__global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap) {
-  constexpr int CS = MAXBS <= 2 ? 16 : 32;
+__global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap,
+                                                                   uint32_t *recbuf, uint32_t rec_cap) {
+  constexpr int CS = MAXBS <= 2 ? 16 : 32, NA = MI_K4_ADAPTERS;
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
   EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
   const int job = blockIdx.x;
   if (job >= njobs) return;
   const TileJob tj = jobs[job];
   const FrameDev *f = frames + tj.frame;
-  if (frame_idle(f)) { if (LANE == 0) f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = 0; return; }
+  const int tile = tj.tile_row * f->tile_cols + tj.tile_col;
+  if (frame_idle(f)) { if (threadIdx.x == 0) f->tile_len[tile] = 0; return; }
+  const int wave = uni32((int)(threadIdx.x >> 6));             // 0 producer, 1 .. NA adapters, NA + 1 coder
+  uint32_t *const bufs = recbuf + (size_t)job * 3 * rec_cap;
+  const int row0 = f->tile_row_start[tj.tile_row] * 16, row1 = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
+  const int col0 = f->tile_col_start[tj.tile_col] * 16, col1 = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
+  const int sbc = uni32((col1 - col0 + 15) >> 4), nsb = uni32(((row1 - row0 + 15) >> 4) * sbc);
+  // the tables: every wave a share
+  for (int i = threadIdx.x; i < CDF_TOTAL; i += MI_K4_THREADS) L.cdf[i] = f->cdf0[i];
+  if (threadIdx.x < 4) L.cdf[CDF_LR_SWITCHABLE + threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? 32768 - 9413 : (threadIdx.x == 1 ? 32768 - 22581 : 0));   // libaom default_switchable_restore_cdf
+  if (threadIdx.x < 6) L.lr_ref[threadIdx.x] = (threadIdx.x & 1) ? 31 : -32;                                                                              // Sgrproj_Xqd_Mid
   TileWriter w;
-  w.f = f;
-  w.t.mi_row_start = f->tile_row_start[tj.tile_row] * 16; w.t.mi_row_end = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
-  w.t.mi_col_start = f->tile_col_start[tj.tile_col] * 16; w.t.mi_col_end = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
-  w.cdf = (LDS uint16_t *)L.cdf; w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
-  w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
-  w.lr_cdf = (LDS uint16_t *)L.lr_cdf; w.lr_ref = (LDS int *)L.lr_ref;
-  w.np = U_(f->np); w.mi_rows = U_(f->mi_rows); w.mi_cols = U_(f->mi_cols); w.ms = U_(f->mi_stride); w.tx_mode_select = U_(f->tx_mode_select);
-  w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
-  w.fw = U_(f->w); w.fh = U_(f->h); w.txc.reduced_tx_set = U_(f->reduced_tx_set); w.txc.base_q_idx = U_(f->base_q_idx);
-  if (LANE < 4) L.lr_cdf[LANE] = (uint16_t)(LANE == 0 ? 32768 - 9413 : (LANE == 1 ? 32768 - 22581 : 0));   // libaom default_switchable_restore_cdf
-  if (LANE < 6) L.lr_ref[LANE] = (LANE & 1) ? 31 : -32;                                                      // Sgrproj_Xqd_Mid
-  load_scans_to_lds((LDS uint16_t *)L.scans, CS);
-  w.sb_cols_tile = (w.t.mi_col_end - w.t.mi_col_start + 15) >> 4;
-  for (int i = LANE; i < CDF_TOTAL; i += 64) L.cdf[i] = f->cdf0[i];
-  re_init_dev(&w.ec, precarry + (size_t)job * pre_cap, pre_cap);
-#if MI_PROFILE == 2
-  for (int i = 0; i < 16; i++) w.prof[i] = 0;
-  w.pt = clock64();
-#endif
+  RangeEncDev ec;
   const unsigned long long clk0 = wall_clock64();
-  WAVE_SYNC();
-  for (int r = w.t.mi_row_start; r < w.t.mi_row_end; r += 16)
-    for (int c = w.t.mi_col_start; c < w.t.mi_col_end; c += 16)
-      write_superblock<MAXBS>(&w, r, c);
-  WAVE_SYNC();
-  if (LANE == 0) {
-    const int ti = f->tile_base + tj.tile_row * f->tile_cols + tj.tile_col;
-    (void)ti;
-    uint8_t *out = f->tile_out + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * f->tile_out_cap;
-    f->tile_len[tj.tile_row * f->tile_cols + tj.tile_col] = re_finish_dev(&w.ec, out, f->tile_out_cap);
 #if MI_PROFILE == 2
-    { TileWriter *w_ = &w; TileWriter *w = w_; K4PH(7); if (f->prof_out) for (int i = 0; i < 16; i++) f->prof_out[(size_t)job * 128 + 96 + i] = w->prof[i]; }
+  unsigned long long busy = 0;
 #endif
-    unsigned long long *tc = f->tile_clk + (size_t)(tj.tile_row * f->tile_cols + tj.tile_col) * 4; tc[2] = clk0; tc[3] = wall_clock64();
+  if (wave == 0) {
+    w.f = f;
+    w.t.mi_row_start = row0; w.t.mi_row_end = row1; w.t.mi_col_start = col0; w.t.mi_col_end = col1;
+    w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
+    w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
+    w.lr_ref = (LDS int *)L.lr_ref; w.cap = rec_cap; w.out = bufs; w.n = 0;
+    w.np = U_(f->np); w.mi_rows = U_(f->mi_rows); w.mi_cols = U_(f->mi_cols); w.ms = U_(f->mi_stride); w.tx_mode_select = U_(f->tx_mode_select);
+    w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
+    w.fw = U_(f->w); w.fh = U_(f->h); w.txc.reduced_tx_set = U_(f->reduced_tx_set); w.txc.base_q_idx = U_(f->base_q_idx);
+    load_scans_to_lds((LDS uint16_t *)L.scans, CS);
+    w.sb_cols_tile = sbc;
+#if MI_PROFILE == 2
+    for (int i = 0; i < 16; i++) w.prof[i] = 0;
+    w.pt = clock64();
+#endif
+  } else if (wave == NA + 1) re_init_dev(&ec, precarry + (size_t)job * pre_cap, pre_cap);
+  __syncthreads();
+  int overflow = 0;
+  for (int t = 0; t < nsb + 2; t++) {
+#if MI_PROFILE == 2
+    const unsigned long long t0_ = clock64();
+#endif
+    if (wave == 0) {
+      if (t < nsb) {
+        w.out = bufs + (size_t)(t % 3) * rec_cap; w.n = 0;
+#if MI_PROFILE == 2
+        w.pt = clock64();
+#endif
+        write_superblock<MAXBS>(&w, row0 + 16 * (t / sbc), col0 + 16 * (t % sbc));
+        WAVE_SYNC();
+        if (LANE == 0) L.nrec[t % 3] = w.n;
+      }
+    } else if (wave <= NA) {
+      if (t >= 1 && t <= nsb) k4_adapt_sb((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
+    } else {
+      if (t >= 2) { const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1; k4_code_sb(&ec, bufs + (size_t)((t - 2) % 3) * rec_cap, (int)imin_((int)n, (int)rec_cap)); }
+    }
+#if MI_PROFILE == 2
+    busy += clock64() - t0_;
+#endif
+    __syncthreads();                                            // the stages hand their superblocks on (workgroup scope: one CU, one L1)
   }
+  if (wave == NA + 1) {
+    uint8_t *out = f->tile_out + (size_t)tile * f->tile_out_cap;
+    uint32_t out_len = re_finish_dev(&ec, out, f->tile_out_cap);       // whole wave
+    if (overflow) out_len = 0xFFFFFFFFu;
+    if (LANE == 0) {
+      f->tile_len[tile] = out_len;
+      unsigned long long *tc = f->tile_clk + (size_t)tile * 4; tc[2] = clk0; tc[3] = wall_clock64();
+    }
+  }
+#if MI_PROFILE == 2
+  if (LANE == 0 && f->prof_out) {
+    if (wave == 0) { TileWriter *w_ = &w; TileWriter *w = w_; for (int i = 0; i < 16; i++) f->prof_out[(size_t)job * 128 + 96 + i] = w->prof[i]; }
+    f->prof_out[(size_t)job * 128 + 64 + wave] = busy;          // busy cycles of every stage wave (barrier waits excluded)
+  }
+#endif
 }
-

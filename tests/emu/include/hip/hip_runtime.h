@@ -55,6 +55,7 @@ extern thread_local alignas(16) uint8_t k4_smem[];
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::xlane(emu::X_DPP, (int)(src), (int)(old), (int)(ctrl), (int)(rm), (int)(bm), (int)(bc), __COUNTER__)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __threadfence() {}
 #define __builtin_amdgcn_s_sleep(n) emu::spin_yield()      /* a workgroup waiting for another one: let its OS thread run */
 inline int __shfl(int v, int src, int width = 64) { (void)width; return emu::xlane(emu::X_SHFL, v, 0, src, 0, 0, 0, -1); }
 inline void __syncthreads() { emu::wg_barrier(); }
@@ -71,6 +72,14 @@ template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(
 #define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
 #define __hip_atomic_store(ptr, v, order, scope) __atomic_store_n((ptr), (v), (order))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
+// wave ballot from the cross-lane shuffle the emulator has (butterfly OR of the lanes' own bits)
+inline unsigned long long emu_ballot64(bool p) {
+  const int l = (int)(threadIdx.x & 63);
+  int lo = (p && l < 32) ? (int)(1u << l) : 0, hi = (p && l >= 32) ? (int)(1u << (l - 32)) : 0;
+  for (int d = 1; d < 64; d <<= 1) { const int a = __shfl(lo, l ^ d), b = __shfl(hi, l ^ d); lo |= a; hi |= b; }
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+#define MI_EMU_BALLOT(p) emu_ballot64(p)
 struct uchar4 { unsigned char x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };

@@ -8,9 +8,11 @@ e = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10)
 b = m.BatchEncoder(e, B, 1920, 1080, 3)
 for i in range(B): b.upload(i, synth_image(1920, 1080, index=i))
 b.encode(); b.encode()
-p = b.phase_profile().astype(np.float64)[:, 3, :16]      # K4 writes into wave 3's slots: [tiles][16]
+full = b.phase_profile().astype(np.float64)
+p = full[:, 3, :16]                                        # the producer's phases sit in wave 3's slots: [tiles][16]
+stage = full[:, 2, :8]                                     # busy cycles of the stage waves (producer, adapters, coder) in wave 2's
 print('stage_ms', b.stage_ms())
-names = ['partition', 'block_header', 'tx_staging', 'ctx_phase_P', 'symbols_S', 'signs', 'lr', 'walk_other']
+names = ['partition', 'block_header', 'tx_staging', 'ctx_phase_P', 'records_R', '(unused)', 'lr', 'walk_other']
 tot = p[:, :8].sum(axis=1)
 print('mean cycles per tile %.4g  (max %.4g)' % (tot.mean(), tot.max()))
 for i, n in enumerate(names): print('%-14s %6.2f%%' % (n, 100 * p[:, i].sum() / tot.sum()))
@@ -18,3 +20,4 @@ blocks, txb, empty, coefs = p[:, 8].sum(), p[:, 9].sum(), p[:, 10].sum(), p[:, 1
 print('per tile: blocks %.0f, transform blocks %.0f (empty %.0f), coefficients up to eob %.0f' % (blocks / len(p), txb / len(p), empty / len(p), coefs / len(p)))
 print('cycles per block header %.0f, per transform block staged %.0f, P per coded block %.0f, S per coefficient %.1f, signs per coefficient %.1f' % (
     p[:, 1].sum() / blocks, p[:, 2].sum() / txb, p[:, 3].sum() / max(1, txb - empty), p[:, 4].sum() / coefs, p[:, 5].sum() / coefs))
+print('stage busy cycles per tile (mean / max): ' + '  '.join('w%d %.3g / %.3g' % (i, stage[:, i].mean(), stage[:, i].max()) for i in range(8) if stage[:, i].max() > 0))
