@@ -44,7 +44,7 @@ bool read_all(FILE *f, std::vector<uint8_t> &out) {
 }
 int usage(const char *msg) {
   fprintf(stderr, "error: %s\nusage: cavif_mi [-Q quality 1-100] [-s speed 1-10] [-j threads] [-f|--overwrite] [-o path] [-q] [--dirty-alpha]\n"
-                  "                [--color ycbcr|rgb] [--depth 8|10|auto] [--devices 0,1,..] IMAGES...   (\"-\" = stdin/stdout)\n", msg);
+                  "                [--color ycbcr|rgb] [--depth 8|10|auto] [--devices 0,1,..] [--rdo-passes 1|2] IMAGES...   (\"-\" = stdin/stdout)\n", msg);
   return 1;
 }
 
@@ -55,7 +55,7 @@ int usage(const char *msg) {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
   const double t_start = now_s(); const bool timing = getenv("CAVIF_MI_TIMING") != nullptr;
-  float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0;
+  float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0, rdo_passes = 1;
   bool overwrite = false, quiet = false, dirty_alpha = false, have_output = false, output_stdio = false;
   std::string output; std::vector<std::string> images; std::vector<int> devices;
   // clap syntax (src/main.rs:45-110): --name value, --name=value, -n value, -nvalue, -n=value, combined short flags (-fq)
@@ -92,6 +92,7 @@ int main(int argc, char **argv) {
     else if (a == "-q" || a == "--quiet") quiet = true;
     else if (a == "--dirty-alpha") dirty_alpha = true;
     else if (a == "--color") { const std::string v = value("--color"); if (v == "ycbcr") color_model = 0; else if (v == "rgb") color_model = 1; else return usage("bad color type"); }
+    else if (a == "--rdo-passes") { rdo_passes = atoi(value("--rdo-passes")); if (rdo_passes < 1 || rdo_passes > 2) return usage("bad --rdo-passes (1 or 2)"); }   // extension: not a cavif flag
     else if (a == "--depth") { const std::string v = value("--depth"); depth = v == "8" ? 8 : v == "10" ? 10 : 0; if (v != "8" && v != "10" && v != "auto") return usage("bad depth"); }
     else if (a == "--devices") { const char *v = value("--devices"); for (const char *p = v; *p;) { devices.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') p++; } }
     else if (a.size() > 1 && a[0] == '-' ) return usage(("unknown option " + a).c_str());
@@ -120,7 +121,7 @@ int main(int argc, char **argv) {
   mi_ravif_encoder enc; mi_ravif_encoder_default(&enc);
   enc.quality = quality;
   enc.alpha_quality = std::fmin((quality + 100.f) / 2.f, quality + quality / 4.f + 2.f);                                   // :115
-  enc.speed = (uint8_t)speed; enc.depth = (uint8_t)depth; enc.color_model = (uint8_t)color_model;
+  enc.speed = (uint8_t)speed; enc.depth = (uint8_t)depth; enc.color_model = (uint8_t)color_model; enc.rdo_passes = rdo_passes;
   enc.alpha_mode = dirty_alpha ? 0 : 1; enc.threads = threads > 0 ? threads : 0;
 
   // load + decide output paths (process(), :169-200); failures are collected per file and reported at the end

@@ -11,11 +11,7 @@
 #ifndef MI_TX_DEPTH_MAX
 #define MI_TX_DEPTH_MAX 2
 #endif
-// PARTITION_HORZ / PARTITION_VERT of 8x8 nodes (8x4 / 4x8 blocks, 2:1 transforms; dev_rect.h) -- the oracle's AV1O_RECT_PART.  0 until the
-// kernels have been checked on the hardware; block / transform size codes 5 (4x8) and 6 (8x4) then appear in m_bsize / m_txsize.
-#ifndef MI_RECT_PART
-#define MI_RECT_PART 0
-#endif
+// Block / transform size codes 5 (4x8) and 6 (8x4) appear in m_bsize / m_txsize: PARTITION_HORZ / PARTITION_VERT of 8x8 nodes (dev_rect.h).
 #define MI_MAX_TILE_COLS 64
 #define MI_MAX_TILE_ROWS 64
 
@@ -66,9 +62,13 @@ struct FrameDev {
   int tile_rows, tile_cols_log2, tile_rows_log2;
   int tile_col_start[MI_MAX_TILE_COLS + 1], tile_row_start[MI_MAX_TILE_ROWS + 1];
   const uint16_t *cdf0;      // initial CDFs [CDF_TOTAL]
+  // two-pass pricing (mi_av1_config.rdo_passes = 2): pass 1's entropy coder leaves every tile's final CDFs in cdf_out, cdf_cost_kernel turns them
+  // into per-tile rate tables, and pass 2's tile search prices tile t against tile_cost + t * CDF_TOTAL.  Both null in a one-pass encode.
+  const uint16_t *tile_cost; uint16_t *cdf_out; uint16_t *tile_cost_buf;
   // loop filter / cdef
   int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
   long long *lf_tally;       // deblock level search: [3 planes][2 passes][65] SSE-delta difference arrays (zeroed per encode)
+  int zero_words;            // 32-bit words of the block starting at m_decoded (decoded flags, lf_tally, sb_prog) that every encode starts from zero: the activity kernel clears it
   int *lf_out;               // the frame's 4 chosen levels, read back by the host for the frame header
   // per-tile outputs
   uint8_t *tile_out;         // per tile: tile_out_cap bytes

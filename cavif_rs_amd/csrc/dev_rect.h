@@ -1,9 +1,8 @@
 // dev_rect.h -- rectangular blocks (PARTITION_HORZ / PARTITION_VERT of an 8x8 node: 8x4 and 4x8 blocks with their 2:1 transforms) for the
-// tile search K1.  Compiled only with -DMI_RECT_PART=1 (the oracle's AV1O_RECT_PART); mirrors oracle/av1o_search.c try_block for the
-// codes BS_4X8 = 5 / BS_8X4 = 6 (oracle/av1o_int.h).  One candidate per wavefront, 32 samples on 32 lanes, no grouping: correctness
-// first -- the square paths keep their tuned code.
+// tile search K1; mirrors oracle/av1o_search.c try_block for the codes BS_4X8 = 5 / BS_8X4 = 6 (oracle/av1o_int.h).  The (mode x tx type) trials, the
+// two halves of the tx-size trial and the chroma candidates run four per wavefront (eval_group_wh, one candidate per 16-lane row) like the square
+// small blocks; the SATD stage and the full mode set of speed <= 1 keep one candidate per wavefront.
 #pragma once
-#if MI_RECT_PART
 enum { BS_4X8 = 5, BS_8X4 = 6 };
 __device__ __forceinline__ int dim_wl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 2 : 3); }   // log2 width / height in samples
 __device__ __forceinline__ int dim_hl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 3 : 2); }
@@ -321,9 +320,181 @@ __device__ inline long long eval_rect(const Ctx<MAXN, NW> k, int plane, int sctx
   tr->sse = dist;
   return ((dist * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
 }
-#endif  // MI_RECT_PART
 
-#if MI_RECT_PART
+// eval_group() (dev_group.h) for the 2:1 sizes: four candidates per wavefront, one per 16-lane row, two coefficients per lane.  Same arithmetic and
+// rounding points as eval_rect() / rect_quant_rate() above.  The rate of the eob class comes from the 32-coefficient table, which is not among the
+// LDS-resident slices: the six entries of its row are fetched up front (lane k of the row holds entry k) and picked after the quantiser.
+template <int WL, int HL, typename CostPtr>
+__device__ inline void eval_group_wh(const CoefCost &cc, CostPtr cost, const LDS FrameDev *f, LDS GroupBuf8 *gb, const LDS uint16_t *src, const LDS uint16_t *pred, int plane, int txtype,
+                                     int skip_ctx, int dc_ctx, int tx_off, int tx_sym, int psv_a, int psv_b, int psy_act, GroupRes *res) {
+  constexpr int W = 1 << WL, H = 1 << HL, P = W + 1, nc = 32, IT = 2, st = W + 4, txs_ctx = 1;
+  const int gl = GROUP_LANE, bd = f->bd;
+  const int cls = tx_class_of(txtype), pt = plane > 0;
+  const uint32_t tx_cost = cost[tx_off >= 0 ? tx_off + tx_sym : 0];
+  const uint32_t ep_cost = cost[eob_pt_cdf(1, pt, cls) + imin_(gl, 5)];
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int idx = gl + 16 * k, i = idx >> WL, j = idx & (W - 1);
+    const int pv = pred[idx];
+    gb->tbuf[i * P + j] = (int)src[idx] - pv;
+    gb->rec[idx] = (uint16_t)pv;
+  }
+  for (int i = gl; i < (st * (H + 4) + 3) / 4; i += 16) ((LDS uint32_t *)gb->lev)[i] = 0;
+  WAVE_SYNC();
+  int ck, rk; tx_kinds(txtype, &ck, &rk);
+  if (gl < W) {                                              // columns: H-point
+    int32_t x[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) x[r] = (int32_t)((uint32_t)gb->tbuf[r * P + gl] << 2);
+    tx1d<H>(x, ck, true);
+#pragma unroll
+    for (int r = 0; r < H; r++) gb->tbuf[r * P + gl] = rshift_round_(x[r], 1);
+  }
+  WAVE_SYNC();
+  if (gl < H) {                                              // rows: W-point, then the sqrt(2) scale of the 2:1 sizes
+    int32_t x[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) x[c] = gb->tbuf[gl * P + c];
+    tx1d<W>(x, rk, true);
+#pragma unroll
+    for (int c = 0; c < W; c++) gb->cbuf[gl * W + c] = (int32_t)(((long long)x[c] * 5793 + 2048) >> 12);
+  }
+  WAVE_SYNC();
+  const int dcq = f->dc_q[plane], acq = f->ac_q[plane];
+  const uint32_t dc_recip = f->dc_recip[plane], ac_recip = f->ac_recip[plane];
+  const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
+  const uint32_t thr = (uint32_t)acq - off_eob, uq = (uint32_t)acq;
+  int pos[IT]; uint32_t mag[IT]; int neg[IT];
+  int last = 0;
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int i = gl + 16 * k;
+    pos[k] = rect_scan_pos(WL, HL, cls, i);
+    const int c = gb->cbuf[pos[k]];
+    mag[k] = (uint32_t)iabs_(c); neg[k] = c < 0;
+    if (i >= 1 && mag[k] >= thr) last = i + 1;
+  }
+  last = row_max_i32(last);
+  const uint32_t x0 = (uint32_t)iabs_(gb->cbuf[0]) + dc_off;
+  uint32_t l0u = __umulhi(x0, dc_recip);
+  if (x0 - l0u * (uint32_t)dcq >= (uint32_t)dcq) l0u++;
+  const int l0 = (int)l0u;
+  int eob = last;
+  if (eob == 0) eob = l0 ? 1 : 0;
+  const int dmx = (1 << (7 + bd)) - 1, dmn = -(1 << (7 + bd));
+  int lvl[IT];
+  WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int i = gl + 16 * k;
+    int lv = 0;
+    if (i < eob) {
+      if (i == 0) lv = l0;
+      else {
+        const uint32_t a = mag[k];
+        uint32_t lv0 = __umulhi(a, ac_recip);
+        if (a - lv0 * uq >= uq) lv0++;
+        const uint32_t off = lv0 > 0 ? off1 : off0;
+        lv = (int)lv0 + ((a + off) >= (lv0 + 1) * uq);
+      }
+    }
+    lvl[k] = lv;
+    const int pp = pos[k];
+    gb->qc[pp] = neg[k] ? -lv : lv;
+    gb->lev[(pp >> WL) * st + (pp & (W - 1))] = (uint8_t)imin_(lv, 127);
+    uint32_t m = (uint32_t)lv * (uint32_t)(pp == 0 ? dcq : acq);
+    m &= 0xFFFFFF;
+    const int v = neg[k] ? -(int)m : (int)m;
+    gb->cbuf[pp] = v < dmn ? dmn : (v > dmx ? dmx : v);
+  }
+  WAVE_SYNC();
+  uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  int bits = 0, cul = 0, dcc = 0;
+  const int eob_pt = eob_to_pt(imax_(eob, 1));
+  const uint32_t ep = (uint32_t)__shfl((int)ep_cost, (LANE & 48) + eob_pt - 1);       // every row picks its own class's entry
+  if (eob > 0) {
+    if (tx_off >= 0) head += tx_cost;
+    head += ep;
+    if (eob_pt >= 3) {
+      const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+      head += cc.eobx[((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
+      head += 512u * (uint32_t)(nb - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+      const int c = gl + 16 * k;
+      if (c < eob) {
+        const int pp = pos[k], row = pp >> WL, col = pp & (W - 1), level = lvl[k];
+        const LDS uint8_t *L = gb->lev + row * st + col;
+        if (c == eob - 1) {
+          const int ctx = c == 0 ? 0 : (c <= nc / 8 ? 1 : (c <= nc / 4 ? 2 : 3));
+          bits += cc.beob[((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+        } else {
+          int ctx = base_ctx(L, st, cls, row, col);
+          if (cls == TXC_2D && !(row == 0 && col == 0)) {                          // spec Coeff_Base_Ctx_Offset of the 2:1 sizes
+            const int mg = imin_(L[1], 3) + imin_(L[st], 3) + imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3), m = imin_((mg + 1) >> 1, 4);
+            ctx = HL > WL ? m + (row < 2 ? 11 : (row + col < 4 ? 6 : 21)) : m + (col < 2 ? 16 : (row + col < 4 ? 6 : 21));
+          }
+          bits += cc.base[((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+        }
+        if (level > 2) {
+          const int off = ((txs_ctx * 2 + pt) * 21 + br_ctx(L, st, cls, row, col, c)) * CDF_COEFF_BR_STRIDE;
+          int rem = level - 3;
+          for (int idx = 0; idx < 4; idx++) { const int s2 = imin_(rem, 3); bits += cc.br[off + s2]; rem -= s2; if (s2 < 3) break; }
+        }
+        if (level) {
+          if (c == 0) { bits += cc.dcs[(pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + neg[k]]; dcc = neg[k] ? 1 : 2; }
+          else bits += 512;
+          if (level > 14) { const int len = 32 - __clz(level - 14); bits += 512 * (2 * len - 1); }
+        }
+        cul += level;
+      }
+    }
+  }
+  bits = row_sum_i32(bits);
+  cul = row_sum_i32(imin_(cul, 1 << 20));
+  dcc = row_max_i32(dcc);
+  res->eob = eob; res->cul = imin_(cul, 63); res->dcc = dcc; res->rate = head + (uint32_t)bits;
+  {
+    const int cbits = imax_(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
+    const bool act_r = gl < H && eob > 0, act_c = gl < W && eob > 0;
+    if (act_r) {
+      int32_t x[W];
+#pragma unroll
+      for (int j = 0; j < W; j++) x[j] = round2_(gb->cbuf[gl * W + j] * 2896, 12);
+      tx1d<W>(x, rk, false);
+#pragma unroll
+      for (int j = 0; j < W; j++) gb->tbuf[gl * P + j] = iclamp_(x[j], cmin, cmax);
+    }
+    WAVE_SYNC();
+    const int mx = (1 << bd) - 1;
+    if (act_c) {
+      int32_t x[H];
+#pragma unroll
+      for (int i = 0; i < H; i++) x[i] = gb->tbuf[i * P + gl];
+      tx1d<H>(x, ck, false);
+#pragma unroll
+      for (int i = 0; i < H; i++) gb->rec[i * W + gl] = (uint16_t)iclamp_((int)gb->rec[i * W + gl] + round2_(x[i], 4), 0, mx);
+    }
+    WAVE_SYNC();
+  }
+  // distortion: luma = the two 4x4 cells priced like psy_dist_wave (boost x activity), chroma (psv_a < 0) = SSE x activity
+  int se[2] = { 0, 0 }, sd[2] = { 0, 0 }, qd[2] = { 0, 0 };
+#pragma unroll
+  for (int k = 0; k < IT; k++) {
+    const int idx = gl + 16 * k, i = idx >> WL, j = idx & (W - 1), cell = W == 8 ? (j >> 2) : (i >> 2);
+    const int rv = gb->rec[idx], d = (int)src[idx] - rv;
+    se[cell] += __mul24(d, d); sd[cell] += rv; qd[cell] += __mul24(rv, rv);
+  }
+  if (psv_a >= 0) {
+    int dist = 0;
+#pragma unroll
+    for (int cell = 0; cell < 2; cell++)
+      dist += psy_cell_dist((uint32_t)row_sum_i32(se[cell]), (uint32_t)row_sum_i32(sd[cell]), (uint32_t)row_sum_i32(qd[cell]), (uint32_t)(cell ? psv_b : psv_a), (uint32_t)psy_act, 4, bd);
+    res->sse = dist;
+  } else res->sse = (int)(((unsigned long long)(uint32_t)row_sum_i32(se[0] + se[1]) * (uint32_t)psy_act + 8192) >> 14);
+}
+
 // ---- the block search for an 8x4 / 4x8 block (oracle try_block with bs = BS_8X4 / BS_4X8): same candidates, same order, same tie-breaks ----
 template <int WL, int HL> __device__ inline void commit_rect(const LDS FrameDev *f, int plane, int r, int c, const LDS uint16_t *rec, const LDS int32_t *qc, int eob, int cul, int dcc) {
   constexpr int W = 1 << WL, H = 1 << HL;
@@ -425,6 +596,50 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   for (int ci = W; ci < ncand; ci += NW) predict_block_wh(f, x, y, WL, HL, availL, availU, SH->order[ci], 0, ftype_y, ra, rl, wa, wl, S->etmp, pcache + ci * NN);
   WG_SYNC();
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 }; uint32_t my_mrate = 0;
+  // up to sixteen (mode x tx type) trials in ONE round, four per wave (one per 16-lane row, eval_group_wh): the 3 x 5 trials of speed 4
+  constexpr bool CAN_GROUP = NW == 4 && MAXN <= 32;
+  bool grouped = false, parked = false; int my_g = 0;
+  if constexpr (CAN_GROUP) grouped = true;
+  if constexpr (CAN_GROUP) if (grouped) {
+    const int g = GROUP_ID, total = ncand * ntx, rounds = (total + 15) >> 4;
+    LDS uint16_t *park_rec = (LDS uint16_t *)S->dcp; LDS int32_t *park_qc = (LDS int32_t *)(S->dcp + 64);     // between rounds a wave parks its best candidate here (dcp is idle until chroma)
+    for (int rd = 0; rd < rounds; rd++) {
+      int e;
+      if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W : (W < 3 ? W * 5 + 4 : -1);   // a wave's rows 0..2 share the tx type (no divergence in the 1-D networks)
+      else e = rd * 16 + W * 4 + g;
+      const bool live = e >= 0 && e < total;
+      const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
+      const uint32_t mode_rate = ycost[m];
+      int ns2, set2;
+      const int tx_off = rect_tx_cdf(f, m, &ns2, &set2);
+      int txtype;
+      if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
+      else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
+      GroupRes gr;
+      eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[0], pcache + ci * NN, 0, txtype, sctx_y, dctx_y, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0,
+                            f->tune_psnr ? -1 : psv_a, psv_b, act, &gr);
+      long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
+      if (!live) j = J_INF;
+      bool improved = false;
+#pragma unroll
+      for (int gg = 0; gg < 4; gg++) {
+        const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+        const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+        if (jg < my_j || (jg == my_j && eg < my_e)) {
+          my_j = jg; my_e = eg; my_g = gg; improved = true;
+          my_mode = __builtin_amdgcn_readlane(m, gg * 16); my_tx = __builtin_amdgcn_readlane(txtype, gg * 16);
+          my_tr.eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); my_tr.cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); my_tr.dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+          my_mrate = (uint32_t)__builtin_amdgcn_readlane((int)mode_rate, gg * 16);
+        }
+      }
+      if (rounds > 1 && improved) {                        // wave-uniform
+        for (int i = LANE; i < NN; i += 64) { park_rec[i] = S->grp[my_g].rec[i]; park_qc[i] = S->grp[my_g].qc[i]; }
+        parked = true;
+        WAVE_SYNC();
+      }
+    }
+  }
+  if (!grouped)
   for (int e = W; e < ncand * ntx; e += NW) {
     const int ci = e / ntx, ti = e - ci * ntx, m = SH->order[ci];
     const LDS uint16_t *cpred = pcache + ci * NN;
@@ -446,13 +661,18 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   const long long best_j = SH->wbest_j[win];
   if (W == win) {
     const int b = cur ^ 1;
-    commit_rect<WL, HL>(f, 0, r, c, S->rec[b], S->qc[b], my_tr.eob, my_tr.cul, my_tr.dcc);
+    const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
+    if constexpr (CAN_GROUP) if (grouped) {
+      if (parked) { best_rec = (const LDS uint16_t *)S->dcp; best_qc = (const LDS int32_t *)(S->dcp + 64); }
+      else { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
+    }
+    commit_rect<WL, HL>(f, 0, r, c, best_rec, best_qc, my_tr.eob, my_tr.cul, my_tr.dcc);
     fill_rect<WL, HL>(f->m_ymode, ms, r, c, my_mode);
     fill_rect<WL, HL>((uint8_t *)f->m_angle_y, ms, r, c, 0);
     fill_rect<WL, HL>(f->m_txtype, ms, r, c, my_tr.eob ? my_tx : DCT_DCT);
     fill_rect<WL, HL>(f->m_bsize, ms, r, c, BSR);
     fill_rect<WL, HL>(f->m_txsize, ms, r, c, BSR);
-    if (f->np > 1) for (int i = LANE; i < NN; i += 64) SH->luma_rec[i] = S->rec[b][i];
+    if (f->np > 1) for (int i = LANE; i < NN; i += 64) SH->luma_rec[i] = best_rec[i];
     if (LANE == 0) { SH->lm_mode = my_mode; SH->lm_eob = my_tr.eob; SH->lm_mode_j = ((long long)my_mrate * f->rdmult + 256) >> 9; SH->lm_tx = my_tr.cul; SH->lm_delta = my_tr.dcc; }
   }
   WG_SYNC();
@@ -511,7 +731,29 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
         }
         WG_SYNC();
         const int ssc = sub[8], sdc = sub[9];
-        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, scur = 0;
+        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, scur = 0, sg = 0;
+        bool sgrouped = false;
+        if constexpr (CAN_GROUP) sgrouped = sntx == 5;
+        if constexpr (CAN_GROUP) if (sgrouped && W < 2) {        // the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1 (as in the square trial)
+          const int g = GROUP_ID, e = W == 0 ? g + 1 : (g == 0 ? 0 : 64);
+          const bool live = e < sntx;
+          const int txtype = sym_to_txtype(stx_set, live ? e : 0);
+          GroupRes gr;
+          eval_group<4>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * 16, SH->spred, 0, 0, txtype, ssc, sdc, stx_off, txtype_to_sym(stx_set, txtype),
+                        f->tune_psnr ? -1 : SH->psv4[q], SH->pact[0], &gr);
+          long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+          if (!live) j = J_INF;
+#pragma unroll
+          for (int gg = 0; gg < 4; gg++) {
+            const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+            const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+            if (jg < sj || (jg == sj && eg < se)) {
+              sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
+              s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+            }
+          }
+        }
+        if (!sgrouped)
         for (int e = W; e < sntx; e += NW) {
           int txtype;
           if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
@@ -528,6 +770,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
         const long long sub_j = SH->wbest_j[sw];
         if (W == sw) {
           const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
+          if constexpr (CAN_GROUP) if (sgrouped) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
           for (int i = LANE; i < 16; i += 64) { split_rec[(bi * 4 + (i >> 2)) * W_ + bj * 4 + (i & 3)] = srec[i]; split_qc[q * 16 + i] = sqc[i]; }
           if (LANE == 0) {
             sub[q * 4 + 0] = s_eob ? stx : DCT_DCT; sub[q * 4 + 1] = s_eob; sub[q * 4 + 2] = s_cul; sub[q * 4 + 3] = s_dcc;
@@ -563,8 +806,101 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   }
   if (luma_j >= budget) return luma_j;
   long long total_j = luma_j;
+  // ---- chroma with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four waves (plane x half of the range), then every
+  // candidate of a plane in one grouped evaluation (waves 0 and 2, one candidate per 16-lane row) -- the square path's scheme (tile_search.h) ----
+  bool cgrouped = false;
+  if constexpr (CAN_GROUP) cgrouped = f->np > 1 && !f->complex_modes;
+  if constexpr (CAN_GROUP) if (cgrouped) {
+    const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
+    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = f->reduced_tx_set ? 2 : 1;
+    const int mx = (1 << f->bd) - 1;
+    {
+      const int p = (W >> 1) + 1, half = W & 1;
+      const LDS uint16_t *luma = SH->luma_rec;
+      int lsum = LANE < NN ? (int)luma[LANE] << 3 : 0;
+      lsum = wave_sum_i32(lsum);
+      const int avg = round2_(lsum, WL + HL);
+      predict_block_wh(f, x, y, WL, HL, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
+      long long best_sse = J_INF; int best_idx = 1 << 20;
+      const int l = LANE < NN ? ((int)luma[LANE] << 3) - avg : 0, dcv = LANE < NN ? (int)S->dcp[LANE] : 0, sv = LANE < NN ? (int)SH->srcb[p][LANE] : 0;
+      if (half == 0) { const int d = sv - dcv; best_sse = (long long)wave_sum_i32(LANE < NN ? d * d : 0); best_idx = -1; }
+      const int la = iabs_(l), ng = l < 0;
+#pragma unroll
+      for (int kq = 0; kq < 8; kq++) {                                       // scan position 2k is alpha +(k + 1), 2k + 1 is -(k + 1)
+        const int mag = half * 8 + kq + 1;
+        const int rr = round2_(__mul24(mag, la), 6), sc = ng ? -rr : rr;
+        const int dp = sv - iclamp_(dcv + sc, 0, mx), dm = sv - iclamp_(dcv - sc, 0, mx);
+        const long long ep = (long long)wave_sum_i32(LANE < NN ? __mul24(dp, dp) : 0), em = (long long)wave_sum_i32(LANE < NN ? __mul24(dm, dm) : 0);
+        if (ep < best_sse) { best_sse = ep; best_idx = half * 16 + 2 * kq; }
+        if (em < best_sse) { best_sse = em; best_idx = half * 16 + 2 * kq + 1; }
+      }
+      if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
+    }
+    WG_SYNC();
+    int alpha_u = 0, alpha_v = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) {
+      const int idx = SH->ca_sse[pp][1] < SH->ca_sse[pp][0] ? SH->ca_idx[pp][1] : SH->ca_idx[pp][0];
+      const int al = idx < 0 ? 0 : ((idx & 1) ? -((idx >> 1) + 1) : ((idx >> 1) + 1));
+      if (pp == 0) alpha_u = al; else alpha_v = al;
+    }
+    const int cfl_ok = alpha_u != 0 || alpha_v != 0;
+    GroupRes gr = { 0, 0, 0, 0, 0 };
+    const int cw = (W & 1) == 0;                              // waves 0 (plane U) and 2 (plane V): their S->dcp already holds the plane's DC prediction
+    if (cw) {
+      const int p = (W >> 1) + 1;
+      if (nplain == 2) predict_block_wh(f, x, y, WL, HL, availL, availU, best_mode, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->pred + NN);
+      {
+        const int al = p == 1 ? alpha_u : alpha_v;
+        LDS uint16_t *cp = S->pred + (nc - 1) * NN;
+        int lsum = LANE < NN ? (int)SH->luma_rec[LANE] << 3 : 0;
+        lsum = wave_sum_i32(lsum);
+        const int avg = round2_(lsum, WL + HL);
+        if (LANE < NN) { const int l = ((int)SH->luma_rec[LANE] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6); cp[LANE] = (uint16_t)iclamp_((int)S->dcp[LANE] + sc, 0, mx); }
+      }
+      WAVE_SYNC();
+      const int g = GROUP_ID, cand = imin_(g, nc - 1);
+      const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
+      int txtype = mode_to_txtype(um);
+      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
+      eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * NN), p, txtype,
+                            SH->sctx[p], SH->dctx[p], -1, 0, -1, 0, SH->cact, &gr);
+      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
+    }
+    WG_SYNC();
+    long long best_uv = J_INF; int bc = 0, b_sign = 0;
+#pragma unroll
+    for (int cnd = 0; cnd < 3; cnd++) {
+      if (cnd < nc) {
+        const int is_cfl = cnd == nc - 1, um = is_cfl ? UV_CFL_PRED : (cnd == 0 ? DC_PRED : best_mode);
+        int jsign = 0;
+        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, false, 0, is_cfl && cfl_ok, alpha_u, alpha_v, &jsign);
+        if (!is_cfl || cfl_ok) {
+          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+          if (j < best_uv) { best_uv = j; bc = cnd; b_sign = jsign; }
+        }
+      }
+    }
+    if (cw) {
+      const int p = (W >> 1) + 1, chose_cfl = bc == nc - 1;
+      const int beob = __builtin_amdgcn_readlane(gr.eob, bc * 16), bcul = __builtin_amdgcn_readlane(gr.cul, bc * 16), bdcc = __builtin_amdgcn_readlane(gr.dcc, bc * 16);
+      commit_rect<WL, HL>(f, p, r, c, S->grp[bc].rec, S->grp[bc].qc, beob, bcul, bdcc);
+      if (LANE == 0) SH->ceob[p - 1] = beob;
+      if (p == 1) {
+        fill_rect<WL, HL>(f->m_uvmode, ms, r, c, chose_cfl ? UV_CFL_PRED : (bc == 0 ? DC_PRED : best_mode));
+        fill_rect<WL, HL>((uint8_t *)f->m_angle_uv, ms, r, c, 0);
+        fill_rect<WL, HL>(f->m_cfl_sign, ms, r, c, chose_cfl ? b_sign : 0);
+        fill_rect<WL, HL>(f->m_cfl_au, ms, r, c, (chose_cfl && alpha_u) ? iabs_(alpha_u) - 1 : 0);
+        fill_rect<WL, HL>(f->m_cfl_av, ms, r, c, (chose_cfl && alpha_v) ? iabs_(alpha_v) - 1 : 0);
+      }
+    }
+    WG_SYNC();
+    any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
+    total_j += best_uv;
+  }
   // ---- chroma: the candidates one after the other, plane p on wave p - 1 (oracle order: DC, the luma mode, [the other modes,] CfL) ----
-  if constexpr (NW >= 2) if (f->np > 1) {
+  if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     unsigned long long cand_pack = 0; int nc = 0;
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
@@ -652,4 +988,3 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   WG_SYNC();
   return total_j;
 }
-#endif  // MI_RECT_PART

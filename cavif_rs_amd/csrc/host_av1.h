@@ -142,6 +142,17 @@ inline uint32_t neg_log2_q9(uint32_t p) {                      // (15 - log2 p) 
   for (int i = 0; i < 9; i++) { x = (x * x) >> 31; frac <<= 1; if (x >> 32) { frac |= 1; x >>= 1; } }
   return (uint32_t)(15 * 512 - (msb * 512 + (int)frac));
 }
+// the rows of the CDF tables that carry symbol probabilities: X(offset, stride, rows, alphabet size).  One list for the host table (initial CDFs)
+// and the device kernel that prices a tile's final CDFs (cdf_cost_kernel, two-pass pricing).
+#define MI_COST_ROWS(X) \
+  X(CDF_KF_Y, CDF_KF_Y_STRIDE, 25, 13) X(CDF_ANGLE, CDF_ANGLE_STRIDE, 8, 7) X(CDF_UV_NOCFL, CDF_UV_NOCFL_STRIDE, 13, 13) X(CDF_UV_CFL, CDF_UV_CFL_STRIDE, 13, 14) \
+  X(CDF_PARTITION, CDF_PARTITION_STRIDE, 4, 4) X(CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10) X(CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8) \
+  X(CDF_SKIP, CDF_SKIP_STRIDE, 3, 2) X(CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7) X(CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5) \
+  X(CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8) X(CDF_CFL_ALPHA, CDF_CFL_ALPHA_STRIDE, 6, 16) X(CDF_TX_SIZE, CDF_TX_SIZE_STRIDE, 3, 2) X(CDF_TX_SIZE + 3 * CDF_TX_SIZE_STRIDE, CDF_TX_SIZE_STRIDE, 9, 3) \
+  X(CDF_TXB_SKIP, CDF_TXB_SKIP_STRIDE, 65, 2) X(CDF_EOB_EXTRA, CDF_EOB_EXTRA_STRIDE, 90, 2) X(CDF_DC_SIGN, CDF_DC_SIGN_STRIDE, 6, 2) \
+  X(CDF_COEFF_BR, CDF_COEFF_BR_STRIDE, 210, 4) X(CDF_COEFF_BASE, CDF_COEFF_BASE_STRIDE, 420, 4) X(CDF_COEFF_BASE_EOB, CDF_COEFF_BASE_EOB_STRIDE, 40, 3) \
+  X(CDF_EOB_PT_16, CDF_EOB_PT_16_STRIDE, 4, 5) X(CDF_EOB_PT_32, CDF_EOB_PT_32_STRIDE, 4, 6) X(CDF_EOB_PT_64, CDF_EOB_PT_64_STRIDE, 4, 7) \
+  X(CDF_EOB_PT_128, CDF_EOB_PT_128_STRIDE, 4, 8) X(CDF_EOB_PT_256, CDF_EOB_PT_256_STRIDE, 4, 9) X(CDF_EOB_PT_512, CDF_EOB_PT_512_STRIDE, 4, 10) X(CDF_EOB_PT_1024, CDF_EOB_PT_1024_STRIDE, 4, 11)
 inline std::vector<uint16_t> build_cost_table(int qctx) {
   const uint16_t *cdf = av1_default_cdfs + (size_t)qctx * CDF_TOTAL;
   std::vector<uint16_t> cost(CDF_TOTAL, 0);
@@ -152,18 +163,9 @@ inline std::vector<uint16_t> build_cost_table(int qctx) {
       cost[off + r * stride + s] = (uint16_t)neg_log2_q9(hi - lo);
     }
   };
-  rows(CDF_KF_Y, CDF_KF_Y_STRIDE, 25, 13); rows(CDF_ANGLE, CDF_ANGLE_STRIDE, 8, 7);
-  rows(CDF_UV_NOCFL, CDF_UV_NOCFL_STRIDE, 13, 13); rows(CDF_UV_CFL, CDF_UV_CFL_STRIDE, 13, 14);
-  rows(CDF_PARTITION, CDF_PARTITION_STRIDE, 4, 4); rows(CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10);
-  rows(CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8);
-  rows(CDF_SKIP, CDF_SKIP_STRIDE, 3, 2); rows(CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7); rows(CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5);
-  rows(CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8); rows(CDF_CFL_ALPHA, CDF_CFL_ALPHA_STRIDE, 6, 16);
-  rows(CDF_TX_SIZE, CDF_TX_SIZE_STRIDE, 3, 2); rows(CDF_TX_SIZE + 3 * CDF_TX_SIZE_STRIDE, CDF_TX_SIZE_STRIDE, 9, 3);
-  rows(CDF_TXB_SKIP, CDF_TXB_SKIP_STRIDE, 65, 2); rows(CDF_EOB_EXTRA, CDF_EOB_EXTRA_STRIDE, 90, 2); rows(CDF_DC_SIGN, CDF_DC_SIGN_STRIDE, 6, 2);
-  rows(CDF_COEFF_BR, CDF_COEFF_BR_STRIDE, 210, 4); rows(CDF_COEFF_BASE, CDF_COEFF_BASE_STRIDE, 420, 4); rows(CDF_COEFF_BASE_EOB, CDF_COEFF_BASE_EOB_STRIDE, 40, 3);
-  rows(CDF_EOB_PT_16, CDF_EOB_PT_16_STRIDE, 4, 5); rows(CDF_EOB_PT_32, CDF_EOB_PT_32_STRIDE, 4, 6); rows(CDF_EOB_PT_64, CDF_EOB_PT_64_STRIDE, 4, 7);
-  rows(CDF_EOB_PT_128, CDF_EOB_PT_128_STRIDE, 4, 8); rows(CDF_EOB_PT_256, CDF_EOB_PT_256_STRIDE, 4, 9);
-  rows(CDF_EOB_PT_512, CDF_EOB_PT_512_STRIDE, 4, 10); rows(CDF_EOB_PT_1024, CDF_EOB_PT_1024_STRIDE, 4, 11);
+#define MI_ROW_(o, st, n, k) rows(o, st, n, k);
+  MI_COST_ROWS(MI_ROW_)
+#undef MI_ROW_
   return cost;
 }
 

@@ -75,17 +75,11 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
   if (pass == 1 && r == 0) return 0;
   const int ms = f->mi_stride;
   const uint8_t *txm = plane == 0 ? f->m_txsize : f->m_bsize;     // luma: the block's transform size; chroma (4:4:4): the block's largest transform
-#if MI_RECT_PART
   // 2:1 transform codes (5 = 4x8, 6 = 8x4): the extent across the edge direction -- width for vertical edges, height for horizontal ones
   auto ext = [&](int code) { return code <= 4 ? 4 << code : (((code == 5) == (pass == 0)) ? 4 : 8); };
   const int cur = imin_(64, ext(txm[r * ms + c]));
   if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;
   const int prev = pass == 0 ? imin_(64, ext(txm[r * ms + c - 1])) : imin_(64, ext(txm[(r - 1) * ms + c]));
-#else
-  const int cur = imin_(64, 4 << txm[r * ms + c]);
-  if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;
-  const int prev = pass == 0 ? imin_(64, 4 << txm[r * ms + c - 1]) : imin_(64, 4 << txm[(r - 1) * ms + c]);
-#endif
   const int base = imin_(cur, prev);
   return plane == 0 ? imin_(16, base) : imin_(8, base);
 }
@@ -365,6 +359,9 @@ __global__ __launch_bounds__(256) void activity_kernel(const FrameDev *__restric
   const FrameDev *f = frames + blockIdx.y;
   const int cw = f->pw >> 3, chh = f->ph >> 3, cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= cw * chh || frame_idle(f)) return;
+  // the state the later stages expect zeroed (decoded flags, deblock tallies, the tile search's progress counters): cleared here, ahead of the
+  // tile search on the same stream, instead of one memset per frame queued between the kernels
+  for (int i = cell; i < f->zero_words; i += cw * chh) ((uint32_t *)f->m_decoded)[i] = 0u;
   const int cy = cell / cw, cx = cell - cy * cw;
   uint32_t s8 = 0, q8 = 0;
   for (int k = 0; k < 4; k++) {

@@ -20,6 +20,15 @@
 #include "loopfilter.h"
 #include "restoration.h"
 
+// The product library reads no environment variables; probe builds (-DMI_TUNING_KNOBS: tools/) get MI_AVIF_TIMING=1 (host-side timeline on stderr),
+// MI_K1_GRID_PER_CU=n (fewer persistent search workgroups per CU) and, with -DMI_DEBUG_HOOKS=1, MI_DEBUG_LEVEL (bisect levels of the tile search).
+static inline bool mi_timing_enabled() {
+#ifdef MI_TUNING_KNOBS
+  static const bool on = getenv("MI_AVIF_TIMING") != nullptr; return on;
+#else
+  return false;
+#endif
+}
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "mi_avif: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return MI_ENCODING_ERROR; } } while (0)
 
 namespace mi {
@@ -34,6 +43,35 @@ __global__ void pack_tiles_kernel(const FrameDev *frames, const TileJob *jobs, i
   const uint8_t *src = f->tile_out + (size_t)ti * f->tile_out_cap;
   uint8_t *dst = packed + offsets[job];
   for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- two-pass pricing (mi_av1_config.rdo_passes = 2): the rate table of the CDFs a tile ended its first pass with ----
+__device__ inline uint32_t neg_log2_q9_dev(uint32_t p) {      // host_av1.h neg_log2_q9, integer only: (15 - log2 p) * 512
+  if (p < 1u) p = 1u;
+  const int msb = 31 - __clz(p);
+  unsigned long long x = (unsigned long long)p << (31 - msb);
+  uint32_t frac = 0;
+  for (int i = 0; i < 9; i++) { x = (x * x) >> 31; frac <<= 1; if (x >> 32) { frac |= 1; x >>= 1; } }
+  return (uint32_t)(15 * 512 - (msb * 512 + (int)frac));
+}
+// grid (tiles, frames): tile t of the frame; also switches the frame over to its second pass (tile_cost set, cdf_out cleared) -- by the
+// block of tile 0, after a grid-wide ... no: by a separate tiny launch (pass_flip_kernel), the frames are read by every block here
+__global__ __launch_bounds__(256) void cdf_cost_kernel(const FrameDev *frames) {
+  const FrameDev *f = frames + blockIdx.y;
+  const int tile = blockIdx.x;
+  if (tile >= f->tile_cols * f->tile_rows || f->cdf_out == nullptr || frame_idle(f)) return;
+  const uint16_t *cdf = f->cdf_out + (size_t)tile * CDF_TOTAL;
+  uint16_t *cost = f->tile_cost_buf + (size_t)tile * CDF_TOTAL;
+  for (int i = threadIdx.x; i < CDF_TOTAL; i += 256) cost[i] = 0;
+  __syncthreads();
+#define MI_ROW_(o, st, n, k) for (int i = threadIdx.x; i < (n) * (k); i += 256) { const int r = i / (k), s = i - r * (k); const uint16_t *row = cdf + (o) + r * (st); \
+    cost[(o) + r * (st) + s] = (uint16_t)neg_log2_q9_dev((s > 0 ? (uint32_t)row[s - 1] : 32768u) - (uint32_t)row[s]); }
+  MI_COST_ROWS(MI_ROW_)
+#undef MI_ROW_
+}
+__global__ void pass_flip_kernel(FrameDev *frames, int nframes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nframes && frames[i].cdf_out != nullptr) { frames[i].tile_cost = frames[i].tile_cost_buf; frames[i].cdf_out = nullptr; }
 }
 
 // ---- per-device read-only tables ----
@@ -109,6 +147,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   // state the kernels expect zeroed before every encode, in one block (one memset): decoded flags + deblock tallies
   d.m_decoded = take(zeroed_bytes(p)); d.lf_tally = (long long *)(d.m_decoded + align_up(nmi, 256));
   d.sb_prog = (int *)(d.m_decoded + align_up(nmi, 256) + align_up(6 * 65 * sizeof(long long), 256));
+  d.zero_words = (int)((zeroed_bytes(p) + 3) / 4);
   d.lf_out = (int *)take(64);
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
@@ -122,6 +161,8 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.tile_out = take((size_t)p.ntiles * tile_cap);
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
+  d.tile_cost = nullptr; d.cdf_out = nullptr; d.tile_cost_buf = nullptr;
+  if (p.cfg.rdo_passes >= 2) { d.cdf_out = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); d.tile_cost_buf = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); }
   d.prof_out = nullptr;
   d.tile_out_cap = tile_cap;
   return off;
@@ -250,6 +291,12 @@ static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_m
 namespace mi {
 // Builds the launch's work list -- per block-size class, the superblocks of the class's tiles in (2 * row + column, job) order; jobs are indexed inside
 // their class segment of d_jobs -- and enqueues one queue launch per class on `s`.
+// the launches over a work list that is already on the device (the second pass of a two-pass encode reuses the first one's)
+static int search_launch(SearchQueue &q, bool bottomup, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
+  for (int cls = 2; cls <= 4; cls++)
+    HIP_OK(launch_search(cls, bottomup, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
+  return MI_OK;
+}
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   q.items.clear();
   size_t snap_need = 0;
@@ -280,9 +327,7 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
   if (snap_need > q.snap_bytes) { if (q.d_snap) (void)hipFree(q.d_snap); q.d_snap = nullptr; q.snap_bytes = snap_need; HIP_OK(hipMalloc(&q.d_snap, snap_need)); }
   memcpy(q.h_items, q.items.data(), q.items.size() * sizeof(SbItem));
   HIP_OK(hipMemcpyAsync(q.d_items, q.h_items, q.items.size() * sizeof(SbItem), hipMemcpyHostToDevice, s));
-  for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_search(cls, bottomup, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
-  return MI_OK;
+  return search_launch(q, bottomup, class_begin, d_frames, d_jobs, device, s);
 }
 }  // namespace mi
 
@@ -299,7 +344,7 @@ struct mi_batch {
   int *d_alpha_flags = nullptr; std::vector<int> alpha_flags;
   uint8_t *d_clean = nullptr, *d_clean_tmp = nullptr; unsigned long long *d_alpha_acc = nullptr;   // dirty-alpha cleaner (RGBA, UnassociatedClean)
   std::vector<FramePlan> frames;                                  // colour frames [0..n), alpha frames after
-  uint8_t *d_arena = nullptr; size_t arena_bytes = 0;
+  uint8_t *d_arena = nullptr; size_t arena_bytes = 0, aux_bytes = 0;   // aux: pre-carry units + symbol records
   FrameDev *d_frames = nullptr; TileJob *d_jobs = nullptr; uint16_t *d_precarry = nullptr; uint32_t pre_cap = 0;
   uint32_t *d_recbuf = nullptr; uint32_t rec_cap = 0;             // K4's symbol records: three rotating superblock buffers per tile
   uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0, packed_max = 0; unsigned long long *d_prof = nullptr;
@@ -321,7 +366,7 @@ static int batch_plan(mi_batch *b, bool with_alpha_frames) {
     FramePlan p; p.image = image; p.is_alpha = alpha;
     mi_av1_config &c = p.cfg;
     c.width = b->w; c.height = b->h; c.bit_depth = (uint8_t)b->depth; c.quantizer = (uint8_t)(alpha ? aquant : quantizer);
-    c.chroma = alpha ? 1 : 0; c.pixel_range = 1; c.threads = b->enc.threads; c.device = b->device; c.tiles_override = b->enc.tiles_override;
+    c.chroma = alpha ? 1 : 0; c.pixel_range = 1; c.threads = b->enc.threads; c.device = b->device; c.tiles_override = b->enc.tiles_override; c.rdo_passes = (uint8_t)(b->enc.rdo_passes >= 2 ? 2 : 1);
     c.has_color_desc = alpha ? 0 : 1; c.primaries = 1; c.transfer = 13; c.matrix = b->enc.color_model == 1 ? 0 : 6;
     tweaks_from_preset(b->enc.speed, c.quantizer, &c);
     plan_geometry(p);
@@ -370,6 +415,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_precarry, (size_t)max_tiles * (size_t)max_cap * 2));
   { int max_np = 1; for (auto &p : worst) max_np = std::max(max_np, p.np); b->rec_cap = MI_K4_SB_RECORDS(max_np); }
   HIP_OK(hipMalloc(&b->d_recbuf, (size_t)max_tiles * 3 * (size_t)b->rec_cap * 4));
+  b->aux_bytes = (size_t)max_tiles * (size_t)max_cap * 2 + (size_t)max_tiles * 3 * (size_t)b->rec_cap * 4;
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
   HIP_OK(hipMalloc(&b->d_prof, std::max<size_t>(max_tiles, 2048) * 128 * 8));   // profiling builds: per tile job (K4) / per persistent workgroup (K1)
   // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
@@ -412,7 +458,7 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   if (e->speed < 1 || e->speed > 10 || !(e->quality >= 1.f && e->quality <= 100.f) || !(e->alpha_quality >= 1.f && e->alpha_quality <= 100.f)) return nullptr;
   if (mi_device_count() <= e->device) { fprintf(stderr, "mi_avif: no HIP device %d (the HIP path is mandatory; there is no CPU fallback)\n", e->device); return nullptr; }
   if (hipSetDevice(e->device) != hipSuccess) return nullptr;
-  const bool timing = getenv("MI_AVIF_TIMING") != nullptr;
+  const bool timing = mi_timing_enabled();
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3; };
   mi_batch *b = new mi_batch();
@@ -554,27 +600,35 @@ int mi_batch_encode_async(mi_batch *b) {
     FramePlan &p = b->frames[k];
     max_mi_cells = std::max(max_mi_cells, p.mi_cols * p.mi_rows * 4); max_sb = std::max(max_sb, p.sb_cols * p.sb_rows);
     if (p.cfg.lrf) { max_lr = std::max(max_lr, lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height)); if (p.cfg.sgr_full) max_lr_sets = 16; }
-    // clear the state the kernels rely on being zero
-    HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   }
   for (size_t k = 0; k < b->frames.size(); k++) b->h_frames[k] = b->frames[k].dev;          // pinned: the copies below never block the host
   memcpy(b->h_jobs, b->jobs.data(), sizeof(TileJob) * b->jobs.size());
   HIP_OK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(FrameDev) * b->frames.size(), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(TileJob) * b->jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)b->jobs.size(), nframes = (int)b->frames.size();
-  // ---- activity mask (Tune::Psychovisual), then K1 tile search
-  { int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
-    hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames); }
-  HIP_OK(hipEventRecord(b->ev[1], s));
-  if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
-  // ---- K2a/K2 deblock (level search + filter), K3 CDEF
-  HIP_OK(hipEventRecord(b->ev[2], s));
-  HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
-  // ---- K4 entropy coding
-  HIP_OK(hipEventRecord(b->ev[4], s));
-  for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap,
-                          b->d_recbuf + (size_t)class_begin[cls] * 3 * (size_t)b->rec_cap, b->rec_cap, s));
+  // ---- activity mask (Tune::Psychovisual) -> K1 tile search -> K2a/K2 deblock (level search + filter), K3 CDEF, K5 restoration -> K4 entropy coding.
+  // A two-pass encode (rdo_passes = 2) runs the chain twice: between the passes every tile's final CDFs become its rate table, the frames switch
+  // over to them, and the activity kernel clears the per-encode state again; the events time the last pass.
+  int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
+  const int passes = b->frames[0].cfg.rdo_passes >= 2 ? 2 : 1;
+  const bool bottomup = b->frames[0].cfg.encode_bottomup != 0;
+  for (int pass = 0; pass < passes; pass++) {
+    if (pass == 1) {
+      int max_tiles = 1; for (auto &p : b->frames) max_tiles = std::max(max_tiles, p.ntiles);
+      hipLaunchKernelGGL(cdf_cost_kernel, dim3(max_tiles, nframes), dim3(256), 0, s, b->d_frames);
+      hipLaunchKernelGGL(pass_flip_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, b->d_frames, nframes);
+    }
+    hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames);
+    HIP_OK(hipEventRecord(b->ev[1], s));
+    if (pass == 0) { if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st; }
+    else if (int st = search_launch(b->queue, bottomup, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
+    HIP_OK(hipEventRecord(b->ev[2], s));
+    HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
+    HIP_OK(hipEventRecord(b->ev[4], s));
+    for (int cls = 2; cls <= 4; cls++)
+      HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap,
+                            b->d_recbuf + (size_t)class_begin[cls] * 3 * (size_t)b->rec_cap, b->rec_cap, s));
+  }
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
@@ -683,19 +737,19 @@ void mi_batch_destroy(mi_batch *b) {
 // _batch and _stream therefore take their batch objects from a process-wide pool keyed by (device, capacity, shape, settings) and
 // hand them back afterwards; mi_release_cached() (or process exit) frees them.  Explicit mi_batch_create objects are not pooled.
 struct PoolKey {
-  int device, cap, channels; uint32_t w, h; float quality, alpha_quality; uint8_t speed, color_model, depth, alpha_mode; int32_t threads, tiles_override;
+  int device, cap, channels; uint32_t w, h; float quality, alpha_quality; uint8_t speed, color_model, depth, alpha_mode; int32_t threads, tiles_override, rdo_passes;
   bool operator==(const PoolKey &o) const {
     return device == o.device && cap == o.cap && channels == o.channels && w == o.w && h == o.h && quality == o.quality && alpha_quality == o.alpha_quality &&
-           speed == o.speed && color_model == o.color_model && depth == o.depth && alpha_mode == o.alpha_mode && threads == o.threads && tiles_override == o.tiles_override;
+           speed == o.speed && color_model == o.color_model && depth == o.depth && alpha_mode == o.alpha_mode && threads == o.threads && tiles_override == o.tiles_override && rdo_passes == o.rdo_passes;
   }
 };
 static PoolKey pool_key(const mi_ravif_encoder *e, int cap, uint32_t w, uint32_t h, int channels) {
-  return PoolKey{ e->device, cap, channels, w, h, e->quality, e->alpha_quality, e->speed, e->color_model, e->depth, e->alpha_mode, e->threads, e->tiles_override };
+  return PoolKey{ e->device, cap, channels, w, h, e->quality, e->alpha_quality, e->speed, e->color_model, e->depth, e->alpha_mode, e->threads, e->tiles_override, e->rdo_passes >= 2 ? 2 : 1 };
 }
 static std::mutex g_pool_mu;
 static std::vector<std::pair<PoolKey, mi_batch *>> g_pool;          // oldest first; never destroyed at process exit (the runtime may be gone by then)
-static size_t batch_footprint(const mi_batch *b) { return b->arena_bytes + 3 * b->pixel_bytes + b->packed_cap; }
-static constexpr size_t MI_POOL_MAX_ITEMS = 12, MI_POOL_MAX_BYTES = (size_t)96 << 30;
+static size_t batch_footprint(const mi_batch *b) { return b->arena_bytes + b->aux_bytes + 3 * b->pixel_bytes + b->packed_cap; }
+static constexpr size_t MI_POOL_MAX_ITEMS = 8, MI_POOL_MAX_BYTES = (size_t)32 << 30;     // what the one-call entry points may keep between calls (mi_release_cached() frees it)
 
 static mi_batch *pool_acquire(const mi_ravif_encoder *e, int cap, uint32_t w, uint32_t h, int channels) {
   const PoolKey key = pool_key(e, cap, w, h, channels);
@@ -772,34 +826,28 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
   std::vector<int> st(n, MI_OK);
   for (size_t i = 0; i < n; i++) { out[i].avif_file = nullptr; out[i].avif_len = out[i].color_byte_size = out[i].alpha_byte_size = 0; }
   std::atomic<size_t> cursor{ 0 };
-  const size_t max_run = 32;
-  const bool timing = getenv("MI_AVIF_TIMING") != nullptr;
+  // A run holds at most 32 images, and no more than an even share of the job when it is small (64 files on 8 GPUs: 8 each, not 32 + 32 + nothing).
+  const size_t max_run = std::min<size_t>(32, std::max<size_t>(1, (n + devs.size() - 1) / devs.size()));
+  const bool timing = mi_timing_enabled();
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3; };
-  // Per device: up to three resident batch objects (from the pool) per image shape, kept for the whole call.  While one batch encodes, the host
-  // fills the next one's pinned staging and enqueues its H2D + encode, so uploads, tile search, entropy coding and the host-side
-  // assembly of consecutive runs overlap (the same rotation bench.py drives).  A batch object costs tens of milliseconds to create
-  // (hipMalloc of the arena, pinned staging), so the one a run will need is created in the background as soon as the first image
-  // of that shape has been fetched, and the following slot's while the current run is being filled.
-  const size_t cap = std::min(max_run, std::max<size_t>(n, 1));
+  // Per device: up to three resident batch objects (from the pool) per image shape.  While one batch encodes, the host fills the next one's
+  // pinned staging and enqueues its H2D + encode, so uploads, tile search, entropy coding and the host-side assembly of consecutive runs overlap
+  // (the same rotation bench.py drives).  Memory is bounded: a batch object holds as many images of its shape as fit MI_SLOT_BYTES (one 12 MP RGBA
+  // image needs ~1.5 GB: such a shape gets runs of a few images, not 32), and before a new object is made the worker gives back the objects of the
+  // shapes it has not used for the longest time until the total stays under its budget (a share of the device's free memory at the start).
+  constexpr size_t MI_SLOT_BYTES = (size_t)8 << 30;
+  auto est_bytes = [](uint32_t w, uint32_t h, int ch, size_t images) { return images * (size_t)w * h * (ch == 4 ? 110 : 82) + ((size_t)32 << 20); };   // arena + records + staging per pixel (measured on the planner)
   auto worker = [&](int dev) {
     mi_ravif_encoder enc = *e; enc.device = dev;
     std::future<int> warm = std::async(std::launch::async, [dev]() { return hipSetDevice(dev) == hipSuccess ? ensure_tables(dev) : (int)MI_ENCODING_ERROR; });
+    size_t budget = (size_t)48 << 30;
+    { size_t fr = 0, tot = 0; if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = fr / 10 * 6; }
     constexpr int NSLOT = 3;
-    struct Slot { mi_batch *b = nullptr; std::future<mi_batch *> making; std::vector<size_t> idx; bool busy = false; };
-    struct Shape { uint32_t w, h; int ch; Slot slot[NSLOT]; int next = 0; };
+    struct Slot { mi_batch *b = nullptr; std::future<mi_batch *> making; std::vector<size_t> idx; bool busy = false; size_t bytes = 0; };
+    struct Shape { uint32_t w, h; int ch; size_t cap; Slot slot[NSLOT]; int next = 0; size_t runs = 0, last_use = 0; };
     std::vector<std::unique_ptr<Shape>> shapes;
-    auto ensure_slot = [&](Shape *sh, int j) {
-      Slot &sl = sh->slot[j];
-      if (sl.b || sl.making.valid()) return;
-      const mi_ravif_encoder ec = enc; const uint32_t w = sh->w, h = sh->h; const int ch = sh->ch; const int c = (int)cap;
-      sl.making = std::async(std::launch::async, [ec, c, w, h, ch]() { return pool_acquire(&ec, c, w, h, ch); });
-    };
-    auto shape_for = [&](const mi_image_desc &x) {
-      for (auto &c : shapes) if (c->w == x.width && c->h == x.height && c->ch == x.channels) return c.get();
-      shapes.emplace_back(new Shape{ x.width, x.height, x.channels, {}, 0 });
-      return shapes.back().get();
-    };
+    size_t live_bytes = 0, tick = 0;
     auto collect = [&](Slot &sl) {
       if (!sl.busy) return;
       const int rc = mi_batch_wait(sl.b);
@@ -807,60 +855,97 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
       for (size_t k = 0; k < sl.idx.size(); k++) st[sl.idx[k]] = rc == MI_OK ? mi_batch_get(sl.b, (int)k, &out[sl.idx[k]]) : rc;
       sl.busy = false;
     };
+    auto drop = [&](Slot &sl) {                                 // finish the slot's run and give its object back to the device
+      collect(sl);
+      if (sl.making.valid()) sl.b = sl.making.get();
+      if (sl.b) mi_batch_destroy(sl.b);
+      sl.b = nullptr; live_bytes -= std::min(live_bytes, sl.bytes); sl.bytes = 0;
+    };
+    auto make_room = [&](Shape *keep, size_t need) {
+      while (live_bytes + need > budget) {
+        Shape *victim = nullptr;
+        for (auto &c : shapes) if (c.get() != keep && (!victim || c->last_use < victim->last_use)) { bool any = false; for (Slot &sl : c->slot) any |= sl.b || sl.making.valid(); if (any) victim = c.get(); }
+        if (!victim) break;
+        for (Slot &sl : victim->slot) drop(sl);
+      }
+    };
+    auto ensure_slot = [&](Shape *sh, int j) {
+      Slot &sl = sh->slot[j];
+      if (sl.b || sl.making.valid()) return;
+      const size_t need = est_bytes(sh->w, sh->h, sh->ch, sh->cap);
+      make_room(sh, need);
+      sl.bytes = need; live_bytes += need;
+      const mi_ravif_encoder ec = enc; const uint32_t w = sh->w, h = sh->h; const int ch = sh->ch; const int c = (int)sh->cap;
+      sl.making = std::async(std::launch::async, [ec, c, w, h, ch]() { return pool_acquire(&ec, c, w, h, ch); });
+    };
+    auto shape_for = [&](const mi_image_desc &x) {
+      for (auto &c : shapes) if (c->w == x.width && c->h == x.height && c->ch == x.channels) return c.get();
+      const size_t per = est_bytes(x.width, x.height, x.channels, 1);
+      const size_t cap = std::max<size_t>(1, std::min(max_run, MI_SLOT_BYTES / per));
+      shapes.emplace_back(new Shape{ x.width, x.height, x.channels, cap, {}, 0, 0, 0 });
+      return shapes.back().get();
+    };
+    // one run (<= the shape's capacity) through the shape's next slot
+    auto submit = [&](Shape *sh, const std::vector<mi_image_desc> &d, const std::vector<size_t> &run, size_t i0, bool more) {
+      const mi_image_desc &d0 = d[run[0]];
+      sh->last_use = ++tick; sh->runs++;
+      const int j = sh->next; sh->next = (j + 1) % NSLOT;
+      Slot &sl = sh->slot[j];
+      collect(sl);                                           // the slot's previous run, if any
+      ensure_slot(sh, j);
+      if (sl.making.valid()) sl.b = sl.making.get();
+      int rc = sl.b ? mi_batch_set_count(sl.b, (int)run.size()) : MI_ENCODING_ERROR;
+      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d ready\n", since(), dev, j);
+      if (rc == MI_OK) {
+        const size_t row = (size_t)d0.width * d0.channels;
+        for (size_t k = 0; k < run.size(); k++) {
+          const mi_image_desc &x = d[run[k]];
+          uint8_t *dst = mi_batch_input(sl.b, (int)k);
+          const size_t sp = x.stride_px ? x.stride_px : x.width;
+          if (sp == x.width) memcpy(dst, x.pixels, row * d0.height);
+          else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, x.pixels + (size_t)y * sp * d0.channels, row);
+        }
+        rc = mi_batch_upload_async(sl.b, 0, (int)run.size());
+      }
+      if (release) for (size_t k : run) release(user, i0 + k);   // staged (or failed): the caller's pixels are no longer read
+      if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
+      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu enqueued on slot %d\n", since(), dev, run.size(), j);
+      if (rc != MI_OK) { for (size_t k : run) st[i0 + k] = rc; return; }
+      sl.idx.clear(); for (size_t k : run) sl.idx.push_back(i0 + k);
+      sl.busy = true;
+      // a shape that keeps coming gets its next slot made while the GPU works on this run (not earlier: hipMalloc / hipHostMalloc on another
+      // thread hold runtime locks that stall this thread's copies and launches; not for a shape seen once: a directory of differently sized files)
+      if (more && sh->runs >= 2) ensure_slot(sh, sh->next);
+    };
+    size_t claims = 0;
     for (;;) {
-      const size_t i0 = cursor.fetch_add(max_run);             // claim the index range [i0, i1)
+      // the first claim is half a run: it starts encoding while the caller's loaders are still producing the next (shorter runs leave the GPU part empty)
+      const size_t want = claims++ == 0 ? std::max<size_t>(1, (max_run + 1) / 2) : max_run;
+      const size_t i0 = cursor.fetch_add(want);                // claim the index range [i0, i1)
       if (i0 >= n) break;
-      const size_t i1 = std::min(n, i0 + max_run);
+      const size_t i1 = std::min(n, i0 + want);
       std::vector<mi_image_desc> d(i1 - i0);
-      std::vector<char> pending(i1 - i0, 0);
+      // images are staged in arrival order: a run is handed over as soon as the next image has another shape or the run is full
+      std::vector<size_t> run; Shape *run_shape = nullptr;
+      auto flush = [&](bool more) { if (!run.empty()) { submit(run_shape, d, run, i0, more); run.clear(); } };
       for (size_t i = i0; i < i1; i++) {
         const int rc = fetch(user, i, &d[i - i0]);
         const mi_image_desc &x = d[i - i0];
-        if (rc != MI_OK) st[i] = rc;
-        else if (!x.pixels || !x.width || !x.height || (x.channels != 3 && x.channels != 4)) { st[i] = MI_INVALID_ARGUMENT; if (release) release(user, i); }
-        else { pending[i - i0] = 1; Shape *sh = shape_for(x); ensure_slot(sh, sh->next); }
+        if (rc != MI_OK) { st[i] = rc; continue; }
+        if (!x.pixels || !x.width || !x.height || (x.channels != 3 && x.channels != 4)) { st[i] = MI_INVALID_ARGUMENT; if (release) release(user, i); continue; }
+        Shape *sh = shape_for(x);
+        if (sh != run_shape || run.size() >= sh->cap) flush(true);
+        run_shape = sh; run.push_back(i - i0);
+        if (run.size() == 1) ensure_slot(sh, sh->next);        // made in the background while the rest of the run arrives
       }
       if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: images %zu..%zu fetched\n", since(), dev, i0, i1);
-      // sub-runs of equal shape inside the range
-      for (size_t a = 0; a < d.size(); a++) {
-        if (!pending[a]) continue;
-        std::vector<size_t> run;
-        for (size_t k = a; k < d.size(); k++) if (pending[k] && d[k].width == d[a].width && d[k].height == d[a].height && d[k].channels == d[a].channels) { run.push_back(k); pending[k] = 0; }
-        const mi_image_desc &d0 = d[a];
-        Shape *sh = shape_for(d0);
-        const int j = sh->next; sh->next = (j + 1) % NSLOT;
-        Slot &sl = sh->slot[j];
-        collect(sl);                                           // the slot's previous run, if any
-        ensure_slot(sh, j);
-        if (sl.making.valid()) sl.b = sl.making.get();
-        int rc = sl.b ? mi_batch_set_count(sl.b, (int)run.size()) : MI_ENCODING_ERROR;
-        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d ready\n", since(), dev, j);
-        if (rc == MI_OK) {
-          const size_t row = (size_t)d0.width * d0.channels;
-          for (size_t k = 0; k < run.size(); k++) {
-            const mi_image_desc &x = d[run[k]];
-            uint8_t *dst = mi_batch_input(sl.b, (int)k);
-            const size_t sp = x.stride_px ? x.stride_px : x.width;
-            if (sp == x.width) memcpy(dst, x.pixels, row * d0.height);
-            else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, x.pixels + (size_t)y * sp * d0.channels, row);
-          }
-          rc = mi_batch_upload_async(sl.b, 0, (int)run.size());
-        }
-        if (release) for (size_t k : run) release(user, i0 + k);   // staged (or failed): the caller's pixels are no longer read
-        if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
-        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu enqueued on slot %d\n", since(), dev, run.size(), j);
-        if (rc != MI_OK) { for (size_t k : run) st[i0 + k] = rc; continue; }
-        sl.idx.clear(); for (size_t k : run) sl.idx.push_back(i0 + k);
-        sl.busy = true;
-        // more ranges to come: have the next slot made while the GPU works on this run (not earlier: hipMalloc / hipHostMalloc
-        // on another thread hold runtime locks that stall this thread's copies and launches)
-        if (cursor.load() < n) ensure_slot(sh, sh->next);
-      }
+      flush(cursor.load() < n);
     }
     for (auto &c : shapes) for (Slot &sl : c->slot) {
       collect(sl);
       if (sl.making.valid()) sl.b = sl.making.get();
       pool_release(sl.b);                                      // back to the pool: the next call (or nobody, at process exit) gets them
+      sl.b = nullptr;
     }
     warm.get();
     if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: worker done\n", since(), dev);
@@ -913,7 +998,6 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
     }
     HIP_OK(hipMemcpy(p.dev.src[i], host.data(), npx * 2, hipMemcpyHostToDevice));
   }
-  HIP_OK(hipMemsetAsync(p.dev.m_decoded, 0, zeroed_bytes(p), s));
   std::vector<TileJob> jobs;
   for (int tr = 0; tr < p.tiles.rows; tr++) for (int tc = 0; tc < p.tiles.cols; tc++) jobs.push_back(TileJob{ 0, tr, tc });
   HIP_OK(hipMalloc(&g.d_frame, sizeof(FrameDev))); HIP_OK(hipMalloc(&g.d_jobs, sizeof(TileJob) * jobs.size())); HIP_OK(hipMalloc(&g.d_pre, (size_t)jobs.size() * (size_t)cap * 2));
@@ -923,15 +1007,22 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipMemcpyAsync(d_frame, &p.dev, sizeof(FrameDev), hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(TileJob) * jobs.size(), hipMemcpyHostToDevice, s));
   const int njobs = (int)jobs.size();
-  hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
   {
     int class_begin[6] = { 0, 0, 0, 0, 0, 0 };
     for (int cls = std::max(p.maxbs, 2) + 1; cls <= 5; cls++) class_begin[cls] = njobs;
     std::vector<FramePlan> one(1, p);
-    if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
+    for (int pass = 0; pass < (p.cfg.rdo_passes >= 2 ? 2 : 1); pass++) {
+      if (pass == 1) {                                          // two-pass pricing: the tiles' final CDFs become their rate tables
+        hipLaunchKernelGGL(cdf_cost_kernel, dim3(njobs, 1), dim3(256), 0, s, d_frame);
+        hipLaunchKernelGGL(pass_flip_kernel, dim3(1), dim3(64), 0, s, d_frame, 1);
+      }
+      hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
+      if (pass == 0) { if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st; }
+      else if (int st = search_launch(g.queue, p.cfg.encode_bottomup != 0, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
+      HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
+      HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, g.d_rec, rec_cap, s));
+    }
   }
-  HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
-  HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, g.d_rec, rec_cap, s));
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);
   HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
@@ -966,7 +1057,7 @@ static int raw_planes(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const v
     if (depth == 8) pl[c][i] = ((const uint8_t *)yuv)[i * 3 + c]; else ((uint16_t *)pl[c].data())[i] = ((const uint16_t *)yuv)[i * 3 + c];
   }
   mi_av1_config c{}; c.width = w; c.height = h; c.bit_depth = (uint8_t)depth; c.quantizer = (uint8_t)quality_to_quantizer(e->quality);
-  c.chroma = 0; c.pixel_range = range; c.threads = e->threads; c.has_color_desc = 1; c.primaries = 1; c.transfer = 13; c.matrix = matrix; c.device = e->device; c.tiles_override = e->tiles_override;
+  c.chroma = 0; c.pixel_range = range; c.threads = e->threads; c.has_color_desc = 1; c.primaries = 1; c.transfer = 13; c.matrix = matrix; c.device = e->device; c.tiles_override = e->tiles_override; c.rdo_passes = (uint8_t)(e->rdo_passes >= 2 ? 2 : 1);
   if (int st = tweaks_from_preset(e->speed, c.quantizer, &c)) return st;
   const void *pp[3] = { pl[0].data(), pl[1].data(), pl[2].data() }; const size_t sb[3] = { w * bps, w * bps, w * bps };
   uint8_t *cobu = nullptr, *aobu = nullptr; size_t clen = 0, alen = 0;

@@ -266,25 +266,16 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
                                                   int tx_off, int tx_sym, int tx_ns) {
   const int eob = uni32(eob_in);
   const LDS int32_t *qc = w->qc; const LDS uint8_t *lev = w->lev;
-#if MI_RECT_PART
   const bool rect = txs > 4;                              // 5 = 4x8, 6 = 8x4 (dev_rect.h)
   const int bwl = rect ? (txs == 5 ? 2 : 3) : imin_(5, 2 + txs), bhl = rect ? (txs == 5 ? 3 : 2) : bwl, n = 1 << bwl, nh = 1 << bhl;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = rect ? 1 : txs;
-#else
-  const int n = imin_(32, 4 << txs), bwl = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, nh = n, bhl = bwl;
-  const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = txs;
-#endif
   k4_sym(w, eob == 0, CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
   K4CNT(9, 1); K4CNT(10, eob == 0);
   if (eob == 0) { K4PH(3); return; }
   // ---- (P) contexts, lane-parallel
   const int st = n + 4, area = n * nh;
   for (int c = LANE; c < eob; c += 64) {
-#if MI_RECT_PART
     const int p = rect ? rect_scan_pos(bwl, bhl, cls, c) : scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
-#else
-    const int p = scan_pos(w->ls, n, cls, c), row = p >> bwl, col = p & (n - 1);
-#endif
     const int v = qc[p], level = iabs_(v);
     const LDS uint8_t *L = lev + row * st + col;
     int off;                                                 // last position: its base_eob CDF row; the others: the base context (0..41)
@@ -293,12 +284,10 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
       off = CDF_COEFF_BASE_EOB + ((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE;
     } else {
       int bctx = base_ctx(L, st, cls, row, col);
-#if MI_RECT_PART
       if (rect && cls == TXC_2D && !(row == 0 && col == 0)) {          // spec Coeff_Base_Ctx_Offset of the 2:1 sizes
         const int mg = imin_(L[1], 3) + imin_(L[st], 3) + imin_(L[st + 1], 3) + imin_(L[2], 3) + imin_(L[2 * st], 3), m = imin_((mg + 1) >> 1, 4);
         bctx = bhl > bwl ? m + (row < 2 ? 11 : (row + col < 4 ? 6 : 21)) : m + (col < 2 ? 16 : (row + col < 4 ? 6 : 21));
       }
-#endif
       off = CDF_COEFF_BASE + ((txs_ctx * 2 + pt) * 42 + bctx) * CDF_COEFF_BASE_STRIDE;
     }
     int boff = 0;
@@ -390,11 +379,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   // read_block_tx_size(): tx_depth of every intra block above 4x4 under TX_MODE_SELECT, coded even when skip
   if (BS > 0 && w->tx_mode_select) {
     const int maxw = 4 << BS;
-#if MI_RECT_PART
     const int actx = availU && (1 << dim_wl(v_txU)) >= maxw, lctx = availL && (1 << dim_hl(v_txL)) >= maxw;
-#else
-    const int actx = availU && (4 << v_txU) >= maxw, lctx = availL && (4 << v_txL) >= maxw;
-#endif
     k4_sym(w, BS - txs_y, CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE, BS == 1 ? 2 : 3);
   }
   K4PH(1); K4CNT(8, 1);
@@ -431,7 +416,6 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   WAVE_SYNC();
 }
 
-#if MI_RECT_PART
 // An 8x4 / 4x8 block (oracle write_block with a 2:1 size): no angle deltas, CfL allowed, tx_depth in the 8x8 category, one 2:1 transform or its two
 // 4x4 halves per luma block, one 2:1 transform per chroma plane.
 template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *w, int r, int c) {
@@ -501,7 +485,6 @@ template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *
   }
   WAVE_SYNC();
 }
-#endif
 
 // Partition symbol of the node (r, c, bs >= 1); returns 0 (NONE) or 3 (SPLIT).  spec 5.11.4
 __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int c, int bs) {
@@ -509,15 +492,9 @@ __device__ __forceinline__ int write_partition_symbol(TileWriter *w, int r, int 
   const int half = (1 << bs) >> 1;
   const int has_rows = (r + half) < w->mi_rows, has_cols = (c + half) < w->mi_cols;
   const int actual = U_(f->m_bsize[r * ms + c]);
-#if MI_RECT_PART
   int part = actual == bs ? 0 : ((bs == BS_8 && actual == BS_8X4) ? 1 : ((bs == BS_8 && actual == BS_4X8) ? 2 : 3));
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int above = availU && dim_wl(U_(f->m_bsize[(r - 1) * ms + c])) < 2 + bs, left = availL && dim_hl(U_(f->m_bsize[r * ms + c - 1])) < 2 + bs;
-#else
-  int part = actual == bs ? 0 : 3;
-  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
-#endif
   const int cdf = CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE;
   const int ns = bs == BS_8 ? 4 : 10;
   if (has_rows && has_cols) k4_sym(w, part, cdf, ns);
@@ -583,10 +560,8 @@ template <int MAXBS> __device__ __forceinline__ void write_superblock(TileWriter
         }
         sp--; continue;
       }
-#if MI_RECT_PART
       if (part == 1) { write_block_rect<BS_8X4>(w, r, c); write_block_rect<BS_8X4>(w, r + 1, c); sp--; continue; }
       if (part == 2) { write_block_rect<BS_4X8>(w, r, c); write_block_rect<BS_4X8>(w, r, c + 1); sp--; continue; }
-#endif
     }
     if (kk == 4) { sp--; continue; }
     const int half = (1 << bs) >> 1;
@@ -682,6 +657,8 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
 #endif
     __syncthreads();                                            // the stages hand their superblocks on (workgroup scope: one CU, one L1)
   }
+  if (wave == 0 && f->cdf_out != nullptr)                       // two-pass pricing: what this tile's CDFs have adapted to (every adapter is past the last barrier)
+    for (int i = LANE; i < CDF_TOTAL; i += 64) f->cdf_out[(size_t)tile * CDF_TOTAL + i] = L.cdf[i];
   if (wave == NA + 1) {
     uint8_t *out = f->tile_out + (size_t)tile * f->tile_out_cap;
     uint32_t out_len = re_finish_dev(&ec, out, f->tile_out_cap);       // whole wave

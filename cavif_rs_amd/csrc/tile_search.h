@@ -52,7 +52,7 @@
 // area snapshots of the partition search, one area per resident workgroup in HBM
 #define MI_SNAP_BYTES(n) (3 * (n) * (n) * 6 + 18 * ((n) / 4) * ((n) / 4) + 3 * ((n) / 4) * ((n) / 4) * 2 + 64)
 #define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
-#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + (MI_RECT_PART ? 2 * MI_SNAP_BYTES(8) : 0))   /* + the 8x8 node's best rectangular / split candidates */
+#define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + 2 * MI_SNAP_BYTES(8))   /* + the 8x8 node's best rectangular / split candidates */
 
 template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N;
@@ -75,7 +75,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   long long satd[13], dsd[7][6];
   long long wbest_j[4], cj[16][2], pbest_j[2];
   int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16], ldelta[7];
-  uint16_t lpred[N <= 16 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
+  uint16_t lpred[N <= 32 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
   // luma transform-size trial, LDS-resident: the undivided winner is already committed to the frame; the four sub-blocks are
@@ -333,7 +333,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
   // ---- luma: SATD pre-filter over the 13 modes (mode m by wave m % NW) ----
-  constexpr bool SMALL_GROUPED = BS <= BS_8 && NW == 4 && MAXN <= 16;
+  constexpr bool SMALL_GROUPED = BS <= BS_8 && NW == 4 && MAXN <= 32;      // (the 64x64 class runs one wavefront per workgroup)
   if constexpr (SMALL_GROUPED) {
     // 4x4 / 8x8: the eight directional modes run four per wave (one prediction angle per 16-lane row, dev_group.h) on
     // waves 0 and 1 -- rows sorted so that a wave's rows mostly share the interpolation branch --, the five others
@@ -442,7 +442,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   LDS uint16_t *split_rec = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->split_rec;
   LDS uint16_t *spred = SH->spred;
   // the surviving (mode, delta) predictions are built once (candidate ci by wave ci) and shared by its tx-type trials
-  const bool pred_cached = MAXN <= 16 && NW > 1 && ncand * nn <= 768;
+  const bool pred_cached = MAXN <= 32 && NW > 1 && ncand * nn <= 768;
   if (pred_cached) {
     for (int ci = NW - 1 - W; ci < ncand; ci += NW) {          // waves 3, 2, 1
       const int m = SH->order[ci];
@@ -464,7 +464,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   // ONE round for the 3 x 5 trials of speed 4, two for 3 x 7, four for 7 x 7.  Between rounds a wave parks its best
   // candidate's reconstruction and levels in S->dcp (idle during the luma trials).
   bool grouped = false, parked = false; int my_g = 0;
-  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) {
+  if constexpr (SMALL_GROUPED) {
     grouped = pred_cached;
     if (grouped) {
       const int g = GROUP_ID, total = ncand * ntx, rounds = (total + 15) >> 4;
@@ -545,7 +545,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   if (W == win) {
     const int b = cur ^ 1;                                  // buffer holding this wave's best
     const LDS uint16_t *best_rec = S->rec[b]; const LDS int32_t *best_qc = S->qc[b];
-    if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (grouped) {
+    if constexpr (SMALL_GROUPED) if (grouped) {
       if (parked) { best_rec = (const LDS uint16_t *)S->dcp; best_qc = (const LDS int32_t *)(S->dcp + 64); }
       else { best_rec = S->grp[my_g].rec; best_qc = S->grp[my_g].qc; }
     }
@@ -573,11 +573,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   // of the sub-block are dealt to the waves (16-lane rows for 4x4 / 8x8 transforms) like the candidates of a block.
   if constexpr (BS > 0) if (f->tx_mode_select) {
     const int maxw = 4 << BS;
-#if MI_RECT_PART
     const int actx = nb_txU >= 0 && (1 << dim_wl(nb_txU)) >= maxw, lctx = nb_txL >= 0 && (1 << dim_hl(nb_txL)) >= maxw;   // neighbours may carry 2:1 transform codes
-#else
-    const int actx = nb_txU >= 0 && (4 << nb_txU) >= maxw, lctx = nb_txL >= 0 && (4 << nb_txL) >= maxw;
-#endif
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
     if (tx_trial) {
@@ -694,7 +690,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
             }
           }
           long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
-          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) {
+          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) {
             // five tx types (the reduced set): the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1 -- a wave whose rows mix
             // identity, DCT and ADST walks all three 1-D networks one after the other under exec masks
             const int g = GROUP_ID, e = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 64)) : W * 4 + g;
@@ -741,7 +737,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           const long long sub_j = SH->wbest_j[sw];
           if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
             const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-            if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 16) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
+            if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
             const int ro = bi * hn * n + bj * hn;
             for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
             for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
@@ -788,8 +784,8 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   // ---- chroma, 4x4 / 8x8 blocks with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four
   // waves (plane x half of the range), then every candidate of a plane in one grouped evaluation (dev_group.h) ----
   bool cgrouped = false;
-  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) cgrouped = f->np > 1 && !f->complex_modes;
-  if constexpr (BS <= BS_8 && NW == 4 && MAXN <= 16) if (cgrouped) {
+  if constexpr (SMALL_GROUPED) cgrouped = f->np > 1 && !f->complex_modes;
+  if constexpr (SMALL_GROUPED) if (cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, f->reduced_tx_set);
     const int bdelta = (best_mode >= V_PRED && best_mode <= D67_PRED && BS >= BS_8) ? best_delta : 0;
@@ -1137,11 +1133,7 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
 __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
   const int ms = f->mi_stride;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-#if MI_RECT_PART
   const int above = availU && dim_wl(f->m_bsize[(r - 1) * ms + c]) < 2 + bs, left = availL && dim_hl(f->m_bsize[r * ms + c - 1]) < 2 + bs;
-#else
-  const int above = availU && f->m_bsize[(r - 1) * ms + c] < bs, left = availL && f->m_bsize[r * ms + c - 1] < bs;
-#endif
   return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
 }
 
@@ -1179,7 +1171,6 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           j_split += sub_j[q];
           if (BS - 1 >= BS_8) j_split += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9);
         }
-#if MI_RECT_PART
         if constexpr (BS == 1) {
           // PARTITION_HORZ / PARTITION_VERT (two 8x4 / 4x8 blocks) against the best of NONE / SPLIT so far (oracle rd_partition)
           uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
@@ -1200,7 +1191,6 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return 1; }   // 1: the later siblings' trial results are stale
           if (have_split) area_copy_dev<BS, NW>(f, split_snap, r, c, 0);
         }
-#endif
         if (j_split < j_none && !DBG_IS(f, 7) && !DBG_IS(f, 8) && !(DBG_IS(f, 10) && BS == 1)) do_split = 1;
         else { area_copy_dev<BS, NW>(f, k.snap(), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
       }
@@ -1260,7 +1250,6 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       if (!must_split && j_split >= j_none) break;
       j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half);
     }
-#if MI_RECT_PART
     if constexpr (BS == 1) if (!must_split) {
       uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
       long long j_best = j_none; int have_split = 0, rect_won = 0;
@@ -1280,7 +1269,6 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_best; }
       if (have_split) { area_copy_dev<BS, NW>(f, split_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_split; }
     }
-#endif
     if (must_split || j_split < j_none) return j_split;
     if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
     return j_none;
@@ -1362,9 +1350,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
         t->mi_row_start = gf->tile_row_start[tj.tile_row] * 16; t->mi_row_end = imin_(gf->tile_row_start[tj.tile_row + 1] * 16, gf->mi_rows);
         t->mi_col_start = gf->tile_col_start[tj.tile_col] * 16; t->mi_col_end = imin_(gf->tile_col_start[tj.tile_col + 1] * 16, gf->mi_cols);
       }
-      cur_job = job;
     }
+    const bool new_tile = job != cur_job;
+    cur_job = job;
     WG_SYNC();
+    if (new_tile && gf->tile_cost != nullptr) {                            // second pass of a two-pass encode: the tile's own rate table
+      const uint16_t *tc = gf->tile_cost + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * CDF_TOTAL;
+      if (threadIdx.x == 0) lf->cost = tc;
+      load_coef_cost(k.cc_base(), tc, MAXBS, threadIdx.x, 64 * NW);
+      WG_SYNC();
+    }
     const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
     const int ncols = (col1 - col0 + 15) >> 4, nrows = (row1 - row0 + 15) >> 4, r = row0 + 16 * sbr, c = col0 + 16 * sbc;
     int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;        // this row's counter; the row above: prog - tile_cols

@@ -31,13 +31,13 @@ class _Av1Config(C.Structure):
                 ('encode_bottomup', C.c_uint8), ('rdo_tx_decision', C.c_uint8), ('reduced_tx_set', C.c_uint8),
                 ('fine_directional_intra', C.c_uint8), ('fast_deblock', C.c_uint8), ('lrf', C.c_uint8), ('cdef', C.c_uint8),
                 ('inter_tx_split', C.c_uint8), ('tx_domain_rate', C.c_uint8), ('tx_domain_distortion', C.c_int8),
-                ('min_tile_size', C.c_uint16), ('tiles_override', C.c_int32), ('device', C.c_int32), ('tune_psnr', C.c_uint8)]
+                ('min_tile_size', C.c_uint16), ('tiles_override', C.c_int32), ('device', C.c_int32), ('tune_psnr', C.c_uint8), ('rdo_passes', C.c_uint8)]
 
 
 class _RavifEncoder(C.Structure):
     _fields_ = [('quality', C.c_float), ('alpha_quality', C.c_float), ('speed', C.c_uint8), ('color_model', C.c_uint8),
                 ('depth', C.c_uint8), ('alpha_mode', C.c_uint8), ('threads', C.c_int32),
-                ('exif', C.c_void_p), ('exif_len', C.c_size_t), ('device', C.c_int32), ('tiles_override', C.c_int32)]
+                ('exif', C.c_void_p), ('exif_len', C.c_size_t), ('device', C.c_int32), ('tiles_override', C.c_int32), ('rdo_passes', C.c_int32)]
 
 
 class _EncodedImage(C.Structure):
@@ -177,6 +177,7 @@ class Encoder:
         self.quality, self.alpha_quality, self.speed = 80.0, 80.0, 5
         self.color_model, self.depth, self.alpha_mode, self.threads = 0, 0, 1, None
         self.device, self.tiles_override = 0, 0
+        self.rdo_passes = 1
         self.exif = None
 
     def _copy(self, **kw):
@@ -219,11 +220,15 @@ class Encoder:
     def with_device(self, device):
         return self._copy(device=int(device))
 
+    def with_rdo_passes(self, n):                       # extension (not in ravif): 2 = second search priced against every tile's final CDFs of a first pass
+        assert n in (1, 2)
+        return self._copy(rdo_passes=int(n))
+
     def _c(self):
         e = _RavifEncoder()
         e.quality, e.alpha_quality, e.speed, e.color_model, e.depth, e.alpha_mode = self.quality, self.alpha_quality, self.speed, self.color_model, self.depth, self.alpha_mode
         e.threads = self.threads or 0
-        e.device, e.tiles_override = self.device, self.tiles_override
+        e.device, e.tiles_override, e.rdo_passes = self.device, self.tiles_override, self.rdo_passes
         if self.exif:
             self._exif_buf = C.create_string_buffer(self.exif, len(self.exif))   # must outlive every call made with `e`
             e.exif, e.exif_len = C.cast(self._exif_buf, C.c_void_p), len(self.exif)

@@ -43,6 +43,9 @@ typedef struct mi_av1_config {
   int32_t tiles_override;   /* >0 forces the tile target (tests) */
   int32_t device;           /* HIP ordinal */
   uint8_t tune_psnr;        /* 0 = Tune::Psychovisual, what ravif always sets (:694); 1 = Tune::Psnr (plain SSE; ablation only) */
+  uint8_t rdo_passes;       /* <= 1: the tile search prices against the table of the frame's initial CDFs.  2 (an extension, not in ravif): the
+                               whole encode runs twice and the second search prices every tile against the CDFs that tile ended the first
+                               pass with -- a step towards rav1e's adaptive pricing that keeps tiles and superblock rows independent */
 } mi_av1_config;
 
 /* SpeedTweaks::from_my_preset (ravif/src/av1encoder.rs:554-606) */
@@ -69,6 +72,7 @@ typedef struct mi_ravif_encoder {
   const uint8_t *exif; size_t exif_len;   /* with_exif :208; copied by mi_batch_create / every encode call, need not outlive it */
   int32_t device;
   int32_t tiles_override;
+  int32_t rdo_passes;             /* extension: see mi_av1_config.rdo_passes (0 / 1 = one pass, ravif's behaviour) */
 } mi_ravif_encoder;
 
 typedef struct mi_encoded_image { uint8_t *avif_file; size_t avif_len, color_byte_size, alpha_byte_size; } mi_encoded_image;

@@ -50,6 +50,8 @@ typedef struct Av1oConfig {
   int min_tile_size;
   int tiles_override;     /* >0: force this tile target (tests) */
   int tune_psnr;          /* 0 = Tune::Psychovisual (what ravif always sets, av1encoder.rs:694), 1 = Tune::Psnr (plain SSE; ablation) */
+  int rdo_passes;         /* <= 1: the search prices against the table of the frame's initial CDFs; 2: the whole encode runs twice and the second search
+                             prices every tile against the CDFs that tile ended its first pass with (an extension towards rav1e's adaptive pricing; not in ravif) */
 } Av1oConfig;
 
 typedef struct Av1oResult {
@@ -75,7 +77,7 @@ uint16_t av1o_to_ten(uint8_t x);                                             /* 
 
 typedef struct RavifOracleEncoder {       /* ravif::Encoder (:67-86) */
   float quality, alpha_quality; int speed; int color_model /*0 YCbCr,1 RGB*/; int depth /*8,10,0=auto*/;
-  int alpha_mode /*0 dirty,1 clean,2 premultiplied*/; int threads; int tiles_override;
+  int alpha_mode /*0 dirty,1 clean,2 premultiplied*/; int threads; int tiles_override; int rdo_passes;
 } RavifOracleEncoder;
 typedef struct RavifOracleImage { uint8_t *avif; size_t avif_len, color_byte_size, alpha_byte_size; } RavifOracleImage;
 int  ravif_oracle_encode_rgba(const RavifOracleEncoder *e, const uint8_t *rgba, int w, int h, int stride_px, RavifOracleImage *out);

@@ -174,41 +174,45 @@ uint32_t av1o_cost_from_icdf(const uint16_t *icdf, int s, int nsyms) {
   uint32_t hi = s > 0 ? icdf[s - 1] : 32768, lo = icdf[s];
   return neglog2_q9(hi - lo);
 }
-static void cost_rows(Av1oFrame *f, int off, int stride, int nrows, int nsyms) {
+static void cost_rows(const uint16_t *cdf, uint32_t *cost, int off, int stride, int nrows, int nsyms) {
   for (int r = 0; r < nrows; r++)
     for (int s = 0; s < nsyms; s++)
-      f->cost[off + r * stride + s] = av1o_cost_from_icdf(f->cdf0 + off + r * stride, s, nsyms);
+      cost[off + r * stride + s] = av1o_cost_from_icdf(cdf + off + r * stride, s, nsyms);
+}
+void av1o_costs_from_cdfs(const uint16_t *cdf, uint32_t *cost) {
+  memset(cost, 0, sizeof(uint32_t) * CDF_TOTAL);
+  cost_rows(cdf, cost, CDF_KF_Y, CDF_KF_Y_STRIDE, 25, 13);
+  cost_rows(cdf, cost, CDF_ANGLE, CDF_ANGLE_STRIDE, 8, 7);
+  cost_rows(cdf, cost, CDF_UV_NOCFL, CDF_UV_NOCFL_STRIDE, 13, 13);
+  cost_rows(cdf, cost, CDF_UV_CFL, CDF_UV_CFL_STRIDE, 13, 14);
+  cost_rows(cdf, cost, CDF_PARTITION, CDF_PARTITION_STRIDE, 4, 4);
+  cost_rows(cdf, cost, CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10);
+  cost_rows(cdf, cost, CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8);
+  cost_rows(cdf, cost, CDF_SKIP, CDF_SKIP_STRIDE, 3, 2);
+  cost_rows(cdf, cost, CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7);
+  cost_rows(cdf, cost, CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5);
+  cost_rows(cdf, cost, CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8);
+  cost_rows(cdf, cost, CDF_CFL_ALPHA, CDF_CFL_ALPHA_STRIDE, 6, 16);
+  cost_rows(cdf, cost, CDF_TX_SIZE, CDF_TX_SIZE_STRIDE, 3, 2);
+  cost_rows(cdf, cost, CDF_TX_SIZE + 3 * CDF_TX_SIZE_STRIDE, CDF_TX_SIZE_STRIDE, 9, 3);
+  cost_rows(cdf, cost, CDF_TXB_SKIP, CDF_TXB_SKIP_STRIDE, 5 * 13, 2);
+  cost_rows(cdf, cost, CDF_EOB_EXTRA, CDF_EOB_EXTRA_STRIDE, 5 * 2 * 9, 2);
+  cost_rows(cdf, cost, CDF_DC_SIGN, CDF_DC_SIGN_STRIDE, 6, 2);
+  cost_rows(cdf, cost, CDF_COEFF_BR, CDF_COEFF_BR_STRIDE, 5 * 2 * 21, 4);
+  cost_rows(cdf, cost, CDF_COEFF_BASE, CDF_COEFF_BASE_STRIDE, 5 * 2 * 42, 4);
+  cost_rows(cdf, cost, CDF_COEFF_BASE_EOB, CDF_COEFF_BASE_EOB_STRIDE, 5 * 2 * 4, 3);
+  cost_rows(cdf, cost, CDF_EOB_PT_16, CDF_EOB_PT_16_STRIDE, 4, 5);
+  cost_rows(cdf, cost, CDF_EOB_PT_32, CDF_EOB_PT_32_STRIDE, 4, 6);
+  cost_rows(cdf, cost, CDF_EOB_PT_64, CDF_EOB_PT_64_STRIDE, 4, 7);
+  cost_rows(cdf, cost, CDF_EOB_PT_128, CDF_EOB_PT_128_STRIDE, 4, 8);
+  cost_rows(cdf, cost, CDF_EOB_PT_256, CDF_EOB_PT_256_STRIDE, 4, 9);
+  cost_rows(cdf, cost, CDF_EOB_PT_512, CDF_EOB_PT_512_STRIDE, 4, 10);
+  cost_rows(cdf, cost, CDF_EOB_PT_1024, CDF_EOB_PT_1024_STRIDE, 4, 11);
 }
 void av1o_build_costs(Av1oFrame *f) {
   memcpy(f->cdf0, av1_default_cdfs + f->qctx * CDF_TOTAL, sizeof(f->cdf0));
-  memset(f->cost, 0, sizeof(f->cost));
-  cost_rows(f, CDF_KF_Y, CDF_KF_Y_STRIDE, 25, 13);
-  cost_rows(f, CDF_ANGLE, CDF_ANGLE_STRIDE, 8, 7);
-  cost_rows(f, CDF_UV_NOCFL, CDF_UV_NOCFL_STRIDE, 13, 13);
-  cost_rows(f, CDF_UV_CFL, CDF_UV_CFL_STRIDE, 13, 14);
-  cost_rows(f, CDF_PARTITION, CDF_PARTITION_STRIDE, 4, 4);
-  cost_rows(f, CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10);
-  cost_rows(f, CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8);
-  cost_rows(f, CDF_SKIP, CDF_SKIP_STRIDE, 3, 2);
-  cost_rows(f, CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7);
-  cost_rows(f, CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5);
-  cost_rows(f, CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8);
-  cost_rows(f, CDF_CFL_ALPHA, CDF_CFL_ALPHA_STRIDE, 6, 16);
-  cost_rows(f, CDF_TX_SIZE, CDF_TX_SIZE_STRIDE, 3, 2);
-  cost_rows(f, CDF_TX_SIZE + 3 * CDF_TX_SIZE_STRIDE, CDF_TX_SIZE_STRIDE, 9, 3);
-  cost_rows(f, CDF_TXB_SKIP, CDF_TXB_SKIP_STRIDE, 5 * 13, 2);
-  cost_rows(f, CDF_EOB_EXTRA, CDF_EOB_EXTRA_STRIDE, 5 * 2 * 9, 2);
-  cost_rows(f, CDF_DC_SIGN, CDF_DC_SIGN_STRIDE, 6, 2);
-  cost_rows(f, CDF_COEFF_BR, CDF_COEFF_BR_STRIDE, 5 * 2 * 21, 4);
-  cost_rows(f, CDF_COEFF_BASE, CDF_COEFF_BASE_STRIDE, 5 * 2 * 42, 4);
-  cost_rows(f, CDF_COEFF_BASE_EOB, CDF_COEFF_BASE_EOB_STRIDE, 5 * 2 * 4, 3);
-  cost_rows(f, CDF_EOB_PT_16, CDF_EOB_PT_16_STRIDE, 4, 5);
-  cost_rows(f, CDF_EOB_PT_32, CDF_EOB_PT_32_STRIDE, 4, 6);
-  cost_rows(f, CDF_EOB_PT_64, CDF_EOB_PT_64_STRIDE, 4, 7);
-  cost_rows(f, CDF_EOB_PT_128, CDF_EOB_PT_128_STRIDE, 4, 8);
-  cost_rows(f, CDF_EOB_PT_256, CDF_EOB_PT_256_STRIDE, 4, 9);
-  cost_rows(f, CDF_EOB_PT_512, CDF_EOB_PT_512_STRIDE, 4, 10);
-  cost_rows(f, CDF_EOB_PT_1024, CDF_EOB_PT_1024_STRIDE, 4, 11);
+  av1o_costs_from_cdfs(f->cdf0, f->cost0);
+  f->cost = f->cost0;
 }
 
 /* ---------------- quantizer selection ----------------

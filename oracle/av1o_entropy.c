@@ -296,6 +296,7 @@ size_t av1o_code_tile(Av1oFrame *f, int tile_row, int tile_col, uint8_t **out) {
       av1o_write_lr_sb(f, r, c, w->lr_ref, lr_sym, ec_lit, w);      /* read_lr() precedes decode_partition() (spec 5.11.2) */
       write_partition(w, r, c, BS_64);
     }
+  if (f->tile_cdf) memcpy(f->tile_cdf + (size_t)(tile_row * f->tile_cols + tile_col) * CDF_TOTAL, w->cdf, sizeof(w->cdf));   /* what a second pass prices this tile against */
   size_t n = re_finish(&w->ec, out);
   re_free(&w->ec);
   free(w->cdef_done);

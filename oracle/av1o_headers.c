@@ -159,17 +159,32 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   av1o_setup_tiles(f);
   av1o_activity(f);
   f->enable_cdef = cfg->cdef; f->enable_restoration = cfg->lrf;
-  /* phase 1 */
-  for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++) av1o_search_tile(f, tr, tc);
-  /* loop filter decisions + final reconstruction */
-  av1o_deblock_frame(f);
-  av1o_cdef_search_and_apply(f);
-  av1o_lr_search_and_apply(f);
-  /* phase 2 */
   const int ntiles = f->tile_cols * f->tile_rows;
   uint8_t **td = (uint8_t **)zalloc(sizeof(uint8_t *) * (size_t)ntiles); size_t *tl = (size_t *)zalloc(sizeof(size_t) * (size_t)ntiles);
-  for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++)
-    tl[tr * f->tile_cols + tc] = av1o_code_tile(f, tr, tc, &td[tr * f->tile_cols + tc]);
+  /* rdo_passes = 2: the first pass is a complete encode whose only product is the CDFs every tile ends with; the second pass prices each tile's
+     search against the table of those (everything else -- decisions made in coding order, filters, syntax -- as in a single pass) */
+  const int passes = cfg->rdo_passes >= 2 ? 2 : 1;
+  if (passes == 2) f->tile_cdf = (uint16_t *)zalloc((size_t)ntiles * CDF_TOTAL * sizeof(uint16_t));
+  for (int pass = 0; pass < passes; pass++) {
+    if (pass == 1) {
+      f->tile_cost = (uint32_t *)zalloc((size_t)ntiles * CDF_TOTAL * sizeof(uint32_t));
+      for (int i = 0; i < ntiles; i++) { av1o_costs_from_cdfs(f->tile_cdf + (size_t)i * CDF_TOTAL, f->tile_cost + (size_t)i * CDF_TOTAL); free(td[i]); td[i] = NULL; }
+      free(f->tile_cdf); f->tile_cdf = NULL;
+      memset(f->m_decoded, 0, nmi);
+      for (int p = 0; p < f->np; p++) { free(f->dbk[p]); free(f->lr_type[p]); free(f->lr_set[p]); free(f->lr_xqd[p]); f->dbk[p] = NULL; f->lr_type[p] = NULL; f->lr_set[p] = NULL; f->lr_xqd[p] = NULL; }
+    }
+    /* phase 1 */
+    for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++) av1o_search_tile(f, tr, tc);
+    f->cost = f->cost0;
+    /* loop filter decisions + final reconstruction */
+    av1o_deblock_frame(f);
+    av1o_cdef_search_and_apply(f);
+    av1o_lr_search_and_apply(f);
+    /* phase 2 */
+    for (int tr = 0; tr < f->tile_rows; tr++) for (int tc = 0; tc < f->tile_cols; tc++)
+      tl[tr * f->tile_cols + tc] = av1o_code_tile(f, tr, tc, &td[tr * f->tile_cols + tc]);
+  }
+  free(f->tile_cost); f->tile_cost = NULL;
   memset(out, 0, sizeof(*out));
   out->obu_len = av1o_write_obus(f, td, tl, &out->obu);
   for (int i = 0; i < ntiles; i++) free(td[i]);

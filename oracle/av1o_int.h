@@ -12,10 +12,7 @@
 #endif
 
 /* Rectangular partitions (PARTITION_HORZ / PARTITION_VERT) of 8x8 nodes: rav1e tries them up to its
- * non_square_partition_max_threshold (8x8 from speed 2 on) [UPSTREAM-RECALL].  0 = squares only (what the HIP path implements). */
-#ifndef AV1O_RECT_PART
-#define AV1O_RECT_PART 0
-#endif
+ * non_square_partition_max_threshold (8x8 from speed 2 on) [UPSTREAM-RECALL].  Always searched since round 3 (oracle and HIP path). */
 /* Block-size and transform-size codes: 0..4 = the squares 4 << code; 5 = 4 wide x 8 tall, 6 = 8 wide x 4 tall (same numbering for both). */
 enum { BS_4X8 = 5, BS_8X4 = 6, TX_4X8 = 5, TX_8X4 = 6 };
 static inline int dim_wl(int code) { return code <= 4 ? 2 + code : (code == 5 ? 2 : 3); }     /* log2 of the width in samples */
@@ -88,7 +85,10 @@ typedef struct Av1oFrame {
   int tile_col_start[MAX_TILE_COLS + 1], tile_row_start[MAX_TILE_ROWS + 1];
   /* static rate table: cost[CDF offset + symbol] in 1/512 bit */
   uint16_t cdf0[CDF_TOTAL];
-  uint32_t cost[CDF_TOTAL];
+  uint32_t cost0[CDF_TOTAL];   /* ... of the frame's initial CDFs */
+  const uint32_t *cost;        /* the table the search prices against: cost0, or the tile's own in a second pass (rdo_passes = 2) */
+  uint32_t *tile_cost;         /* [tiles][CDF_TOTAL], second pass only */
+  uint16_t *tile_cdf;          /* [tiles][CDF_TOTAL]: the CDFs every tile ended its first pass with (rdo_passes = 2) */
   /* loop filter / cdef frame params */
   int lf_level[4], lf_sharp;
   int cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
@@ -116,6 +116,7 @@ int  av1o_tx_class(int txtype);
 const uint16_t *av1o_scan(int txs, int txtype, uint16_t *tmp); /* positions within min(32,N) square */
 uint32_t av1o_cost_from_icdf(const uint16_t *icdf, int s, int nsyms);
 void av1o_build_costs(Av1oFrame *f);
+void av1o_costs_from_cdfs(const uint16_t *cdf, uint32_t *cost);   /* the static rate table of one set of CDFs */
 void av1o_select_quantizers(Av1oFrame *f);               /* rav1e rate.rs constant-Q key frame rule (recall) */
 void av1o_setup_tiles(Av1oFrame *f);
 uint32_t av1o_psy_boost_q14(uint32_t svar, uint32_t dvar);

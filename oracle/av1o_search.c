@@ -384,7 +384,7 @@ static int rd_partition(Search *s, int r, int c, int bs, int64_t known_j) {
     }
     /* PARTITION_HORZ / PARTITION_VERT of an 8x8 node (two 8x4 / 4x8 blocks), tried against the best of NONE / SPLIT so far */
     int rect_won = 0;
-    if (AV1O_RECT_PART && bs == BS_8) {
+    if (bs == BS_8) {
       static AreaSnap best_snap, split_snap;
       int64_t j_best = j_none; int have_split = 0;
       if (j_split < j_none) { j_best = j_split; area_copy(f, &split_snap, r, c, bs, 1); have_split = 1; }
@@ -438,7 +438,7 @@ static int64_t rd_partition_bottomup(Search *s, int r, int c, int bs) {
     if (!must_split && j_split >= j_none) break;               /* costs only grow */
     j_split += rd_partition_bottomup(s, r + (k >> 1) * half, c + (k & 1) * half, bs - 1);
   }
-  if (AV1O_RECT_PART && bs == BS_8 && !must_split) {
+  if (bs == BS_8 && !must_split) {
     static AreaSnap best_snap, split_snap;
     int64_t j_best = j_none; int rect_won = 0, have_split = 0;
     if (j_split < j_none) { j_best = j_split; area_copy(f, &split_snap, r, c, bs, 1); have_split = 1; }
@@ -460,6 +460,7 @@ static int64_t rd_partition_bottomup(Search *s, int r, int c, int bs) {
 
 void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
   Search s; s.f = f;
+  f->cost = f->tile_cost ? f->tile_cost + (size_t)(tile_row * f->tile_cols + tile_col) * CDF_TOTAL : f->cost0;
   s.t.mi_row_start = f->tile_row_start[tile_row] * SB_MI; s.t.mi_row_end = imin(f->tile_row_start[tile_row + 1] * SB_MI, f->mi_rows);
   s.t.mi_col_start = f->tile_col_start[tile_col] * SB_MI; s.t.mi_col_end = imin(f->tile_col_start[tile_col + 1] * SB_MI, f->mi_cols);
   for (int p = 0; p < f->np; p++) {

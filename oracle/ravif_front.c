@@ -133,7 +133,7 @@ static int encode_planes(const RavifOracleEncoder *e, int w, int h, uint16_t *pl
   const int quantizer = av1o_quality_to_quantizer(e->quality), aquant = av1o_quality_to_quantizer(e->alpha_quality);
   Av1oConfig c; memset(&c, 0, sizeof(c));
   c.width = w; c.height = h; c.bit_depth = depth; c.mono = 0; c.quantizer = quantizer; c.full_range = 1;
-  c.has_color_desc = 1; c.color_primaries = 1; c.transfer = 13; c.matrix = matrix; c.threads = e->threads; c.tiles_override = e->tiles_override;
+  c.has_color_desc = 1; c.color_primaries = 1; c.transfer = 13; c.matrix = matrix; c.threads = e->threads; c.tiles_override = e->tiles_override; c.rdo_passes = e->rdo_passes;
   if (av1o_tweaks_from_preset(e->speed, quantizer, &c)) return 4;
   Av1oResult rc, ra; memset(&ra, 0, sizeof(ra));
   const uint16_t *planes[3] = { pl[0], pl[1], pl[2] }; int strides[3] = { w, w, w };
@@ -142,7 +142,7 @@ static int encode_planes(const RavifOracleEncoder *e, int w, int h, uint16_t *pl
   if (alpha_plane) {
     Av1oConfig a; memset(&a, 0, sizeof(a));
     a.width = w; a.height = h; a.bit_depth = depth; a.mono = 1; a.quantizer = aquant; a.full_range = 1; a.has_color_desc = 0;
-    a.threads = e->threads; a.tiles_override = e->tiles_override;
+    a.threads = e->threads; a.tiles_override = e->tiles_override; a.rdo_passes = e->rdo_passes;
     av1o_tweaks_from_preset(e->speed, aquant, &a);
     const uint16_t *ap[3] = { alpha_plane, 0, 0 };
     st = av1o_encode(&a, ap, strides, &ra);

@@ -24,30 +24,43 @@ PLANE_CASES = {
              (72, 136, 8, 8, 160, False, 2), (8, 8, 8, 4, 121, False, 0), (17, 9, 10, 4, 90, False, 0), (200, 120, 10, 2, 121, False, 0), (200, 120, 8, 3, 170, False, 0)],
 }.get(which, [])
 ok_all = True
-for (w, h, bd, speed, q, mono, tiles) in PLANE_CASES:
+if which == 'quick':
+    PLANE_CASES = [c + (1,) for c in PLANE_CASES] + [(136, 136, 8, 4, 121, False, 4, 2), (72, 40, 10, 1, 121, False, 2, 2)]      # + two-pass pricing (rdo_passes = 2)
+else:
+    PLANE_CASES = [c + (1,) for c in PLANE_CASES]
+for (w, h, bd, speed, q, mono, tiles, passes) in PLANE_CASES:
     pl = planes(h, w, seed=w + h, bd=bd, mono=mono)
-    r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, speed, tiles=tiles), pl)
+    r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, speed, tiles=tiles, rdo_passes=passes), pl)
     t = time.time()
-    obu, rec = m.encode_planes(pl, bd, q, speed, mono, tiles=tiles)
+    obu, rec = m.encode_planes(pl, bd, q, speed, mono, tiles=tiles, rdo_passes=passes)
     ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
     ok_all &= ok
-    print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d' % (w, h, bd, speed, q, int(mono), tiles), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
+    print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d passes%d' % (w, h, bd, speed, q, int(mono), tiles, passes), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
 
 if which == 'rect':
     sys.exit(0 if ok_all else 1)
 if which == 'batch':                               # batch API: several images, colour + alpha frames, bottom-up order (work lists spanning frames and block-size classes)
     from cavif_rs_amd.synth import synth_image
     ok_all = True
-    for (w, h, speed, q, depth, alpha, nimg) in [(200, 136, 4, 80.0, 10, False, 3), (136, 100, 4, 60.0, 8, True, 2), (72, 72, 2, 80.0, 10, False, 1)]:
-        e = m.Encoder().with_quality(q).with_alpha_quality(90.0).with_speed(speed).with_bit_depth(depth)
+    for (w, h, speed, q, depth, alpha, nimg, passes) in [(200, 136, 4, 80.0, 10, False, 3, 1), (136, 100, 4, 60.0, 8, True, 2, 2), (72, 72, 2, 80.0, 10, False, 1, 1)]:
+        e = m.Encoder().with_quality(q).with_alpha_quality(90.0).with_speed(speed).with_bit_depth(depth).with_rdo_passes(passes)
         imgs = [synth_image(w, h, index=i, alpha=alpha) for i in range(nimg)]
         b = m.BatchEncoder(e, nimg, w, h, 4 if alpha else 3)
         for i, im in enumerate(imgs): b.upload(i, im)
         t = time.time(); b.encode()
-        ok = all(b.get(i).avif_file == oracle.ravif_encode(im, quality=q, alpha_quality=90.0, speed=speed, depth=depth)[0] for i, im in enumerate(imgs))
+        ok = all(b.get(i).avif_file == oracle.ravif_encode(im, quality=q, alpha_quality=90.0, speed=speed, depth=depth, rdo_passes=passes)[0] for i, im in enumerate(imgs))
         ok_all &= ok
         print(json.dumps({'case': 'batch %dx%d s%d n%d alpha%d' % (w, h, speed, nimg, int(alpha)), 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
         b.close()
+    # the streaming fan-out with a dozen shapes (the emulated device reports little free memory: the worker's eviction path runs) and two workers on one device
+    shapes = [(40 + 8 * k2, 24 + 8 * (k2 % 3)) for k2 in range(7)]
+    imgs = [synth_image(w, h, index=k2, alpha=(k2 % 4 == 3)) for k2, (w, h) in enumerate(shapes)] + [synth_image(*shapes[1], index=20)]
+    e = m.Encoder().with_quality(70).with_speed(8)
+    t = time.time()
+    ref = [oracle.ravif_encode(im, quality=70, alpha_quality=80, speed=8)[0] for im in imgs]
+    ok = [g.avif_file for g in m.encode_many(e, imgs, devices=[0])] == ref and [g.avif_file for g in m.encode_many(e, imgs, devices=[0, 0])] == ref
+    ok_all &= ok
+    print(json.dumps({'case': 'stream, 7 shapes, 1 and 2 workers', 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
     sys.exit(0 if ok_all else 1)
 # ravif level: RGBA with a used alpha channel, UnassociatedClean (dirty-alpha kernels + front end + colour and alpha frames + container)
 img = rgba_noisy()[:40, :56].copy()

@@ -97,6 +97,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)192 << 20; *tot = (size_t)4 << 30; return hipSuccess; }   // a small device: the stream's eviction path gets exercised
 void *emu_alloc(size_t n);
 void emu_free(void *p);
 template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)emu_alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }

@@ -10,7 +10,7 @@ class Av1oConfig(C.Structure):
         'has_color_desc', 'color_primaries', 'transfer', 'matrix', 'threads',
         'part_min', 'part_max', 'complex_modes', 'fine_directional', 'rdo_tx', 'reduced_tx_set',
         'fast_deblock', 'cdef', 'lrf', 'sgr_full', 'bottomup', 'tx_domain_rate', 'inter_tx_split',
-        'min_tile_size', 'tiles_override', 'tune_psnr')]
+        'min_tile_size', 'tiles_override', 'tune_psnr', 'rdo_passes')]
 
 class Av1oResult(C.Structure):
     _fields_ = [('obu', C.POINTER(C.c_uint8)), ('obu_len', C.c_size_t),
@@ -23,7 +23,7 @@ class Av1oResult(C.Structure):
 
 class RavifEncoder(C.Structure):
     _fields_ = [('quality', C.c_float), ('alpha_quality', C.c_float), ('speed', C.c_int), ('color_model', C.c_int),
-                ('depth', C.c_int), ('alpha_mode', C.c_int), ('threads', C.c_int), ('tiles_override', C.c_int)]
+                ('depth', C.c_int), ('alpha_mode', C.c_int), ('threads', C.c_int), ('tiles_override', C.c_int), ('rdo_passes', C.c_int)]
 
 class RavifImage(C.Structure):
     _fields_ = [('avif', C.POINTER(C.c_uint8)), ('avif_len', C.c_size_t), ('color_byte_size', C.c_size_t), ('alpha_byte_size', C.c_size_t)]
@@ -93,12 +93,12 @@ def container(color, alpha, w, h, depth, mono_color=0, cp=1, tc=13, mc=6, full_r
     L.av1o_free(outp)
     return data
 
-def ravif_encode(pixels, quality=80., alpha_quality=80., speed=5, color_model=0, depth=0, alpha_mode=1, threads=0, tiles=0):
+def ravif_encode(pixels, quality=80., alpha_quality=80., speed=5, color_model=0, depth=0, alpha_mode=1, threads=0, tiles=0, rdo_passes=1):
     """pixels: HxWx3 or HxWx4 uint8. Returns (avif bytes, color_size, alpha_size)."""
     L = lib()
     px = np.ascontiguousarray(pixels, dtype=np.uint8)
     h, w, ch = px.shape
-    e = RavifEncoder(quality, alpha_quality, speed, color_model, depth, alpha_mode, threads, tiles)
+    e = RavifEncoder(quality, alpha_quality, speed, color_model, depth, alpha_mode, threads, tiles, rdo_passes)
     img = RavifImage()
     fn = L.ravif_oracle_encode_rgba if ch == 4 else L.ravif_oracle_encode_rgb
     st = fn(C.byref(e), px.ctypes.data, w, h, w, C.byref(img))

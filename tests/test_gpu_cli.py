@@ -41,6 +41,23 @@ def test_encode_many_equals_single_calls_and_oracle(oracle):
         m.encode_many(e, imgs, devices=[m.device_count() + 3])
 
 
+def test_encode_many_with_a_dozen_shapes_and_two_workers_on_one_device(oracle):
+    """A directory of differently sized files: every shape gets its own batch object, the worker gives the least recently used ones back when its
+    memory budget says so, runs follow the arrival order.  devices=[0, 0] drives the multi-device code path (two host workers, one shared cursor,
+    independent slots) on a single GPU; the bytes do not depend on which worker took an image."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    shapes = [(64 + 8 * k, 48 + 16 * (k % 5)) for k in range(13)]
+    imgs = [synth_image(w, h, index=k, alpha=(k % 4 == 3)) for k, (w, h) in enumerate(shapes)]
+    imgs += [synth_image(*shapes[2], index=40), synth_image(*shapes[2], index=41), synth_image(*shapes[0], index=42)]      # shapes that come back
+    e = m.Encoder().with_quality(75).with_speed(6)
+    ref = [oracle.ravif_encode(im, quality=75, alpha_quality=80, speed=6)[0] for im in imgs]
+    got = m.encode_many(e, imgs, devices=[0])
+    assert [g.avif_file for g in got] == ref
+    two = m.encode_many(e, imgs, devices=[0, 0])
+    assert [g.avif_file for g in two] == ref
+
+
 def test_cli_matches_library_and_reports_like_the_reference(tmp_path):
     rgb = (np.add.outer(np.arange(72), np.arange(120))[..., None] * np.array([1, 2, 3])).astype(np.uint8)
     rgba = rgba_gradient(96, 80)

@@ -15,7 +15,7 @@ CLI = os.path.join(ROOT, 'cavif_rs_amd', 'cavif_mi')
 
 
 @pytest.mark.parametrize('over', [dict(lrf=0), dict(rdo_tx_decision=0), dict(fast_deblock=1), dict(tune_psnr=1), dict(cdef=0), dict(sgr_full=1),
-                                  dict(rdo_tx_decision=0, inter_tx_split=1), dict(lrf=0, cdef=0, fast_deblock=1, rdo_tx_decision=0, tune_psnr=1)])
+                                  dict(rdo_tx_decision=0, inter_tx_split=1), dict(lrf=0, cdef=0, fast_deblock=1, rdo_tx_decision=0, tune_psnr=1), dict(rdo_passes=2), dict(rdo_passes=2, tiles_override=6)])
 def test_tool_switches_hip_equals_oracle(oracle, over):
     import cavif_rs_amd as m
     w, h, bd = 264, 200, 10

@@ -29,6 +29,18 @@ def test_tool_switches_stay_decodable(oracle, avifdec, over):
     _roundtrip(oracle, avifdec, 200, 150, 10, 4, 121, **over)
 
 
+def test_two_pass_pricing_decodes_and_pays(oracle, avifdec):
+    """rdo_passes = 2 (an extension towards rav1e's adaptive pricing): the second search prices every tile against the CDFs the
+    tile ended its first pass with.  The stream stays decodable bit-exactly and, on these inputs, costs no more bytes at no more squared error."""
+    for (w, h, bd, q, tiles) in [(200, 136, 10, 121, 0), (300, 270, 10, 121, 4)]:
+        pl = planes(h, w, seed=w + h, bd=bd)
+        one = oracle.encode_planes(oracle.make_config(w, h, bd, False, q, 4, tiles=tiles), pl)
+        two = oracle.encode_planes(oracle.make_config(w, h, bd, False, q, 4, tiles=tiles, rdo_passes=2), pl)
+        d = avifdec.decode(oracle.container(two['obu'], None, w, h, bd))
+        assert all(np.array_equal(a, b) for a, b in zip(d['planes'], two['recon']))
+        assert two['obu'] != one['obu'] and len(two['obu']) <= len(one['obu']) and sum(two['sse']) <= sum(one['sse'])
+
+
 def test_speed4_q80_switches_are_on(oracle, avifdec):
     cfg, r = _roundtrip(oracle, avifdec, 264, 200, 10, 4, 121)
     assert cfg.lrf == 1 and cfg.rdo_tx == 1 and cfg.fast_deblock == 0 and cfg.cdef == 1      # av1encoder.rs:580,586,589,590

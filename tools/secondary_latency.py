@@ -1,5 +1,5 @@
 """Single-image latency of BASELINE configs 2 / 3 / 5 (tools/secondary_latency.py [2] [3] [5]); configs 3 and 5 are also compared with the
-oracle's committed sha256 (tests/golden/fullsize_golden.json).  MI_K1_WORKERS=1 switches the tile search's row workers off for an A/B."""
+oracle's committed sha256 (tests/golden/fullsize_golden.json).  the tile search is a work queue of superblocks for every launch size."""
 import hashlib, json, os, sys, time
 sys.path.insert(0, '.')
 import cavif_rs_amd as m
@@ -19,6 +19,6 @@ for key in (sys.argv[1:] or ['2', '3']):
         best = dt if best is None or dt < best else best
     data = bt.get(0).avif_file
     same = None if gname is None else hashlib.sha256(data).hexdigest() == gold[gname]['avif_sha256']
-    print(json.dumps({'workload': name, 'workers_env': os.environ.get('MI_K1_WORKERS', 'auto'), 'latency_ms': round(best * 1e3, 1), 'MPix_per_s': round(w * h / 1e6 / best, 2), 'tiles': bt.num_tiles(),
+    print(json.dumps({'workload': name, 'latency_ms': round(best * 1e3, 1), 'MPix_per_s': round(w * h / 1e6 / best, 2), 'tiles': bt.num_tiles(),
                       'bytes': len(data), 'equals_oracle_sha256': same, 'stage_ms': {k: round(v, 1) for k, v in bt.stage_ms().items()}}), flush=True)
     bt.close()
