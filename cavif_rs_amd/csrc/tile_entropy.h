@@ -154,21 +154,25 @@ __device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, 
     const uint32_t cur = rv;
     if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
     const int m = imin_(64, n - cb);
-    for (int j = 0; j < m; j++) {
-      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, j);
+    // ONE coding step per iteration and one normalisation site: a literal's bits are steps of their own -- an equiprobable bool is the bounds
+    // (fl >> 6, fh >> 6, 4 * (N - s)) = (256, 0, 0) for a one and (512 = the top, 256, 4) for a zero
+    int j = 0, lit_left = 0; uint32_t lit_val = 0;
+    uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, 0);
+    while (j < m) {
+      uint32_t fl6, fh6, nms4;
+      if (lit_left == 0 && (rec >> 31)) { lit_left = (int)((rec >> 20) & 31u); lit_val = rec & 0xFFFFFu; }
+      bool advance = true;
+      if (lit_left) {
+        lit_left--;
+        const uint32_t bit = (lit_val >> lit_left) & 1u;
+        fl6 = bit ? 256u : 512u; fh6 = bit ? 0u : 256u; nms4 = bit ? 0u : 4u;
+        advance = lit_left == 0;
+      } else { fl6 = rec & 1023u; fh6 = (rec >> 10) & 1023u; nms4 = (rec >> 18) & 60u; }
+      if (advance) { j++; rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, imin_(j, m - 1)); }
       const uint32_t r = e->rng, r8 = r >> 8;
-      if (rec >> 31) {
-        const uint32_t val = rec & 0xFFFFFu;
-        for (int b = (int)((rec >> 20) & 31u) - 1; b >= 0; b--) {
-          const uint32_t rr = e->rng, hv = ((rr >> 8) << 7) + 4u;                 // the boundary of the two equiprobable halves
-          if ((val >> b) & 1u) re_normalize_dev(e, e->low + (rr - hv), hv); else re_normalize_dev(e, e->low, rr - hv);
-        }
-      } else {
-        const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms4 = (rec >> 18) & 60u;      // 4 * (alphabet size - 1 - symbol)
-        const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
-        const uint32_t u = fl6 >= 512u ? r : (k4_smul(r8, fl6) >> 1) + nms4 + 4u;
-        re_normalize_dev(e, e->low + (r - u), u - v);
-      }
+      const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
+      const uint32_t u = fl6 >= 512u ? r : (k4_smul(r8, fl6) >> 1) + nms4 + 4u;
+      re_normalize_dev(e, e->low + (r - u), u - v);
     }
   }
 }
