@@ -89,13 +89,10 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
   *total = __builtin_amdgcn_readlane(x, 63);
   return x - v;
 }
-__device__ __forceinline__ unsigned long long k4_ballot(bool p) {
-#ifdef MI_EMU_BALLOT
-  return MI_EMU_BALLOT(p);
-#else
-  return __builtin_amdgcn_ballot_w64(p);
+#ifndef MI_BALLOT64                                      /* (the CPU test harness tests/emu/ predefines both, like LDS in dev_common.h) */
+#define MI_BALLOT64(p) __builtin_amdgcn_ballot_w64(p)
 #endif
-}
+__device__ __forceinline__ unsigned long long k4_ballot(bool p) { return MI_BALLOT64(p); }
 // Adapter `a` over one superblock's records: only its own rows' records are visited (ballot of the chunk, lowest set bit first).  The row sits in a
 // register (lane i = entry i, lane nsyms = the adaptation counter) and stays there while consecutive records name it.
 __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, int n_in, int a) {
@@ -140,13 +137,10 @@ __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, in
   }
 }
 // The coder over one superblock's finished records: range arithmetic and byte output only, on the scalar unit.
-__device__ __forceinline__ uint32_t k4_smul(uint32_t a, uint32_t b) {        // (the compiler would route a provably-24-bit uniform product through the vector unit)
-#ifdef MI_EMU_BALLOT
-  return a * b;
-#else
-  uint32_t r; asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r;
+#ifndef MI_SMUL32
+#define MI_SMUL32(r, a, b) asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b))
 #endif
-}
+__device__ __forceinline__ uint32_t k4_smul(uint32_t a, uint32_t b) { uint32_t r; MI_SMUL32(r, a, b); return r; }   // (the compiler would route a provably-24-bit uniform product through the vector unit)
 __device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, int n_in) {
   const int n = uni32(n_in);
   uint32_t rv = n > 0 ? buf[imin_(LANE, n - 1)] : 0u;

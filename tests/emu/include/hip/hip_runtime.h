@@ -79,7 +79,8 @@ inline unsigned long long emu_ballot64(bool p) {
   for (int d = 1; d < 64; d <<= 1) { const int a = __shfl(lo, l ^ d), b = __shfl(hi, l ^ d); lo |= a; hi |= b; }
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
-#define MI_EMU_BALLOT(p) emu_ballot64(p)
+#define MI_BALLOT64(p) emu_ballot64(p)
+#define MI_SMUL32(r, a, b) ((r) = (a) * (b))
 struct uchar4 { unsigned char x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };

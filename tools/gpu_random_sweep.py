@@ -12,17 +12,18 @@ for i in range(N):
     w, h = int(rng.integers(8, 420)), int(rng.integers(8, 300))
     speed = int(rng.integers(1, 11)); q = float(rng.integers(5, 100)); aq = float(rng.integers(5, 100))
     depth = int(rng.choice([8, 10])); cm = int(rng.integers(0, 2)); am = int(rng.integers(0, 3)); alpha = bool(rng.integers(0, 2))
-    threads = int(rng.choice([0, 0, 1, 3]))
+    threads = int(rng.choice([0, 0, 1, 3])); passes = 2 if rng.integers(0, 5) == 0 else 1
     img = synth_image(w, h, index=int(rng.integers(0, 1000)), alpha=alpha)
     if rng.integers(0, 3) == 0:
         img = rng.integers(0, 256, size=img.shape, dtype=np.uint8)          # pure noise now and then
     e = m.Encoder().with_quality(q).with_alpha_quality(aq).with_speed(speed).with_bit_depth(depth).with_alpha_color_mode(['dirty', 'clean', 'premultiplied'][am])
     if cm: e = e.with_internal_color_model('rgb')
     if threads: e = e.with_num_threads(threads)
+    e = e.with_rdo_passes(passes)
     got = e.encode_rgba(img) if alpha else e.encode_rgb(img)
-    ref, cs, als = oracle.ravif_encode(img, quality=q, alpha_quality=aq, speed=speed, color_model=cm, depth=depth, alpha_mode=am, threads=threads)
+    ref, cs, als = oracle.ravif_encode(img, quality=q, alpha_quality=aq, speed=speed, color_model=cm, depth=depth, alpha_mode=am, threads=threads, rdo_passes=passes)
     ok = got.avif_file == ref
     if not ok:
         bad += 1
-        print('MISMATCH', dict(w=w, h=h, speed=speed, q=q, aq=aq, depth=depth, cm=cm, am=am, alpha=alpha, threads=threads), len(got.avif_file), len(ref), flush=True)
+        print('MISMATCH', dict(w=w, h=h, speed=speed, q=q, aq=aq, depth=depth, cm=cm, am=am, alpha=alpha, threads=threads, passes=passes), len(got.avif_file), len(ref), flush=True)
 print('sweep done: %d cases, %d mismatches' % (N, bad))
