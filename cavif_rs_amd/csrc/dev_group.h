@@ -26,6 +26,33 @@ __device__ __forceinline__ int row_max_i32(int v) {
   v = imax_(v, dpp_row_<0x128>(v)); v = imax_(v, dpp_row_<0x124>(v)); v = imax_(v, dpp_row_<0x122>(v)); v = imax_(v, dpp_row_<0x121>(v)); return v;
 }
 
+// ---- 4x4 blocks: both 1-D passes in registers.  Every 4-point network of txfm_gen.hip.h rounds each output once, so it is a
+// 4x4 integer matrix: out[k] = R12(A[k] . x) + sign * R12(B[k] . x)  (B is the odd half of the inverse DCT, whose butterfly adds two
+// separately rounded terms; zero everywhere else).  A group's 16 lanes hold the block one sample per lane, a quad = one column (then
+// one row); a pass is four quad broadcasts (DPP quad_perm) and four 24-bit multiply-adds, the transposition between the passes one
+// ds_bpermute.  Table: [inverse][kind][k] -> A[0..3], B[0..3].
+static __device__ const int tx4_tab[2][3][4][8] = {
+  { { { 2896, 2896, 2896, 2896, 0, 0, 0, 0 }, { 3784, 1567, -1567, -3784, 0, 0, 0, 0 }, { 2896, -2896, -2896, 2896, 0, 0, 0, 0 }, { 1567, -3784, 3784, -1567, 0, 0, 0, 0 } },
+    { { 1321, 2482, 3344, 3803, 0, 0, 0, 0 }, { 3344, 3344, 0, -3344, 0, 0, 0, 0 }, { 3803, -1321, -3344, 2482, 0, 0, 0, 0 }, { 2482, -3803, 3344, -1321, 0, 0, 0, 0 } },
+    { { 5793, 0, 0, 0, 0, 0, 0, 0 }, { 0, 5793, 0, 0, 0, 0, 0, 0 }, { 0, 0, 5793, 0, 0, 0, 0, 0 }, { 0, 0, 0, 5793, 0, 0, 0, 0 } } },
+  { { { 2896, 0, 2896, 0, 0, 3784, 0, 1567 }, { 2896, 0, -2896, 0, 0, 1567, 0, -3784 }, { 2896, 0, -2896, 0, 0, 1567, 0, -3784 }, { 2896, 0, 2896, 0, 0, 3784, 0, 1567 } },
+    { { 1321, 3344, 3803, 2482, 0, 0, 0, 0 }, { 2482, 3344, -1321, -3803, 0, 0, 0, 0 }, { 3344, 0, -3344, 3344, 0, 0, 0, 0 }, { 3803, -3344, 2482, -1321, 0, 0, 0, 0 } },
+    { { 5793, 0, 0, 0, 0, 0, 0, 0 }, { 0, 5793, 0, 0, 0, 0, 0, 0 }, { 0, 0, 5793, 0, 0, 0, 0, 0 }, { 0, 0, 0, 5793, 0, 0, 0, 0 } } } };
+__device__ __forceinline__ int tx4_dot(int v, const int *m) {      // R12(m . quad), the quad's four values broadcast to each of its lanes
+  int acc = __mul24(m[0], dpp_row_<0x00>(v)) + 2048;
+  acc += __mul24(m[1], dpp_row_<0x55>(v));
+  acc += __mul24(m[2], dpp_row_<0xAA>(v));
+  acc += __mul24(m[3], dpp_row_<0xFF>(v));
+  return acc >> 12;
+}
+__device__ __forceinline__ int tx4_fwd(int v, int kind) { return tx4_dot(v, tx4_tab[0][kind][LANE & 3]); }
+__device__ __forceinline__ int tx4_inv(int v, int kind) {
+  const int *m = tx4_tab[1][kind][LANE & 3];
+  const int e = tx4_dot(v, m), o = tx4_dot(v, m + 4);              // o = R12(0) = 0 outside the DCT
+  return (LANE & 2) ? e - o : e + o;
+}
+__device__ __forceinline__ int group_transpose4(int v) { return __shfl(v, (LANE & 48) | ((LANE & 3) << 2) | ((LANE >> 2) & 3)); }
+
 struct GroupRes { int eob, cul, dcc, sse; uint32_t rate; };
 
 // All arguments may differ between the four groups of the wave (they are uniform inside a group).  `live` = false groups
@@ -38,6 +65,18 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   const int gl = GROUP_LANE;
   const int bd = f->bd;
   const uint32_t tx_cost = cost[tx_off >= 0 ? tx_off + tx_sym : 0];     // the one global-memory operand of the evaluation: issued first, consumed after the transforms
+  int ck, rk; tx_kinds(txtype, &ck, &rk);
+  [[maybe_unused]] int t_src = 0, t_rec = 0;                        // N == 4: this lane's sample (transposed index, see tx4_tab) lives in registers
+  [[maybe_unused]] const int tidx = ((gl & 3) << 2) | (gl >> 2);
+  if constexpr (N == 4) {
+    t_src = src[tidx]; t_rec = pred[tidx];
+    gb->rec[tidx] = (uint16_t)t_rec;
+    for (int i = gl; i < 36; i += 16) ((LDS uint32_t *)gb->lev)[i] = 0;
+    int v = tx4_fwd((int)((uint32_t)(t_src - t_rec) << 2), ck);    // column pass: the quad holds one column
+    v = group_transpose4(v);
+    gb->cbuf[gl] = tx4_fwd(v, rk);                                  // row pass: the quad holds one row; the lane's coefficient is raster position gl
+    WAVE_SYNC();
+  } else {
   // ---- residual, reconstruction seed, level-map reset
 #pragma unroll
   for (int k = 0; k < IT; k++) {
@@ -49,7 +88,6 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   for (int i = gl; i < 36; i += 16) ((LDS uint32_t *)gb->lev)[i] = 0;
   WAVE_SYNC();
   // ---- forward 2-D transform (fwd_txfm2d_dev: shifts {2, 0, 0} for 4x4, {2, -1, 0} for 8x8)
-  int ck, rk; tx_kinds(txtype, &ck, &rk);
   if (gl < N) {
     int32_t x[N];
 #pragma unroll
@@ -68,6 +106,7 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
     for (int c = 0; c < N; c++) gb->cbuf[gl * N + c] = x[c];
   }
   WAVE_SYNC();
+  }
   // ---- quantise + level map + dequantise + rate (quant_rate_dev, 16 lanes per candidate)
   const int dcq = f->dc_q[plane], acq = f->ac_q[plane];
   const uint32_t dc_recip = f->dc_recip[plane], ac_recip = f->ac_recip[plane];
@@ -165,30 +204,42 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   {
     constexpr int ROWSH = N == 4 ? 0 : 1;
     const int cbits = imax_(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
-    const bool act = gl < N && eob > 0;
-    if (act) {
-      int32_t x[N];
-#pragma unroll
-      for (int j = 0; j < N; j++) x[j] = gb->cbuf[gl * N + j];
-      tx1d<N>(x, rk, false);
-#pragma unroll
-      for (int j = 0; j < N; j++) gb->tbuf[gl * P + j] = iclamp_(round2_(x[j], ROWSH), cmin, cmax);
+    if constexpr (N == 4) {
+      if (eob > 0) {
+        int v = iclamp_(tx4_inv(gb->cbuf[gl], rk), cmin, cmax);    // row pass (ROWSH = 0)
+        v = group_transpose4(v);
+        t_rec = iclamp_(t_rec + round2_(tx4_inv(v, ck), 4), 0, (1 << bd) - 1);
+        gb->rec[tidx] = (uint16_t)t_rec;
+      }
+      WAVE_SYNC();
+    } else {
+      const bool act = gl < N && eob > 0;
+      if (act) {
+        int32_t x[N];
+  #pragma unroll
+        for (int j = 0; j < N; j++) x[j] = gb->cbuf[gl * N + j];
+        tx1d<N>(x, rk, false);
+  #pragma unroll
+        for (int j = 0; j < N; j++) gb->tbuf[gl * P + j] = iclamp_(round2_(x[j], ROWSH), cmin, cmax);
+      }
+      WAVE_SYNC();
+      const int mx = (1 << bd) - 1;
+      if (act) {
+        int32_t x[N];
+  #pragma unroll
+        for (int i = 0; i < N; i++) x[i] = gb->tbuf[i * P + gl];
+        tx1d<N>(x, ck, false);
+  #pragma unroll
+        for (int i = 0; i < N; i++) gb->rec[i * N + gl] = (uint16_t)iclamp_((int)gb->rec[i * N + gl] + round2_(x[i], 4), 0, mx);
+      }
+      WAVE_SYNC();
     }
-    WAVE_SYNC();
-    const int mx = (1 << bd) - 1;
-    if (act) {
-      int32_t x[N];
-#pragma unroll
-      for (int i = 0; i < N; i++) x[i] = gb->tbuf[i * P + gl];
-      tx1d<N>(x, ck, false);
-#pragma unroll
-      for (int i = 0; i < N; i++) gb->rec[i * N + gl] = (uint16_t)iclamp_((int)gb->rec[i * N + gl] + round2_(x[i], 4), 0, mx);
-    }
-    WAVE_SYNC();
   }
   // distortion (Tune::Psychovisual): psy_sv >= 0 = luma, the block is one cdef-dist cell (its SSE boosted by the SSIM-like
   // factor of source / reconstruction variance) x activity; psy_sv < 0 = plain SSE x the activity scale psy_act (Q14)
   int s = 0, sd = 0, qd = 0;
+  if constexpr (N == 4) { const int d = t_src - t_rec; s = __mul24(d, d); sd = t_rec; qd = __mul24(t_rec, t_rec); }
+  else
 #pragma unroll
   for (int k = 0; k < IT; k++) { const int idx = gl + 16 * k; const int rv = gb->rec[idx], d = (int)src[idx] - rv; s += __mul24(d, d); sd += rv; qd += __mul24(rv, rv); }
   s = row_sum_i32(s);                            // <= 64 * 1023^2 < 2^27

@@ -15,10 +15,6 @@
 #include "dev_rate.h"
 #include "restoration.h"
 
-// Three pipelined forms of this kernel (walker wave + range-coder wave; walker | four CDF-adapter waves | coder through an LDS ring; the same
-// three stages as three kernels with the record stream in HBM) were measured on the MI355X in round 3 and all lost against the single wave
-// (43.5 ms per 1024 tiles: 44.0 / 46.0 / 75.9 ms, profiles/r03_variants_ab.txt); they are not in the tree.
-#define MI_K4_THREADS 64
 struct RangeEncDev {
   uint16_t *pre; uint32_t cap, offs;     // pre-carry units in HBM; offs counts every unit flushed so far, stored or not (overflow <=> the total exceeds cap)
   uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
