@@ -87,7 +87,7 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
 // K2a: deblock level search (rav1e deblock_filter_optimize with fast_deblock == false; oracle/av1o_filters.c
 // deblock_tally_line).  One thread per edge line, judged on the unfiltered reconstruction: with sharpness 0 the filter of a
 // line is off below the smallest level Lmin that passes the masks and can only change where L >> 4 changes, so a line adds at
-// most four (level range, SSE delta) pairs to the (plane, pass) difference array -- LDS first, then one global atomic per
+// most two (level range, SSE delta) pairs to the (plane, pass) difference array -- LDS first, then one global atomic per
 // non-zero entry and workgroup.  grid = (line chunks, plane * 2 + pass, frame).
 __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__restrict__ frames, int nframes) {
   const FrameDev *f = frames + blockIdx.z;
@@ -118,8 +118,14 @@ __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__re
       int sse0 = 0;
 #pragma unroll
       for (int k = 0; k < 16; k++) { const int d = R[k] - S[k]; sse0 += d * d; }
+      // above lmin the level reaches the filter only through the high-edge-variance threshold (L >> 4): consecutive ranges with the same
+      // hev decision share one filtered line and one (first level, end) pair -- at most two filter runs per line (hev only falls as L grows)
+      const int hm = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
+      long long dl = 0; int hev_open = -1, a_open = 0;
       for (int a = lmin; a < 64; a = (a | 15) + 1) {
-        const int bnd = imin_(64, (a | 15) + 1);
+        const int hev = hm > ((a >> 4) << s8);
+        if (hev == hev_open) continue;
+        if (dl) { atomicAdd((unsigned long long *)&ldiff[a_open], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[a], (unsigned long long)(-dl)); }
         uint16_t t[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) t[k] = (uint16_t)R[k];
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__re
         int sse = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) { const int d = (int)t[k] - S[k]; sse += d * d; }
-        const long long dl = (long long)(sse - sse0);
-        if (dl) { atomicAdd((unsigned long long *)&ldiff[a], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[bnd], (unsigned long long)(-dl)); }
+        dl = (long long)(sse - sse0); hev_open = hev; a_open = a;
       }
+      if (dl) { atomicAdd((unsigned long long *)&ldiff[a_open], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[64], (unsigned long long)(-dl)); }
     }
   }
   __syncthreads();
