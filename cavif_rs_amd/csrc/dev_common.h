@@ -22,6 +22,14 @@ enum { DCT_DCT = 0, ADST_DCT, DCT_ADST, ADST_ADST, FLIPADST_DCT, DCT_FLIPADST, F
        ADST_FLIPADST, FLIPADST_ADST, IDTX, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST };
 enum { TXC_2D = 0, TXC_HORIZ = 1, TXC_VERT = 2 };
 
+// Segmentation (segment_kernel in loopfilter.h; oracle/av1o_segment.c): what the frame's activity scales were fitted to.  n = 0: off.
+// Segment i: q[i] = its quantiser steps and reciprocals per plane, laid out like FrameDev::dc_q .. ac_recip (the tile search copies
+// a block's entry over those fields of its LDS copy).  thr[]: scale-bucket thresholds between the n clusters (ascending).
+#define MI_SEG_BINS 4096
+struct SegTab {
+  int n, mean, thr[7], qidx[8], pad_[3];
+  struct Q { int dc_q[3], ac_q[3]; uint32_t dc_recip[3], ac_recip[3]; } q[8];
+};
 // Everything a kernel needs to know about one plane-set being encoded (one AV1 frame: the colour
 // image or the alpha plane of one input image).  Lives in device memory; pointers are device pointers.
 struct FrameDev {
@@ -31,7 +39,7 @@ struct FrameDev {
   int pw, ph, stride, mi_stride, mi_h;
   uint16_t *src[3], *rec[3];               // source, in-loop reconstruction (deblocked in place)
   int32_t *coef[3];
-  uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av, *m_decoded;
+  uint8_t *m_bsize, *m_skip, *m_ymode, *m_uvmode, *m_txtype, *m_cfl_sign, *m_cfl_au, *m_cfl_av, *m_decoded;   // m_skip: bit 0 = skip, bits 1.. = segment id
   uint8_t *m_txsize;                       // luma transform size of the block (0 = 4x4 .. 4 = 64x64), uniform over the block
   int8_t *m_angle_y, *m_angle_uv;
   uint8_t *m_lvl[3], *m_dc[3];
@@ -45,6 +53,8 @@ struct FrameDev {
   int tile_cols;
   // Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent)
   const uint32_t *act, *svar8, *svar4; int tune_psnr;
+  int seg_n;                 // segments in use (0 = segmentation off); written by segment_kernel, like *seg
+  const SegTab *seg;
   int *sb_prog;              // K1 work queue: superblocks finished per (frame SB row, tile column); zeroed before every encode
   int dbg;                   // debug bisect level (0 = off; probe builds only)
   const uint16_t *cost;      // static rate table [CDF_TOTAL] (cost per symbol in 1/512 bit, same flat layout as the CDF context)
@@ -67,6 +77,7 @@ struct FrameDev {
   const uint16_t *tile_cost; uint16_t *cdf_out; uint16_t *tile_cost_buf;
   // loop filter / cdef
   int lf_level[4], lf_sharp, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
+  int seg_ddc[3], seg_dac[3];   // the frame header's plane deltas (dc / ac index of plane p minus base_q_idx): a segment's steps are looked up at its index + these
   long long *lf_tally;       // deblock level search: [3 planes][2 passes][65] SSE-delta difference arrays (zeroed per encode)
   int zero_words;            // 32-bit words of the block starting at m_decoded (decoded flags, lf_tally, sb_prog) that every encode starts from zero: the activity kernel clears it
   int *lf_out;               // the frame's 4 chosen levels, read back by the host for the frame header
@@ -144,6 +155,37 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #define WG_SYNC() __syncthreads()
 
 struct TileB { int mi_row_start, mi_row_end, mi_col_start, mi_col_end; };
+
+// ---- segmentation helpers (oracle/av1o_segment.c: av1o_ilog2_q11, av1o_seg_bucket, av1o_seg_pred, av1o_seg_symbol; spec 5.11.9)
+__device__ __forceinline__ int seg_ilog2_q11(uint32_t x) {
+  if (x == 0) x = 1;
+  const int msb = 31 - __clz((int)x);
+  unsigned long long m = (unsigned long long)x << (31 - msb);
+  int frac = 0;
+#pragma unroll
+  for (int i = 0; i < 11; i++) { m = (m * m) >> 31; frac <<= 1; if (m >> 32) { frac |= 1; m >>= 1; } }
+  return (msb << 11) | frac;
+}
+__device__ __forceinline__ int seg_bucket(uint32_t scale_q14) { return iclamp_((seg_ilog2_q11(scale_q14) - (6 << 11)) >> 3, 0, MI_SEG_BINS - 1); }
+// neighbours' ids (-1 = outside the tile) -> predicted id, CDF context
+__device__ __forceinline__ int seg_pred(int ul, int u, int l, int *ctx) {
+  *ctx = ul < 0 ? 0 : ((ul == u && ul == l) ? 2 : ((ul == u || ul == l || u == l) ? 1 : 0));
+  if (u == -1) return l == -1 ? 0 : l;
+  if (l == -1) return u;
+  return ul == u ? u : l;
+}
+__device__ __forceinline__ int seg_neg_deinterleave(int diff, int ref, int max) {
+  if (!ref) return diff;
+  if (ref >= max - 1) return max - diff - 1;
+  if (2 * ref < max) { if (diff <= 2 * ref) return (diff & 1) ? ref + ((diff + 1) >> 1) : ref - (diff >> 1); return diff; }
+  if (diff <= 2 * (max - ref - 1)) return (diff & 1) ? ref + ((diff + 1) >> 1) : ref - (diff >> 1);
+  return max - (diff + 1);
+}
+__device__ __forceinline__ int seg_symbol(int seg, int pred, int max) {     // the symbol that decodes to `seg`
+  int d = 0;
+  for (int k = 0; k < 8; k++) if (k < max && seg_neg_deinterleave(k, pred, max) == seg) d = k;
+  return d;
+}
 
 // ---- Tune::Psychovisual helpers (oracle/av1o_common.c av1o_psy_boost_q14 / av1o_cell_var; rav1e dist.rs cdef_dist_kernel,
 // activity.rs, recalled): integer, bit-identical to the CPU restatement.

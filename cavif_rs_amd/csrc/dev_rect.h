@@ -547,7 +547,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   const int have_ar = can_ar && uni32(f->m_decoded[can_ar ? (r - 1) * ms + c + w4 : mi]), have_bl = can_bl && uni32(f->m_decoded[can_bl ? (r + h4) * ms + c - 1 : mi]);
   const int amode = availU ? uni32(f->m_ymode[iU]) : DC_PRED, lmode = availL ? uni32(f->m_ymode[iL]) : DC_PRED;
   const int uvU = f->np > 1 ? uni32(f->m_uvmode[iU]) : 0, uvL = f->np > 1 ? uni32(f->m_uvmode[iL]) : 0;
-  const int nb_skip = (availU ? uni32(f->m_skip[iU]) : 0) + (availL ? uni32(f->m_skip[iL]) : 0);
+  const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];        // bit 0 = skip, the rest = segment id
+  const int nb_skip = (availU ? uni32(v_skU) & 1 : 0) + (availL ? uni32(v_skL) & 1 : 0);
+  const int seg_nb = (availU && availL ? (uni32(v_skUL) >> 1) + 1 : 0) | ((availU ? (uni32(v_skU) >> 1) + 1 : 0) << 4) | ((availL ? (uni32(v_skL) >> 1) + 1 : 0) << 8);   // as in try_block
   const int nb_txU = availU ? uni32(f->m_txsize[iU]) : -1, nb_txL = availL ? uni32(f->m_txsize[iL]) : -1;
   const uint16_t *ycost = k.cost() + CDF_KF_Y + (intra_mode_ctx(amode) * 5 + intra_mode_ctx(lmode)) * CDF_KF_Y_STRIDE;
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);
@@ -563,9 +565,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
     for (int idx = LANE; idx < NN; idx += 64) SH->srcb[p][idx] = g[(idx >> WL) * f->stride + (idx & (W_ - 1))];
     load_edges_wh(f, p, x, y, W_, H_, availL, availU, have_ar, have_bl, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF);
   }
-  if (W == NW - 1 && LANE < 2) {
-    SH->psv4[LANE] = (int)f->svar4[(r + (HL == 3 ? LANE : 0)) * ms + c + (WL == 3 ? LANE : 0)];
-    if (LANE == 0) { const int a = (int)f->act[(y >> 3) * (f->pw >> 3) + (x >> 3)]; SH->pact[0] = a; SH->cact = a; }
+  if (W == NW - 1) {
+    const int a = (int)f->act[(y >> 3) * (f->pw >> 3) + (x >> 3)];
+    if (LANE < 2) SH->psv4[LANE] = (int)f->svar4[(r + (HL == 3 ? LANE : 0)) * ms + c + (WL == 3 ? LANE : 0)];
+    if (LANE == 0) { SH->pact[0] = a; SH->cact = a; SH->seg_nb = seg_nb; }
+    seg_select(f, SH, a);
   }
   WG_SYNC();
   const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];
@@ -979,8 +983,12 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   }
   // ---- skip flag ----
   const int skip = !any_coef;
+  int seg_ctx = 0;                                                       // intra_segment_id, as in try_block
+  const int seg_nb2 = SH->seg_nb, seg_ul = (seg_nb2 & 15) - 1, seg_u = ((seg_nb2 >> 4) & 15) - 1, seg_l = (seg_nb2 >> 8) - 1;
+  const int seg_p = seg_pred(seg_ul, seg_u, seg_l, &seg_ctx), seg_own = f->seg_n ? SH->seg : 0, seg_fin = f->seg_n ? (skip ? seg_p : seg_own) : 0;
+  if (f->seg_n && !skip) total_j += ((long long)k.cost()[CDF_SEG_ID + seg_ctx * CDF_SEG_ID_STRIDE + seg_symbol(seg_own, seg_p, f->seg_n)] * f->rdmult + 256) >> 9;
   if (W == 0) {
-    fill_rect<WL, HL>(f->m_skip, ms, r, c, skip);
+    fill_rect<WL, HL>(f->m_skip, ms, r, c, skip | (seg_fin << 1));
     if (skip) for (int p = 0; p < f->np; p++) { fill_rect<WL, HL>(f->m_lvl[p], ms, r, c, 0); fill_rect<WL, HL>(f->m_dc[p], ms, r, c, 0); }
     fill_rect<WL, HL>(f->m_decoded, ms, r, c, 1);
   }

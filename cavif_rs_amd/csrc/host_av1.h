@@ -147,7 +147,7 @@ inline uint32_t neg_log2_q9(uint32_t p) {                      // (15 - log2 p) 
 #define MI_COST_ROWS(X) \
   X(CDF_KF_Y, CDF_KF_Y_STRIDE, 25, 13) X(CDF_ANGLE, CDF_ANGLE_STRIDE, 8, 7) X(CDF_UV_NOCFL, CDF_UV_NOCFL_STRIDE, 13, 13) X(CDF_UV_CFL, CDF_UV_CFL_STRIDE, 13, 14) \
   X(CDF_PARTITION, CDF_PARTITION_STRIDE, 4, 4) X(CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10) X(CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8) \
-  X(CDF_SKIP, CDF_SKIP_STRIDE, 3, 2) X(CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7) X(CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5) \
+  X(CDF_SKIP, CDF_SKIP_STRIDE, 3, 2) X(CDF_SEG_ID, CDF_SEG_ID_STRIDE, 3, 8) X(CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7) X(CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5) \
   X(CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8) X(CDF_CFL_ALPHA, CDF_CFL_ALPHA_STRIDE, 6, 16) X(CDF_TX_SIZE, CDF_TX_SIZE_STRIDE, 3, 2) X(CDF_TX_SIZE + 3 * CDF_TX_SIZE_STRIDE, CDF_TX_SIZE_STRIDE, 9, 3) \
   X(CDF_TXB_SKIP, CDF_TXB_SKIP_STRIDE, 65, 2) X(CDF_EOB_EXTRA, CDF_EOB_EXTRA_STRIDE, 90, 2) X(CDF_DC_SIGN, CDF_DC_SIGN_STRIDE, 6, 2) \
   X(CDF_COEFF_BR, CDF_COEFF_BR_STRIDE, 210, 4) X(CDF_COEFF_BASE, CDF_COEFF_BASE_STRIDE, 420, 4) X(CDF_COEFF_BASE_EOB, CDF_COEFF_BASE_EOB_STRIDE, 40, 3) \
@@ -185,7 +185,8 @@ inline void put_leb128(std::vector<uint8_t> &o, uint64_t v) { do { uint8_t b = v
 
 struct FrameHeaderInfo {                                       // what the OBU writer needs about one frame
   mi_av1_config cfg; int np; int sb_cols, sb_rows; QuantSel q; Tiling tiles;
-  int lf_level[4], lf_sharp; int enable_cdef, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
+  int lf_level[4], seg_n, seg_qidx[8];                         // one block: what the device reports back per frame (FrameDev::lf_out, 13 ints)
+  int lf_sharp; int enable_cdef, cdef_damping, cdef_bits, cdef_y[8], cdef_uv[8];
   int enable_restoration, tx_mode_select;
 };
 
@@ -228,7 +229,15 @@ inline std::vector<uint8_t> frame_obu_header(const FrameHeaderInfo &h, int tile_
     delta_q(h.q.dc_qi[1] - h.q.base_q_idx); delta_q(h.q.ac_qi[1] - h.q.base_q_idx);
     if (diff) { delta_q(h.q.dc_qi[2] - h.q.base_q_idx); delta_q(h.q.ac_qi[2] - h.q.base_q_idx); }
   }
-  b.put(0, 1); b.put(0, 1);                       // using_qmatrix, segmentation_enabled
+  b.put(0, 1);                                    // using_qmatrix
+  // segmentation_params(): primary_ref_frame = NONE -> update_map = 1, temporal_update = 0, update_data = 1 without bits; one feature, ALT_Q
+  b.put(h.seg_n > 0, 1);
+  if (h.seg_n > 0)
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) {
+      const bool on = j == 0 && i < h.seg_n;
+      b.put(on, 1);
+      if (on) b.put((uint32_t)(h.seg_qidx[i] - h.q.base_q_idx) & 0x1FFu, 9);    // feature_value su(1 + 8)
+    }
   if (h.q.base_q_idx > 0) b.put(0, 1);            // delta_q_present
   b.put(h.lf_level[0], 6); b.put(h.lf_level[1], 6);
   if (h.np > 1 && (h.lf_level[0] || h.lf_level[1])) { b.put(h.lf_level[2], 6); b.put(h.lf_level[3], 6); }

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
     for (int b = wave; b < 64; b += 4) {
       const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
       if (r >= f->mi_rows || c >= f->mi_cols) continue;
-      const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
+      const int sk = f->m_skip[r * ms + c] & f->m_skip[(r + 1) * ms + c] & f->m_skip[r * ms + c + 1] & f->m_skip[(r + 1) * ms + c + 1] & 1;      // bit 0 of the map (the rest is the segment id)
       if (sk) continue;
       int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, part, &var);
       if (lane == 0) { dirvar[b][0] = ydir; dirvar[b][1] = var; }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
   for (int b = wave; b < 64; b += 4) {
     const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
     if (r >= f->mi_rows || c >= f->mi_cols) continue;
-    const int sk = f->m_skip[r * ms + c] && f->m_skip[(r + 1) * ms + c] && f->m_skip[r * ms + c + 1] && f->m_skip[(r + 1) * ms + c + 1];
+    const int sk = f->m_skip[r * ms + c] & f->m_skip[(r + 1) * ms + c] & f->m_skip[r * ms + c + 1] & f->m_skip[(r + 1) * ms + c + 1] & 1;      // bit 0 of the map (the rest is the segment id)
     const int filt = best > 0 && !sk;                    // index 0 of the list is (0, 0): nothing to filter
     const int ydir = filt ? dirvar[b][0] : 0, var = filt ? dirvar[b][1] : 0;
     for (int p = 0; p < f->np; p++) {
@@ -383,6 +383,98 @@ __global__ __launch_bounds__(256) void activity_kernel(const FrameDev *__restric
   const uint32_t v = psy_cell_var(s8, q8, 8, f->bd);
   ((uint32_t *)f->svar8)[cell] = v;
   ((uint32_t *)f->act)[cell] = f->tune_psnr ? 16384u : psy_boost_q14(v, v);
+}
+
+// Segmentation (oracle/av1o_segment.c, rav1e segmentation.rs as recalled): one workgroup per frame, after activity_kernel.  The visible cells'
+// scale buckets go into an LDS histogram; prefix sums turn every k-means step into a handful of lookups, so the six fits (k = 8 .. 3) run on
+// six lanes; lane 0 picks the most evenly spaced one, derives each segment's quantiser index (nearest step to base / sqrt(scale / mean)) and
+// fills the table the tile search and the entropy coder read.  lf_out[4 .. 12] = segment count + indices for the host's frame header.
+__device__ inline int seg_value_at(const uint32_t *cnt, uint32_t idx) {
+  int lo = 0, hi = MI_SEG_BINS - 1;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (cnt[mid + 1] > idx) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+__global__ __launch_bounds__(256) void segment_kernel(FrameDev *frames) {
+  FrameDev *f = frames + blockIdx.x;
+  if (frame_idle(f)) return;
+  __shared__ uint32_t cnt[MI_SEG_BINS + 1];
+  __shared__ unsigned long long wsum[MI_SEG_BINS + 1];
+  __shared__ int lq[256], cent[6][8];
+  __shared__ unsigned long long var[6];
+  const int tid = threadIdx.x;
+  SegTab *st = (SegTab *)f->seg;
+  const int16_t *ac = f->bd == 8 ? av1_ac_q8_dev : av1_ac_q10_dev, *dc = f->bd == 8 ? av1_dc_q8_dev : av1_dc_q10_dev;
+  for (int i = tid; i <= MI_SEG_BINS; i += 256) cnt[i] = 0;
+  lq[tid] = seg_ilog2_q11((uint32_t)ac[tid]);
+  __syncthreads();
+  const int cw = f->pw >> 3, vw = (f->w + 7) >> 3, vh = (f->h + 7) >> 3;
+  for (int i = tid; i < vw * vh; i += 256) { const int cy = i / vw, cx = i - cy * vw; atomicAdd(&cnt[seg_bucket(f->act[cy * cw + cx]) + 1], 1u); }
+  __syncthreads();
+  if (tid == 0) {
+    int bmin = -1, bmax = -1;
+    unsigned long long ws = 0; uint32_t c = 0;
+    wsum[0] = 0;
+    for (int b = 0; b < MI_SEG_BINS; b++) {
+      const uint32_t m = cnt[b + 1];
+      if (m) { if (bmin < 0) bmin = b; bmax = b; }
+      ws += (unsigned long long)b * m; c += m; wsum[b + 1] = ws; cnt[b + 1] = c;
+    }
+    var[0] = (bmin == bmax || c < 2) ? 1 : 0;       // flag: one scale everywhere -> no segmentation
+  }
+  __syncthreads();
+  const bool off = var[0] != 0;
+  __syncthreads();
+  const uint32_t n = cnt[MI_SEG_BINS];
+  if (!off && tid < 6) {
+    const int k = 8 - tid;
+    int c[8];
+    for (int j = 0; j < k; j++) c[j] = seg_value_at(cnt, (uint32_t)(((unsigned long long)j * (n - 1)) / (unsigned long long)(k - 1)));
+    int limit = 0; while ((n >> limit) != 0) limit++;
+    limit *= 2;
+    for (int it = 0; it < limit; it++) {
+      int changed = 0, lo = 0, t[8];
+      for (int j = 0; j + 1 < k; j++) t[j] = (c[j] + c[j + 1] + 1) >> 1;
+      for (int j = 0; j < k; j++) {
+        const int hi = j == k - 1 ? MI_SEG_BINS : imax_(lo, t[j]);
+        const uint32_t m = cnt[hi] - cnt[lo];
+        if (m) { const int nc = (int)((wsum[hi] - wsum[lo] + m / 2) / m); if (nc != c[j]) changed = 1; c[j] = nc; }
+        lo = hi;
+      }
+      if (!changed) break;
+    }
+    long long sum = 0;
+    for (int j = 0; j + 1 < k; j++) sum += c[j + 1] - c[j];
+    const long long mu = sum / (k - 1);
+    unsigned long long v = 0;
+    for (int j = 0; j + 1 < k; j++) { const long long d = (c[j + 1] - c[j]) - mu; v += (unsigned long long)(d * d); }
+    var[tid] = v;
+    for (int j = 0; j < 8; j++) cent[tid][j] = j < k ? c[j] : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int *out = f->lf_out + 4;
+    if (off) {
+      st->n = 0; f->seg_n = 0; out[0] = 0;
+    } else {
+      int bi = 0;
+      for (int i = 1; i < 6; i++) if (var[i] <= var[bi]) bi = i;          // k = 8 .. 3 in lane order: the last minimum = the fewest segments
+      const int k = 8 - bi, mean = (int)((wsum[MI_SEG_BINS] + n / 2) / n), lbase = lq[f->base_q_idx];
+      st->n = k; st->mean = mean; f->seg_n = k; out[0] = k;
+      // plane deltas of the frame's quantiser (the header's DeltaQ*): dc index per plane and chroma ac index relative to base_q_idx
+      for (int i = 0; i < k; i++) {
+        const int target = lbase - (cent[bi][k - 1 - i] - mean) * 4;
+        int qi = 1, bdiff = 1 << 30;
+        for (int q = 1; q < 256; q++) { const int d = iabs_(lq[q] - target); if (d < bdiff) { bdiff = d; qi = q; } }
+        st->qidx[i] = qi; out[1 + i] = qi;
+        for (int p = 0; p < 3; p++) {
+          const int dq = dc[iclamp_(qi + f->seg_ddc[p], 0, 255)], aq = ac[p == 0 ? qi : iclamp_(qi + f->seg_dac[p], 0, 255)];
+          st->q[i].dc_q[p] = dq; st->q[i].ac_q[p] = aq;
+          st->q[i].dc_recip[p] = 0xFFFFFFFFu / (uint32_t)imax_(1, dq); st->q[i].ac_recip[p] = 0xFFFFFFFFu / (uint32_t)imax_(1, aq);
+        }
+      }
+      for (int j = 0; j + 1 < k; j++) st->thr[j] = (cent[bi][j] + cent[bi][j + 1] + 1) >> 1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- K0: front end

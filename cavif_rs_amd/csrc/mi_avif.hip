@@ -148,7 +148,8 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.m_decoded = take(zeroed_bytes(p)); d.lf_tally = (long long *)(d.m_decoded + align_up(nmi, 256));
   d.sb_prog = (int *)(d.m_decoded + align_up(nmi, 256) + align_up(6 * 65 * sizeof(long long), 256));
   d.zero_words = (int)((zeroed_bytes(p) + 3) / 4);
-  d.lf_out = (int *)take(64);
+  d.lf_out = (int *)take(64);                              // 4 deblock levels, segment count, 8 segment indices
+  d.seg = (const SegTab *)take(sizeof(SegTab));
   d.m_angle_y = (int8_t *)take(nmi); d.m_angle_uv = (int8_t *)take(nmi);
   d.cdef_idx = (int8_t *)take((size_t)p.sb_cols * p.sb_rows);
   { const size_t ncell = (size_t)(p.pw / 8) * (p.ph / 8); d.act = (const uint32_t *)take(ncell * 4); d.svar8 = (const uint32_t *)take(ncell * 4); d.svar4 = (const uint32_t *)take(nmi * 4); }
@@ -182,6 +183,8 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   d.mi_cols = p.mi_cols; d.mi_rows = p.mi_rows; d.sb_cols = p.sb_cols; d.sb_rows = p.sb_rows;
   d.pw = p.pw; d.ph = p.ph; d.stride = p.pw; d.mi_stride = p.mi_stride; d.mi_h = p.mi_h;
   d.base_q_idx = p.q.base_q_idx; d.qctx = p.q.qctx; d.rdmult = p.q.rdmult;
+  d.seg_n = 0;
+  for (int i = 0; i < 3; i++) { d.seg_ddc[i] = i < p.np ? p.q.dc_qi[i] - p.q.base_q_idx : 0; d.seg_dac[i] = i < p.np ? p.q.ac_qi[i] - p.q.base_q_idx : 0; }
   for (int i = 0; i < 3; i++) { d.dc_q[i] = p.q.dc_q[i]; d.ac_q[i] = p.q.ac_q[i]; d.wq[i] = p.q.wq[i]; d.dc_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.dc_q[i]); d.ac_recip[i] = 0xFFFFFFFFu / (uint32_t)std::max(1, p.q.ac_q[i]); }
   d.part_min = c.part_min; d.part_max = c.part_max; d.complex_modes = c.complex_pred_modes; d.fine_directional = c.fine_directional_intra;
   d.bottomup = c.encode_bottomup;
@@ -207,6 +210,7 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
   FrameHeaderInfo &h = p.hdr;
   h.cfg = c; h.np = p.np; h.sb_cols = p.sb_cols; h.sb_rows = p.sb_rows; h.q = p.q; h.tiles = p.tiles;
   for (int i = 0; i < 4; i++) h.lf_level[i] = d.lf_level[i];
+  h.seg_n = 0; for (int i = 0; i < 8; i++) h.seg_qidx[i] = p.q.base_q_idx;
   h.lf_sharp = 0; h.enable_cdef = c.cdef; h.cdef_damping = 3; h.cdef_bits = 3; h.enable_restoration = c.lrf; h.tx_mode_select = d.tx_mode_select;
   for (int i = 0; i < 8; i++) { h.cdef_y[i] = strengths[i]; h.cdef_uv[i] = strengths[i]; }
 }
@@ -349,7 +353,7 @@ struct mi_batch {
   uint32_t *d_recbuf = nullptr; uint32_t rec_cap = 0;             // K4's symbol records: three rotating superblock buffers per tile
   uint32_t *d_offsets = nullptr; uint8_t *d_packed = nullptr; size_t packed_cap = 0, packed_max = 0; unsigned long long *d_prof = nullptr;
   int *h_alpha = nullptr; FrameDev *h_frames = nullptr; TileJob *h_jobs = nullptr;   // pinned: alpha flags (D2H), frame descriptors and tile jobs (H2D sources)
-  uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels (4 per frame)
+  uint8_t *h_packed = nullptr; uint32_t *h_lens = nullptr; int *h_lf = nullptr;   // pinned: packed tiles, tile lengths, deblock levels + segment indices (13 per frame)
   std::vector<TileJob> jobs;
   SearchQueue queue;                                               // the tile search's work list and its device objects (allocated on first use)
   std::vector<std::vector<uint8_t>> files; std::vector<size_t> color_sz, alpha_sz;
@@ -425,7 +429,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_packed, b->packed_cap));
   HIP_OK(hipHostMalloc(&b->h_lens, max_tiles * 4));
-  HIP_OK(hipHostMalloc(&b->h_lf, worst.size() * 4 * sizeof(int)));
+  HIP_OK(hipHostMalloc(&b->h_lf, worst.size() * 13 * sizeof(int)));
   HIP_OK(hipHostMalloc(&b->h_alpha, sizeof(int) * b->cap));
   HIP_OK(hipHostMalloc(&b->h_frames, sizeof(FrameDev) * worst.size()));
   HIP_OK(hipHostMalloc(&b->h_jobs, sizeof(TileJob) * max_tiles));
@@ -619,6 +623,7 @@ int mi_batch_encode_async(mi_batch *b) {
       hipLaunchKernelGGL(pass_flip_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, b->d_frames, nframes);
     }
     hipLaunchKernelGGL(activity_kernel, dim3((max_cells + 255) / 256, nframes), dim3(256), 0, s, b->d_frames);
+    hipLaunchKernelGGL(segment_kernel, dim3(nframes), dim3(256), 0, s, b->d_frames);
     HIP_OK(hipEventRecord(b->ev[1], s));
     if (pass == 0) { if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st; }
     else if (int st = search_launch(b->queue, bottomup, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
@@ -633,7 +638,7 @@ int mi_batch_encode_async(mi_batch *b) {
   // ---- tile lengths -> offsets -> pack -> one D2H
   HIP_OK(hipEventRecord(b->ev[5], s));
   for (size_t k = 0; k < b->frames.size(); k++) { FramePlan &p = b->frames[k]; HIP_OK(hipMemcpyAsync(b->h_lens + p.dev.tile_base, p.dev.tile_len, (size_t)p.ntiles * 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(b->h_lf + 4 * k, p.dev.lf_out, 4 * sizeof(int), hipMemcpyDeviceToHost, s)); }
+    HIP_OK(hipMemcpyAsync(b->h_lf + 13 * k, p.dev.lf_out, 13 * sizeof(int), hipMemcpyDeviceToHost, s)); }
   b->in_flight = true;
   return MI_OK;
 }
@@ -672,7 +677,7 @@ int mi_batch_wait(mi_batch *b) {
     if (idle(p)) { p.obu.clear(); continue; }
     std::vector<std::pair<const uint8_t *, size_t>> tl;
     for (int t = 0; t < p.ntiles; t++) { const int j = p.dev.tile_base + t; tl.push_back({ b->h_packed + offsets[j], (size_t)b->h_lens[j] }); }
-    for (int i = 0; i < 4; i++) p.hdr.lf_level[i] = b->h_lf[4 * k + i];
+    for (int i = 0; i < 13; i++) p.hdr.lf_level[i] = b->h_lf[13 * k + i];      // levels, then seg_n and seg_qidx (contiguous in FrameHeaderInfo)
     p.obu = assemble_obus(p.hdr, tl);
   }
   for (int i = 0; i < b->n; i++) {
@@ -1017,6 +1022,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
         hipLaunchKernelGGL(pass_flip_kernel, dim3(1), dim3(64), 0, s, d_frame, 1);
       }
       hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
+      hipLaunchKernelGGL(segment_kernel, dim3(1), dim3(256), 0, s, d_frame);
       if (pass == 0) { if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st; }
       else if (int st = search_launch(g.queue, p.cfg.encode_bottomup != 0, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
       HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
@@ -1026,7 +1032,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipGetLastError());
   std::vector<uint32_t> lens(njobs);
   HIP_OK(hipMemcpyAsync(lens.data(), p.dev.tile_len, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipMemcpyAsync(p.hdr.lf_level, p.dev.lf_out, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(p.hdr.lf_level, p.dev.lf_out, 13 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   std::vector<std::vector<uint8_t>> td(njobs); std::vector<std::pair<const uint8_t *, size_t>> tl;
   for (int j = 0; j < njobs; j++) {

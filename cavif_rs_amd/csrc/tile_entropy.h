@@ -221,7 +221,7 @@ struct TileWriter {                                                 // the produ
   int sb_cols_tile;
   // Frame scalars that steer the walk, pinned to SGPRs once per tile: every control value the walk loads (skip, modes, transform sizes, eob,
   // block sizes, restoration types) goes through v_readfirstlane as well, so that the record counter and the walk's branches stay scalar.
-  int np, mi_rows, mi_cols, ms, tx_mode_select, enable_cdef, cdef_bits, enable_restoration, sb_cols, fw, fh;
+  int np, mi_rows, mi_cols, ms, tx_mode_select, enable_cdef, cdef_bits, enable_restoration, sb_cols, fw, fh, seg_n;
   struct TxCfg { int reduced_tx_set, base_q_idx; } txc;
 #if MI_PROFILE == 2
   unsigned long long prof[16], pt;
@@ -330,6 +330,15 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   K4PH(4); K4CNT(11, eob);
 }
 
+// intra_segment_id (spec 5.11.8 / 5.11.9, no pre-skip feature): after the skip flag; a skipped block's id is the prediction and nothing is coded.
+// Arguments: the m_skip entries (bit 0 = skip, the rest = segment id) of the block and of its above / left / above-left neighbours.
+__device__ __forceinline__ void k4_segment_id(TileWriter *w, int own, int up, int left, int upleft, int availU, int availL) {
+  if (!w->seg_n || (own & 1)) return;
+  int ctx;
+  const int pred = seg_pred(availU && availL ? upleft >> 1 : -1, availU ? up >> 1 : -1, availL ? left >> 1 : -1, &ctx);
+  k4_sym(w, seg_symbol(own >> 1, pred, w->seg_n), CDF_SEG_ID + ctx * CDF_SEG_ID_STRIDE, 8);
+}
+
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
@@ -339,16 +348,18 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
   const int l_skip = f->m_skip[mi], l_ymode = f->m_ymode[mi], l_txs_y = f->m_txsize[mi];
   const int l_skU = f->m_skip[iU], l_skL = f->m_skip[iL], l_ymU = f->m_ymode[iU], l_ymL = f->m_ymode[iL], l_txU = f->m_txsize[iU], l_txL = f->m_txsize[iL];
+  const int l_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];
   const int l_ay = f->m_angle_y[mi], l_cdef = f->cdef_idx[(r >> 4) * w->sb_cols + (c >> 4)];
   int l_uvmode = 0, l_auv = 0, l_js = 0, l_au = 0, l_av = 0;
   if (w->np > 1) { l_uvmode = f->m_uvmode[mi]; l_auv = f->m_angle_uv[mi]; l_js = f->m_cfl_sign[mi]; l_au = f->m_cfl_au[mi]; l_av = f->m_cfl_av[mi]; }
-  const int skip = U_(l_skip), ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
+  const int sk_seg = U_(l_skip), skip = sk_seg & 1, ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);   // m_skip: bit 0 = skip, the rest = segment id
   const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_ay = U_(l_ay), v_cdef = U_(l_cdef);
   const int uvmode = U_(l_uvmode), v_auv = U_(l_auv), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
   {
     const int cdf = 0;                                   // CDF rows are named by their offset in the tables
-    const int sctx = (availU ? v_skU : 0) + (availL ? v_skL : 0);
+    const int sctx = (availU ? v_skU & 1 : 0) + (availL ? v_skL & 1 : 0);
     k4_sym(w, skip, cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
+    k4_segment_id(w, sk_seg, v_skU, v_skL, U_(l_skUL), availU, availL);
     if (!skip && w->enable_cdef) {
       if (w->cdef_pending) { w->cdef_pending = 0; k4_lit(w, (uint32_t)v_cdef, w->cdef_bits); }   // first non-skip block of the superblock (spec 5.11.56)
     }
@@ -419,13 +430,14 @@ template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
   const int l_skip = f->m_skip[mi], l_ymode = f->m_ymode[mi], l_txs_y = f->m_txsize[mi];
   const int l_skU = f->m_skip[iU], l_skL = f->m_skip[iL], l_ymU = f->m_ymode[iU], l_ymL = f->m_ymode[iL], l_txU = f->m_txsize[iU], l_txL = f->m_txsize[iL];
-  const int l_cdef = f->cdef_idx[(r >> 4) * w->sb_cols + (c >> 4)];
+  const int l_cdef = f->cdef_idx[(r >> 4) * w->sb_cols + (c >> 4)], l_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];
   int l_uvmode = 0, l_js = 0, l_au = 0, l_av = 0;
   if (w->np > 1) { l_uvmode = f->m_uvmode[mi]; l_js = f->m_cfl_sign[mi]; l_au = f->m_cfl_au[mi]; l_av = f->m_cfl_av[mi]; }
-  const int skip = U_(l_skip), ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
+  const int sk_seg = U_(l_skip), skip = sk_seg & 1, ymode = U_(l_ymode), txs_y = U_(l_txs_y), v_skU = U_(l_skU), v_skL = U_(l_skL), v_ymU = U_(l_ymU), v_ymL = U_(l_ymL);
   const int v_txU = U_(l_txU), v_txL = U_(l_txL), v_cdef = U_(l_cdef), uvmode = U_(l_uvmode), v_js = U_(l_js), v_au = U_(l_au), v_av = U_(l_av);
   const int cdf = 0;
-  k4_sym(w, skip, cdf + CDF_SKIP + ((availU ? v_skU : 0) + (availL ? v_skL : 0)) * CDF_SKIP_STRIDE, 2);
+  k4_sym(w, skip, cdf + CDF_SKIP + ((availU ? v_skU & 1 : 0) + (availL ? v_skL & 1 : 0)) * CDF_SKIP_STRIDE, 2);
+  k4_segment_id(w, sk_seg, v_skU, v_skL, U_(l_skUL), availU, availL);
   if (!skip && w->enable_cdef && w->cdef_pending) { w->cdef_pending = 0; k4_lit(w, (uint32_t)v_cdef, w->cdef_bits); }
   const int am = intra_mode_ctx(availU ? v_ymU : DC_PRED), lm = intra_mode_ctx(availL ? v_ymL : DC_PRED);
   k4_sym(w, ymode, cdf + CDF_KF_Y + (am * 5 + lm) * CDF_KF_Y_STRIDE, 13);
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
     w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
     w.lr_ref = (LDS int *)L.lr_ref; w.cap = rec_cap; w.out = bufs; w.n = 0;
     w.np = U_(f->np); w.mi_rows = U_(f->mi_rows); w.mi_cols = U_(f->mi_cols); w.ms = U_(f->mi_stride); w.tx_mode_select = U_(f->tx_mode_select);
-    w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
+    w.seg_n = U_(f->seg_n); w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
     w.fw = U_(f->w); w.fh = U_(f->h); w.txc.reduced_tx_set = U_(f->reduced_tx_set); w.txc.base_q_idx = U_(f->base_q_idx);
     load_scans_to_lds((LDS uint16_t *)L.scans, CS);
     w.sb_cols_tile = sbc;

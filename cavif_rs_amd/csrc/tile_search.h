@@ -85,7 +85,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   long long lm_mode_j;   // (the trial's per-sub-block results alias dsd / satd, dead by then)
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
   // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
-  int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact;
+  int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact, seg, seg_nb;
   uint16_t ssrc[N * N], spred[(N / 2) * (N / 2)];
   uint8_t nb_top[16][2], nb_left[16][2];
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
@@ -125,6 +125,21 @@ template <int MAXN, int NW> struct Ctx {
   __device__ __forceinline__ uint8_t *snap() const { return sh()->snap; }
   __device__ __forceinline__ const uint16_t *cost() const { return f()->cost; }
 };
+
+// The block's segment (oracle/av1o_segment.c av1o_block_segment: looked up from its mean activity scale, no RD search over segments).  Called by
+// every lane of one wave with a wave-uniform scale while the block is being staged: the segment's quantiser steps replace the frame's in the
+// workgroup's LDS copy of the descriptor, which is where every evaluation of the block reads them.
+static_assert(offsetof(FrameDev, ac_recip) - offsetof(FrameDev, dc_q) == 36 && sizeof(SegTab::Q) == 48, "a SegTab entry is copied over FrameDev::dc_q .. ac_recip");
+template <typename SHT> __device__ __forceinline__ void seg_select(const LDS FrameDev *f, LDS SHT *SH, int scale) {
+  if (!f->seg_n) return;
+  const SegTab *st = f->seg;
+  const int b = seg_bucket((uint32_t)uni32(scale));
+  int a = 0;
+  for (int j = 0; j + 1 < f->seg_n; j++) a += b >= st->thr[j];
+  const int seg = f->seg_n - 1 - a;
+  if (LANE < 12) ((LDS uint32_t *)((LDS FrameDev *)f)->dc_q)[LANE] = ((const uint32_t *)&st->q[seg])[LANE];
+  if (LANE == 0) SH->seg = seg;
+}
 
 #define IS_SMOOTH_(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
 #define J_INF 0x7fffffffffffffffLL
@@ -294,9 +309,12 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   const int v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL];
   const int v_uvU = f->np > 1 ? f->m_uvmode[iU] : 0, v_uvL = f->np > 1 ? f->m_uvmode[iL] : 0;
   const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
+  const int v_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];                                  // (segment id of the above-left neighbour)
   const int have_ar = can_ar && uni32(v_ar), have_bl = can_bl && uni32(v_bl);
   const int amode = availU ? uni32(v_ymU) : DC_PRED, lmode = availL ? uni32(v_ymL) : DC_PRED;
-  const int nb_skip = (availU ? uni32(v_skU) : 0) + (availL ? uni32(v_skL) : 0);                      // skip context
+  const int nb_skip = (availU ? uni32(v_skU) & 1 : 0) + (availL ? uni32(v_skL) & 1 : 0);              // skip context (bit 0 of the map)
+  // neighbours' segment ids + 1 (0 = outside the tile), packed: needed again when the block's skip flag is known -- parked in LDS, not in registers
+  const int seg_nb = (availU && availL ? (uni32(v_skUL) >> 1) + 1 : 0) | ((availU ? (uni32(v_skU) >> 1) + 1 : 0) << 4) | ((availL ? (uni32(v_skL) >> 1) + 1 : 0) << 8);
   const int nb_txU = availU ? uni32(v_txU) : -1, nb_txL = availL ? uni32(v_txL) : -1;                   // tx-size context (-1: no neighbour)
   const uint16_t *ycost = k.cost() + CDF_KF_Y + (intra_mode_ctx(amode) * 5 + intra_mode_ctx(lmode)) * CDF_KF_Y_STRIDE;
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);                                           // DC_PRED (no neighbour) is not smooth
@@ -323,7 +341,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
     }
     if (BS == 1 && LANE < 4) SH->psv4[LANE] = (int)f->svar4[(r + (LANE >> 1)) * ms + c + (LANE & 1)];
     const int tot = wave_sum_i32(a);
-    if (LANE == 0) SH->cact = (tot + ncell / 2) / ncell;
+    const int cact = (tot + ncell / 2) / ncell;
+    if (LANE == 0) { SH->cact = cact; SH->seg_nb = seg_nb; }
+    seg_select(f, SH, cact);
   }
   PH(1);
   WG_SYNC();
@@ -1065,13 +1085,18 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   if (DBG_IS(f, 6)) return 0;
   // ---- skip flag ----
   const int skip = !any_coef;
+  // intra_segment_id follows the skip flag (no pre-skip feature): a skipped block takes the predicted id, any other codes its own
+  int seg_ctx = 0;
+  const int seg_nb2 = SH->seg_nb, seg_ul = (seg_nb2 & 15) - 1, seg_u = ((seg_nb2 >> 4) & 15) - 1, seg_l = (seg_nb2 >> 8) - 1;
+  const int seg_p = seg_pred(seg_ul, seg_u, seg_l, &seg_ctx), seg_own = f->seg_n ? SH->seg : 0, seg_fin = f->seg_n ? (skip ? seg_p : seg_own) : 0;
   if (W == 0) {
-    fill_map_dev(f->m_skip, ms, r, c, n4, skip);
+    fill_map_dev(f->m_skip, ms, r, c, n4, skip | (seg_fin << 1));
     if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
     fill_map_dev(f->m_decoded, ms, r, c, n4, 1);
   }
   const int sctx = nb_skip;
   total_j += ((long long)k.cost()[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
+  if (f->seg_n && !skip) total_j += ((long long)k.cost()[CDF_SEG_ID + seg_ctx * CDF_SEG_ID_STRIDE + seg_symbol(seg_own, seg_p, f->seg_n)] * f->rdmult + 256) >> 9;
   PH(11);
   WG_SYNC();
   PH(2);

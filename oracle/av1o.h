@@ -64,6 +64,7 @@ typedef struct Av1oResult {
   int tile_cols, tile_rows;
   int64_t total_sse[3];
   int lf_level[4];                         /* deblock levels: luma vertical / horizontal edges, U, V */
+  int seg_n, seg_qidx[8];                  /* segmentation: segments in use (0 = off) and their luma-AC quantiser indices; m_skip carries (segment id << 1) | skip */
 } Av1oResult;
 
 int  av1o_tweaks_from_preset(int speed, int quantizer, Av1oConfig *c);   /* av1encoder.rs:554-606 */

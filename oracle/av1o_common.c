@@ -189,6 +189,7 @@ void av1o_costs_from_cdfs(const uint16_t *cdf, uint32_t *cost) {
   cost_rows(cdf, cost, CDF_PARTITION + 4 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 12, 10);
   cost_rows(cdf, cost, CDF_PARTITION + 16 * CDF_PARTITION_STRIDE, CDF_PARTITION_STRIDE, 4, 8);
   cost_rows(cdf, cost, CDF_SKIP, CDF_SKIP_STRIDE, 3, 2);
+  cost_rows(cdf, cost, CDF_SEG_ID, CDF_SEG_ID_STRIDE, 3, 8);
   cost_rows(cdf, cost, CDF_INTRA_TX1, CDF_INTRA_TX1_STRIDE, 26, 7);
   cost_rows(cdf, cost, CDF_INTRA_TX2, CDF_INTRA_TX2_STRIDE, 39, 5);
   cost_rows(cdf, cost, CDF_CFL_SIGN, CDF_CFL_SIGN_STRIDE, 1, 8);

@@ -176,9 +176,14 @@ static void write_block(TileW *w, int r, int c, int bs) {
   const SymSink k = { ec_sym, ec_lit, w };
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int skip = f->m_skip[mi];
-  /* intra_frame_mode_info: (segmentation off) skip, cdef, (delta q off), y mode, angle, uv mode, cfl, angle uv */
+  /* intra_frame_mode_info: skip, segment id, cdef, (delta q off), y mode, angle, uv mode, cfl, angle uv */
   int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
   re_symbol(&w->ec, skip, w->cdf + CDF_SKIP + sctx * CDF_SKIP_STRIDE, 2);
+  if (f->seg_n && !skip) {                          /* intra_segment_id (SegIdPreSkip = 0): after the skip flag; a skipped block's id is the prediction */
+    int ctx;
+    const int pred = av1o_seg_pred(availU && availL ? f->m_seg[mi - ms - 1] : -1, availU ? f->m_seg[mi - ms] : -1, availL ? f->m_seg[mi - 1] : -1, &ctx);
+    re_symbol(&w->ec, av1o_seg_symbol(f->m_seg[mi], pred, f->seg_n), w->cdf + CDF_SEG_ID + ctx * CDF_SEG_ID_STRIDE, 8);
+  }
   if (!skip && f->enable_cdef) {
     int sbi = (r >> 4) * f->sb_cols + (c >> 4);
     if (!w->cdef_done[sbi]) {                       /* first non-skip block of this 64x64: read_cdef() */

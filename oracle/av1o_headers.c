@@ -71,7 +71,14 @@ static void write_frame_header(const Av1oFrame *f, BitW *b, int tile_size_bytes)
     if (diff) { write_delta_q(b, f->dc_qi[2] - f->base_q_idx); write_delta_q(b, f->ac_qi[2] - f->base_q_idx); }
   }
   bw_put(b, 0, 1);                     /* using_qmatrix */
-  bw_put(b, 0, 1);                     /* segmentation_enabled */
+  /* segmentation_params(): primary_ref_frame = NONE -> update_map = 1, temporal_update = 0, update_data = 1 without bits; the one feature is ALT_Q */
+  bw_put(b, f->seg_n > 0, 1);
+  if (f->seg_n > 0)
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) {
+      const int on = j == 0 && i < f->seg_n;
+      bw_put(b, (uint32_t)on, 1);
+      if (on) bw_su(b, f->seg_qidx[i] - f->base_q_idx, 9);      /* feature_value su(1 + 8) */
+    }
   if (f->base_q_idx > 0) bw_put(b, 0, 1); /* delta_q_present */
   /* loop_filter_params(): CodedLossless == 0 */
   bw_put(b, (uint32_t)f->lf_level[0], 6); bw_put(b, (uint32_t)f->lf_level[1], 6);
@@ -150,7 +157,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   }
   f->m_bsize = (uint8_t *)zalloc(nmi); f->m_skip = (uint8_t *)zalloc(nmi); f->m_ymode = (uint8_t *)zalloc(nmi);
   f->m_uvmode = (uint8_t *)zalloc(nmi); f->m_txtype = (uint8_t *)zalloc(nmi); f->m_cfl_sign = (uint8_t *)zalloc(nmi);
-  f->m_cfl_au = (uint8_t *)zalloc(nmi); f->m_cfl_av = (uint8_t *)zalloc(nmi); f->m_txsize = (uint8_t *)zalloc(nmi);
+  f->m_cfl_au = (uint8_t *)zalloc(nmi); f->m_cfl_av = (uint8_t *)zalloc(nmi); f->m_txsize = (uint8_t *)zalloc(nmi); f->m_seg = (uint8_t *)zalloc(nmi);
   f->tx_mode_select = cfg->rdo_tx || cfg->inter_tx_split;
   f->m_angle_y = (int8_t *)zalloc(nmi); f->m_angle_uv = (int8_t *)zalloc(nmi); f->m_decoded = (uint8_t *)zalloc(nmi);
   f->cdef_idx = (int8_t *)zalloc((size_t)f->sb_cols * f->sb_rows);
@@ -158,6 +165,7 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   av1o_build_costs(f);
   av1o_setup_tiles(f);
   av1o_activity(f);
+  av1o_segmentation(f);
   f->enable_cdef = cfg->cdef; f->enable_restoration = cfg->lrf;
   const int ntiles = f->tile_cols * f->tile_rows;
   uint8_t **td = (uint8_t **)zalloc(sizeof(uint8_t *) * (size_t)ntiles); size_t *tl = (size_t *)zalloc(sizeof(size_t) * (size_t)ntiles);
@@ -203,10 +211,12 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   out->mi_cols = f->mi_cols; out->mi_rows = f->mi_rows; out->mi_stride = f->mi_stride;
   out->m_bsize = f->m_bsize; out->m_ymode = f->m_ymode; out->m_uvmode = f->m_uvmode; out->m_skip = f->m_skip; out->m_txtype = f->m_txtype;
   for (int i = 0; i < 4; i++) out->lf_level[i] = f->lf_level[i];
+  out->seg_n = f->seg_n; for (int i = 0; i < 8; i++) out->seg_qidx[i] = f->seg_qidx[i];
+  if (f->seg_n) for (size_t i = 0; i < nmi; i++) f->m_skip[i] = (uint8_t)(f->m_skip[i] | (f->m_seg[i] << 1));      /* the dump uses the product's packing */
   out->base_q_idx = f->base_q_idx; out->tile_cols = f->tile_cols; out->tile_rows = f->tile_rows;
   for (int p = 0; p < f->np; p++) { free(f->src[p]); free(f->rec[p]); free(f->coef[p]); free(f->m_lvl[p]); free(f->m_dc[p]); free(f->m_eob[p]); }
   for (int p = 0; p < f->np; p++) { free(f->dbk[p]); free(f->lr_type[p]); free(f->lr_set[p]); free(f->lr_xqd[p]); }
-  free(f->m_txsize); free(f->act); free(f->svar8); free(f->svar4);
+  free(f->m_txsize); free(f->m_seg); free(f->act); free(f->svar8); free(f->svar4);
   free(f->m_cfl_sign); free(f->m_cfl_au); free(f->m_cfl_av); free(f->m_angle_y); free(f->m_angle_uv); free(f->m_decoded); free(f->cdef_idx);
   free(f);
   return 0;

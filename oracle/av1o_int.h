@@ -100,6 +100,9 @@ typedef struct Av1oFrame {
   uint32_t lr_cost[3];          /* static cost of the switchable restoration_type symbols */
   /* Tune::Psychovisual: per 8x8 cell activity scale (Q14) and source variance, per 4x4 source variance (8x8-equivalent) */
   uint32_t *act, *svar8, *svar4;
+  /* segmentation (av1o_segment.c): seg_n = 0 -> off; segment i: absolute luma-AC index and the per-plane steps; thresholds in scale buckets */
+  uint8_t *m_seg;               /* segment id per mi (the predicted id where the block is skipped, spec read_segment_id) */
+  int seg_n, seg_mean, seg_thr[7], seg_qidx[8], seg_dcq[8][3], seg_acq[8][3];
   int64_t sse[3];
 } Av1oFrame;
 
@@ -125,6 +128,14 @@ void av1o_activity(Av1oFrame *f);
 int64_t av1o_psy_dist_luma(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int n);
 int64_t av1o_psy_dist_luma_wh(const Av1oFrame *f, const uint16_t *rec, int rs, int x, int y, int bw, int bh);
 uint32_t av1o_act_mean(const Av1oFrame *f, int x, int y, int w, int h);
+/* segmentation */
+#define AV1O_SEG_BINS 4096
+int  av1o_ilog2_q11(uint32_t x);
+int  av1o_seg_bucket(uint32_t scale_q14);
+void av1o_segmentation(Av1oFrame *f);
+int  av1o_block_segment(const Av1oFrame *f, int x, int y, int w, int h);
+int  av1o_seg_pred(int prev_ul, int prev_u, int prev_l, int *ctx);
+int  av1o_seg_symbol(int seg, int pred, int max);
 
 /* prediction (spec 7.11.2) */
 typedef struct { uint16_t above[2 * 64 + 16 + 32], left[2 * 64 + 16 + 32]; } EdgeBuf;  /* index +16 = position 0 */

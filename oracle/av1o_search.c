@@ -15,13 +15,14 @@ static const uint8_t intra_mode_ctx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 
 typedef struct {
   Av1oFrame *f; TileB t;
   int64_t wq[3];           /* plane distortion weights, Q12 */
+  int dcq[3], acq[3];      /* the quantiser steps of the block being evaluated (its segment's) */
 } Search;
 
 typedef struct {            /* saved state of one block area (for NONE-vs-SPLIT comparison) */
   int n;
   uint16_t rec[3][64 * 64];
   int32_t coef[3][64 * 64];
-  uint8_t maps[11][16 * 16];
+  uint8_t maps[12][16 * 16];
   uint8_t lvl[3][16 * 16], dc[3][16 * 16];
   uint16_t eob[3][16 * 16];
 } AreaSnap;
@@ -30,7 +31,7 @@ static uint8_t *map_ptr(Av1oFrame *f, int i) {
   switch (i) {
     case 0: return f->m_bsize; case 1: return f->m_skip; case 2: return f->m_ymode; case 3: return f->m_uvmode;
     case 4: return f->m_txtype; case 5: return f->m_cfl_sign; case 6: return f->m_cfl_au; case 7: return f->m_cfl_av;
-    case 8: return (uint8_t *)f->m_angle_y; case 9: return (uint8_t *)f->m_angle_uv; default: return f->m_txsize;
+    case 8: return (uint8_t *)f->m_angle_y; case 9: return (uint8_t *)f->m_angle_uv; case 10: return f->m_txsize; default: return f->m_seg;
   }
 }
 static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save) {
@@ -49,7 +50,7 @@ static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save)
       else { memcpy(f->m_lvl[p] + o, s->lvl[p] + i * n4, (size_t)n4); memcpy(f->m_dc[p] + o, s->dc[p] + i * n4, (size_t)n4); memcpy(f->m_eob[p] + o, s->eob[p] + i * n4, 2 * (size_t)n4); }
     }
   }
-  for (int m = 0; m < 11; m++) {
+  for (int m = 0; m < 12; m++) {
     uint8_t *mp = map_ptr(f, m);
     for (int i = 0; i < n4; i++) {
       if (save) memcpy(s->maps[m] + i * n4, mp + (r + i) * f->mi_stride + c, (size_t)n4);
@@ -103,13 +104,13 @@ static int64_t eval_tx(Search *s, int plane, int r, int c, int txs, int bs /* bl
   const uint16_t *src = f->src[plane] + y * f->stride + x;
   for (int i = 0; i < nh; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
   av1o_fwd_txfm2d(resid, n, coef, txs, txtype, f->bd);
-  int eob = av1o_quantize(coef, qc_out, txs, txtype, f->dc_q[plane], f->ac_q[plane]);
+  int eob = av1o_quantize(coef, qc_out, txs, txtype, s->dcq[plane], s->acq[plane]);
   int sctx, dctx;
   av1o_txb_ctx(f, &s->t, plane, r, c, txs, bs, &sctx, &dctx);
   tr->rate = av1o_coef_rate_full(f, qc_out, eob, plane, txs, txtype, sctx, dctx, tx_off, tx_sym, tx_ns, &tr->cul, &tr->dcc);
   memcpy(rec_out, pred, sizeof(uint16_t) * (size_t)(n * nh));
   if (eob > 0) {
-    av1o_dequantize(qc_out, dq, txs, f->dc_q[plane], f->ac_q[plane], f->bd, eob, txtype);
+    av1o_dequantize(qc_out, dq, txs, s->dcq[plane], s->acq[plane], f->bd, eob, txtype);
     av1o_inv_txfm2d_add(dq, rec_out, n, txs, txtype, f->bd);
   }
   tr->eob = eob;
@@ -163,6 +164,9 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   static uint16_t pred[64 * 64], rec_best[3][64 * 64], rec_tmp[64 * 64];
   static int32_t qc_best[3][32 * 32], qc_tmp[32 * 32];
   const uint16_t *src = f->src[0] + y * f->stride + x;
+  /* the block's segment (SegmentationLevel::Simple: from its mean activity scale) selects the quantiser of all its planes */
+  const int seg = av1o_block_segment(f, x, y, n, bh);
+  for (int p = 0; p < 3; p++) { s->dcq[p] = f->seg_dcq[seg][p]; s->acq[p] = f->seg_acq[seg][p]; }
 
   /* ---- luma: SATD pre-filter over the 13 modes ---- */
   int64_t satd[13]; int order[13];
@@ -337,6 +341,13 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   if (skip) for (int p = 0; p < f->np; p++) { fill_map2(f->m_lvl[p], ms, r, c, w4, h4, 0); fill_map2(f->m_dc[p], ms, r, c, w4, h4, 0); }
   const int sctx = (availU ? f->m_skip[mi - ms] : 0) + (availL ? f->m_skip[mi - 1] : 0);
   total_j += ((int64_t)f->cost[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult[0] + 256) >> 9;
+  if (f->seg_n) {
+    /* intra_segment_id after the skip flag (no pre-skip feature): a skipped block takes the predicted id, any other codes its own */
+    int ctx;
+    const int pred = av1o_seg_pred(availU && availL ? f->m_seg[mi - ms - 1] : -1, availU ? f->m_seg[mi - ms] : -1, availL ? f->m_seg[mi - 1] : -1, &ctx);
+    fill_map2(f->m_seg, ms, r, c, w4, h4, skip ? pred : seg);
+    if (!skip) total_j += ((int64_t)f->cost[CDF_SEG_ID + ctx * CDF_SEG_ID_STRIDE + av1o_seg_symbol(seg, pred, f->seg_n)] * f->rdmult[0] + 256) >> 9;
+  }
   set_decoded(f, r, c, bs, 1);
   return total_j;
 }

@@ -19,7 +19,7 @@ class Av1oResult(C.Structure):
                 ('m_bsize', C.POINTER(C.c_uint8)), ('m_ymode', C.POINTER(C.c_uint8)), ('m_uvmode', C.POINTER(C.c_uint8)),
                 ('m_skip', C.POINTER(C.c_uint8)), ('m_txtype', C.POINTER(C.c_uint8)),
                 ('base_q_idx', C.c_int), ('tile_cols', C.c_int), ('tile_rows', C.c_int),
-                ('total_sse', C.c_int64 * 3), ('lf_level', C.c_int * 4)]
+                ('total_sse', C.c_int64 * 3), ('lf_level', C.c_int * 4), ('seg_n', C.c_int), ('seg_qidx', C.c_int * 8)]
 
 class RavifEncoder(C.Structure):
     _fields_ = [('quality', C.c_float), ('alpha_quality', C.c_float), ('speed', C.c_int), ('color_model', C.c_int),
@@ -75,7 +75,7 @@ def encode_planes(cfg, planes):
     h, w = planes[0].shape
     out = dict(obu=bytes(bytearray(r.obu[:r.obu_len])),
                recon=[np.ctypeslib.as_array(r.recon[i], shape=(h, w)).copy() for i in range(len(planes))],
-               base_q_idx=r.base_q_idx, tiles=(r.tile_cols, r.tile_rows), sse=[r.total_sse[i] for i in range(len(planes))], lf_level=[r.lf_level[i] for i in range(4)])
+               base_q_idx=r.base_q_idx, tiles=(r.tile_cols, r.tile_rows), sse=[r.total_sse[i] for i in range(len(planes))], lf_level=[r.lf_level[i] for i in range(4)], seg_n=r.seg_n, seg_qidx=[r.seg_qidx[i] for i in range(8)])
     n = r.mi_stride * ((r.mi_rows + 15) // 16 * 16)
     for k in ('m_bsize', 'm_ymode', 'm_uvmode', 'm_skip', 'm_txtype'):
         a = np.ctypeslib.as_array(getattr(r, k), shape=(n,)).copy().reshape(-1, r.mi_stride)

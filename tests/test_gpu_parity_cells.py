@@ -29,6 +29,28 @@ def test_tool_switches_hip_equals_oracle(oracle, over):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('kind', ['textured', 'flat', 'two_regions', 'noise_tiles'])
+def test_segmentation_hip_equals_oracle(oracle, kind):
+    """segment_kernel's fit (histogram, k-means, indices, thresholds), the per-block quantiser switch in K1 and the segment ids K4 codes: the frame
+    header carries the fit, so equal bytes mean equal fits; `flat` is the one-scale frame that leaves segmentation off."""
+    import cavif_rs_amd as m
+    w, h, bd, tiles = 264, 200, 10, 0
+    if kind == 'textured': pl = planes(h, w, seed=7, bd=bd)
+    elif kind == 'flat': pl = [np.full((h, w), v, np.uint16) for v in (300, 512, 700)]
+    elif kind == 'two_regions':
+        rng = np.random.default_rng(3)
+        pl = [np.where(np.arange(w)[None, :] < w // 2, 400, rng.integers(0, 1024, (h, w))).astype(np.uint16) for _ in range(3)]
+    else:
+        rng = np.random.default_rng(4); tiles = 4
+        pl = [(rng.integers(0, 1024, (h, w)) >> rng.integers(0, 6, (h // 8 + 1, w // 8 + 1)).repeat(8, 0).repeat(8, 1)[:h, :w]).astype(np.uint16) for _ in range(3)]
+    r = oracle.encode_planes(oracle.make_config(w, h, bd, False, 100, 4, tiles=tiles), pl)
+    assert (r['seg_n'] == 0) == (kind == 'flat')
+    obu, rec = m.encode_planes(pl, bd, 100, 4, False, tiles=tiles)
+    assert obu == r['obu']
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('depth,full_range,with_alpha', [(8, 0, False), (8, 1, True), (10, 0, True), (10, 1, False)])
 def test_raw_planes_entry_points(oracle, avifdec, depth, full_range, with_alpha):
     """encode_raw_planes_8_bit / _10_bit (av1encoder.rs:366,390) incl. PixelRange::Limited == oracle frames + container."""

@@ -18,6 +18,8 @@ SMALL = {
     'switchable_restore': [[9413, 22581]],
     'use_wiener': [[11570]],
     'use_sgrproj': [[16855]],
+    # Default_Segment_Id_Cdf (spatial prediction contexts 0..2, 8 symbols); found verbatim in libaom's .rodata (tools/extract_av1_tables.py LIB, offset 0x4842f0)
+    'segment_id': [[5622, 7893, 16093, 18233, 27809, 28373, 32533], [14274, 18230, 22557, 24935, 29980, 30851, 32344], [27527, 28487, 28723, 28890, 32397, 32647, 32679]],
 }
 
 def rows_of(name):
@@ -45,6 +47,7 @@ def build(q):
     add('SW_RESTORE', SMALL['switchable_restore'], 3)
     add('USE_WIENER', SMALL['use_wiener'], 2)
     add('USE_SGRPROJ', SMALL['use_sgrproj'], 2)
+    add('SEG_ID', SMALL['segment_id'], 8)
     def qslice(name, per_q):
         r = rows_of(name); n = len(r) // 4
         return r[q * n:(q + 1) * n]
@@ -120,6 +123,8 @@ def emit(path, guard, const_qual):
         f'[{len(allv)}]', f'[4 * CDF_TOTAL]'))
     for k in ('dc_q8', 'ac_q8', 'dc_q10', 'ac_q10'):
         o.append(carr('av1_' + k, 'int16_t', T[k]['rows']))
+        if const_qual:                            # the segment kernel looks the per-segment steps up on the device
+            o.append(carr('av1_' + k + '_dev', 'int16_t', T[k]['rows']).replace('static const', const_qual))
     for n in (4, 8, 16, 32):
         a = carr(f'av1_default_scan_{n}x{n}', 'uint16_t', default_scan(n, n))
         if const_qual:
