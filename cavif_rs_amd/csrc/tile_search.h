@@ -117,6 +117,7 @@ template <int MAXN, int NW> struct Ctx {
   LDS WaveScratch<MAXN> *ws;          // this wave's scratch inside it
   __device__ __forceinline__ LDS SharedScratch<MAXN> *sh() const { return (LDS SharedScratch<MAXN> *)base; }
   __device__ __forceinline__ LDS WaveScratch<MAXN> *s() const { return ws; }
+  __device__ __forceinline__ LDS WaveScratch<MAXN> *wave(int w) const { return (LDS WaveScratch<MAXN> *)(base + SH_BYTES + (size_t)w * WS_BYTES); }
   __device__ __forceinline__ const LDS uint16_t *ls() const { return (const LDS uint16_t *)(base + LS_OFF); }
   __device__ __forceinline__ LDS uint16_t *cc_base() const { return (LDS uint16_t *)(base + CC_OFF); }
   __device__ __forceinline__ CoefCost cc() const { return coef_cost_layout(cc_base(), MAXBS); }
@@ -642,6 +643,126 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
         }
         WG_SYNC();
         PH(22);
+        if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) {
+          // 4x4 / 8x8 sub-blocks: at most eight tx types per sub-block fit two waves (four per wave, one per 16-lane row), so the workgroup runs as
+          // two wave pairs on two sub-blocks at a time wherever the coding order's dependencies allow it.  A sub-block needs its left neighbour,
+          // the row above up to its above-right neighbour and nothing below: the 4 x 4 grid runs as a wavefront skewed by two (slot = bj + 2 bi,
+          // 10 slots for 16 sub-blocks); the 2 x 2 grid can only pair (0,1) with (1,0), which is legal when the prediction reads no above-right
+          // samples (every mode but the directional ones below 90 degrees).  Costs are sums, the pruning rules only ever discard a losing trial,
+          // and every context a sub-block reads was written in an earlier slot: decisions and bytes are those of the raster-order walk.
+          const int P = W >> 1, WP = W & 1;
+          LDS WaveScratch<MAXN> *SL = k.wave(P * 2);           // the pair's first wave owns the pair's edge scratch and prediction
+          LDS uint16_t *ppred = SL->dcp;                        // (dcp is idle during the trial)
+          const bool dirm = best_mode >= V_PRED && best_mode <= D67_PRED;
+          const bool uses_ar = dirm && mode_angle_of(best_mode) + 3 * best_delta < 90;
+          const int nslot = G == 4 ? 10 : (uses_ar ? 4 : 3);
+#pragma unroll 1
+          for (int slot = 0; slot < nslot; slot++) {
+            if (j_split >= budget && luma_j >= budget) { tr_done_(); return true; }   // wave-uniform (see the one-at-a-time loop below)
+            if (!(j_split < luma_j)) break;
+            // the slot's sub-blocks: q0 for pair 0, q1 for pair 1 (-1: none)
+            int q0, q1;
+            if (G == 4) { const int lo = imax_(0, (slot - 2) >> 1), hi = imin_(3, slot >> 1); q0 = lo * 4 + slot - 2 * lo; q1 = lo + 1 <= hi ? (lo + 1) * 4 + slot - 2 * (lo + 1) : -1; }
+            else if (uses_ar) { q0 = slot; q1 = -1; }
+            else { q0 = slot == 0 ? 0 : (slot == 1 ? 1 : 3); q1 = slot == 1 ? 2 : -1; }
+            const int q = P == 0 ? q0 : q1, bi = q / G, bj = q % G;
+            const int sx = x + bj * hn, sy = y + bi * hn;
+            const int sU = availU || bi, sL = availL || bj;
+            if (WP == 0 && q >= 0) {
+              const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
+              const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
+              LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+              const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+              const uint16_t *grec = f->rec[0];
+              const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
+              auto px = [&](int ax, int ay) -> int {
+                const int xr = ax - x, yr = ay - y;
+                if (xr >= 0 && xr < n && yr >= 0 && yr < n) return (int)split_rec[yr * n + xr];
+                if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
+                if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
+                return (int)grec[(size_t)ay * rs + ax];
+              };
+              for (int i = LANE; i <= 2 * hn; i += 64) {
+                const bool corner = i == 2 * hn;
+                int a, l;
+                if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+                if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+                if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+                if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+              }
+              WAVE_SYNC();
+              predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, ppred);
+            }
+            PH(23);
+            WG_SYNC();
+            PH(24);
+            long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0;
+            if (q >= 0 && WP * 4 < sntx) {                       // wave-uniform: this wave has at least one live row
+              int ssc, sdc;
+              {
+                int top = 0, left = 0, dcs = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < half; k2++) {
+                  int l, d;
+                  if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; }
+                  top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+                  if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; }
+                  left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+                }
+                sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+                if (top == 0 && left == 0) ssc = 1;
+                else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+                else if (imax_(top, left) <= 3) ssc = 4;
+                else if (imin_(top, left) <= 3) ssc = 5;
+                else ssc = 6;
+              }
+              constexpr int pcp = n >= 8 ? n / 8 : 1;
+              // five tx types (the reduced set): the four DCT / ADST combinations on the pair's first wave, IDTX alone on its second -- a wave whose
+              // rows mix identity, DCT and ADST walks all three 1-D networks one after the other under exec masks
+              const int g = GROUP_ID, e = sntx == 5 ? (WP == 0 ? g + 1 : (g == 0 ? 0 : 64)) : WP * 4 + g;
+              const int psv_q = hn == 4 ? (n == 8 ? SH->psv4[q] : psv16[q]) : SH->psv[bi * pcp + bj];
+              const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
+              const bool live = e < sntx;
+              int txtype;
+              if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
+              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+              GroupRes gr;
+              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
+                             f->tune_psnr ? -1 : psv_q, pact_q, &gr);
+              long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+              if (!live) j = J_INF;
+#pragma unroll
+              for (int gg = 0; gg < 4; gg++) {
+                const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
+                const int eg = __builtin_amdgcn_readlane(e, gg * 16);
+                if (jg < sj || (jg == sj && eg < se)) {
+                  sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
+                  s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+                }
+              }
+            }
+            if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+            PH(25);
+            WG_SYNC();
+            PH(26);
+            // each pair's winner (lower cost, then lower symbol) keeps its reconstruction and levels in LDS
+            const int w0 = (SH->wbest_j[1] < SH->wbest_j[0] || (SH->wbest_j[1] == SH->wbest_j[0] && SH->wbest_e[1] < SH->wbest_e[0])) ? 1 : 0;
+            const int w1 = (SH->wbest_j[3] < SH->wbest_j[2] || (SH->wbest_j[3] == SH->wbest_j[2] && SH->wbest_e[3] < SH->wbest_e[2])) ? 3 : 2;
+            const long long sub_j0 = SH->wbest_j[w0], sub_j1 = q1 >= 0 ? SH->wbest_j[w1] : 0;
+            if (q >= 0 && W == (P == 0 ? w0 : w1)) {
+              const LDS uint16_t *srec = S->grp[sg].rec; const LDS int32_t *sqc = S->grp[sg].qc;
+              const int ro = bi * hn * n + bj * hn;
+              for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
+              for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
+              if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
+            }
+            WG_SYNC();
+            PH(27);
+            sub_any |= sub_eob[q0] > 0;
+            if (q1 >= 0) sub_any |= sub_eob[q1] > 0;
+            j_split += sub_j0 + sub_j1;
+          }
+        } else
 #pragma unroll 1
         for (int q = 0; q < G * G; q++) {
           // costs only grow: once the split can neither beat the best transform size so far nor stay below the caller's budget
@@ -710,33 +831,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
             }
           }
           long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
-          if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) {
-            // five tx types (the reduced set): the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1 -- a wave whose rows mix
-            // identity, DCT and ADST walks all three 1-D networks one after the other under exec masks
-            const int g = GROUP_ID, e = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 64)) : W * 4 + g;
-            const int psv_q = hn == 4 ? (n == 8 ? SH->psv4[q] : psv16[q]) : SH->psv[bi * pcp + bj];
-            const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
-            if (W * 4 < sntx) {                                  // wave-uniform: this wave has at least one live row
-              const bool live = e < sntx;
-              int txtype;
-              if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
-              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-              GroupRes gr;
-              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, spred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
-                             f->tune_psnr ? -1 : psv_q, pact_q, &gr);
-              long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
-              if (!live) j = J_INF;
-#pragma unroll
-              for (int gg = 0; gg < 4; gg++) {
-                const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
-                const int eg = __builtin_amdgcn_readlane(e, gg * 16);
-                if (jg < sj || (jg == sj && eg < se)) {
-                  sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
-                  s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
-                }
-              }
-            }
-          } else {
+          {
             WG_SYNC();                                           // spsv / spact staged by wave 0
             for (int e = W; e < sntx; e += NW) {
               int txtype;
@@ -757,7 +852,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           const long long sub_j = SH->wbest_j[sw];
           if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
             const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-            if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
             const int ro = bi * hn * n + bj * hn;
             for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
             for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
