@@ -114,7 +114,7 @@ struct FramePlan;
 static size_t zeroed_bytes(const FramePlan &p);
 
 static int lr_units_host(uint32_t size) { const int n = ((int)size + 32) / 64; return n < 1 ? 1 : n; }
-static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + (size_t)p.sb_rows * p.tiles.cols * sizeof(int); }
+static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + ((size_t)p.sb_rows * p.tiles.cols + (size_t)p.sb_rows * p.sb_cols) * sizeof(int); }   // decoded flags, deblock tallies, K1's per-row counters and per-superblock root masks
 static void plan_geometry(FramePlan &p) {
   const mi_av1_config &c = p.cfg;
   p.np = c.chroma == 1 ? 1 : 3;
@@ -319,6 +319,17 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
     const int nitems = (int)q.items.size() - q.q_begin[cls];
     int grid = 0;
     HIP_OK(launch_search(cls, bottomup, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
+    // How many superblocks can be at work at once under whole-superblock dependencies (a tile's wavefront is min(rows, cols / 2) wide): when that
+    // leaves resident workgroups idle the launch synchronises per root block instead (tile_search.h root_wait); a full batch keeps the cheaper
+    // one-acquire-one-release-per-superblock protocol.
+    long runnable = 0;
+    for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
+      const TileJob &tj = jobs[j]; const FramePlan &p = frames[tj.frame];
+      const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
+      const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
+      runnable += std::min(rows, (cols + 1) / 2);
+    }
+    if (cls < 4 && runnable < grid) for (int i = q.q_begin[cls]; i < (int)q.items.size(); i++) q.items[i].job |= 0x80000000u;
     snap_need = std::max(snap_need, (size_t)grid * k1_snap_bytes(cls));
   }
   q.q_begin[5] = (int)q.items.size();

@@ -92,6 +92,7 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t split_rec[N <= 16 ? 1 : N * N];
   TileB tile; uint8_t *snap;                       // the tile's bounds (mi units) and its snapshot area (per-tile constants of Ctx)
   int q_item;                                      // the work item the workgroup has just claimed
+  int fine;                                        // the launch synchronises per root block instead of per superblock (root_wait / root_publish)
 #if MI_PROFILE
   unsigned long long prof[4][32];
 #endif
@@ -1259,6 +1260,46 @@ __device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS Fr
 // `known_j` >= 0: the parent's split trial has just evaluated this block undivided, every earlier sibling kept
 // PARTITION_NONE, and the frame buffers still hold that result -- try_block() would reproduce it bit for bit, so
 // its cost is taken from the trial (oracle/av1o_search.c rd_partition does the same).  Returns 1 when split.
+// ---- fine-grained launches: dependencies per root block ----
+// A launch with fewer runnable superblocks than resident workgroups (single images: the wavefront over a tile's superblocks is short) synchronises
+// at the granularity of the search's root blocks (the largest block size of the class: 16x16 or 32x32) instead of whole superblocks.  A workgroup still
+// claims a superblock and walks its roots in coding order; before a root it waits for exactly the roots that root reads -- left, above, above-left,
+// and above-right / below-left where those precede it in coding order (the only case in which the decoder, and so the search, treats them as
+// available) -- and after it publishes the root's bit in the superblock's word of f->sb_prog's second array.  Every root a workgroup waits for
+// belongs to its own superblock or to one earlier in the work list, so the no-deadlock argument of the list order holds unchanged; the decoded
+// flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
+// superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
+__device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) | (bj & 1) | ((bi & 2) << 2) | ((bj & 2) << 1); }   // Morton index in the superblock
+template <int MAXBS, int MAXN, int NW> __device__ inline void root_wait(const Ctx<MAXN, NW> k, int r, int c) {
+  constexpr int G = 1 << (4 - MAXBS);
+  const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t();
+  if (threadIdx.x == 0) {
+    const int *mask = f->sb_prog + f->sb_rows * f->tile_cols;
+    const int gr = r >> MAXBS, gc = c >> MAXBS, zc = root_z(gr & (G - 1), gc & (G - 1)), sr = r >> 4, sc = c >> 4;
+    auto need = [&](int dr, int dc, bool only_if_earlier) {
+      const int rr = (gr + dr) << MAXBS, cc = (gc + dc) << MAXBS;
+      if (rr < t->mi_row_start || rr >= t->mi_row_end || cc < t->mi_col_start || cc >= t->mi_col_end) return;
+      const int sr2 = rr >> 4, sc2 = cc >> 4, z2 = root_z((gr + dr) & (G - 1), (gc + dc) & (G - 1));
+      if (only_if_earlier && !(sr2 < sr || (sr2 == sr && (sc2 < sc || (sc2 == sc && z2 < zc))))) return;
+      const int *w = mask + sr2 * f->sb_cols + sc2;
+      // (bounded: a protocol error must end in wrong bytes that the parity tests catch, not in a hung device; ~2^25 polls are tens of seconds)
+      for (unsigned spin = 0; !((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25); spin++) __builtin_amdgcn_s_sleep(16);
+    };
+    need(0, -1, false); need(-1, 0, false); need(-1, -1, false); need(-1, 1, true); need(1, -1, true);
+  }
+  WG_SYNC();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <int MAXBS, int MAXN, int NW> __device__ inline void root_publish(const Ctx<MAXN, NW> k, int r, int c) {
+  constexpr int G = 1 << (4 - MAXBS);
+  const LDS FrameDev *f = k.f();
+  WG_SYNC();                                                               // every wave's stores of this root are issued
+  if (threadIdx.x == 0) {
+    int *w = f->sb_prog + f->sb_rows * f->tile_cols + (r >> 4) * f->sb_cols + (c >> 4);
+    __hip_atomic_fetch_or(w, 1 << root_z((r >> MAXBS) & (G - 1), (c >> MAXBS) & (G - 1)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   static __device__ MI_K1_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
@@ -1319,7 +1360,13 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
       int chain = !must_split && !DBG_IS(f, 11);      // the four trial results are in place until a sibling decides to split
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half, chain ? sub_j[q] : -1)) chain = 0;
+      {
+        const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
+        const bool sync_root = BS - 1 == MAXBS && MAXBS < 4 && k.sh()->fine && rr < f->mi_rows && cc < f->mi_cols;
+        if constexpr (BS - 1 == MAXBS && MAXBS < 4) if (sync_root) root_wait<MAXBS>(k, rr, cc);
+        if (RdPart<MAXN, MAXBS, BS - 1, NW>::run(k, rr, cc, chain ? sub_j[q] : -1)) chain = 0;
+        if constexpr (BS - 1 == MAXBS && MAXBS < 4) if (sync_root) root_publish<MAXBS>(k, rr, cc);
+      }
       return 1;
     }
     return 0;
@@ -1367,7 +1414,11 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
       if (!must_split && j_split >= j_none) break;
-      j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, r + (q >> 1) * half, c + (q & 1) * half);
+      const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
+      const bool sync_root = BS - 1 == MAXBS && MAXBS < 4 && k.sh()->fine && rr < f->mi_rows && cc < f->mi_cols;
+      if constexpr (BS - 1 == MAXBS && MAXBS < 4) if (sync_root) root_wait<MAXBS>(k, rr, cc);
+      j_split += RdPartBU<MAXN, MAXBS, BS - 1, NW>::run(k, rr, cc);
+      if constexpr (BS - 1 == MAXBS && MAXBS < 4) if (sync_root) root_publish<MAXBS>(k, rr, cc);
     }
     if constexpr (BS == 1) if (!must_split) {
       uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
@@ -1454,7 +1505,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     const int it = k.sh()->q_item;
     if (it >= nitems) break;
     const SbItem item = items[it];
-    const int job = (int)item.job, sbr = item.sbr, sbc = item.sbc;
+    const int job = (int)(item.job & 0x7fffffffu), sbr = item.sbr, sbc = item.sbc;
+    const bool fine = (item.job >> 31) != 0;                               // per-root synchronisation (the whole launch has the flag or not)
     const TileJob tj = jobs[job];
     const FrameDev *gf = frames + tj.frame;
     if (frame_idle(gf)) continue;
@@ -1472,6 +1524,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     }
     const bool new_tile = job != cur_job;
     cur_job = job;
+    if (threadIdx.x == 0) k.sh()->fine = fine;
     WG_SYNC();
     if (new_tile && gf->tile_cost != nullptr) {                            // second pass of a two-pass encode: the tile's own rate table
       const uint16_t *tc = gf->tile_cost + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * CDF_TOTAL;
@@ -1482,7 +1535,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
     const int ncols = (col1 - col0 + 15) >> 4, nrows = (row1 - row0 + 15) >> 4, r = row0 + 16 * sbr, c = col0 + 16 * sbc;
     int *const prog = gf->sb_prog + (r >> 4) * gf->tile_cols + tj.tile_col;        // this row's counter; the row above: prog - tile_cols
-    if (sbc > 0 || sbr > 0) {
+    if (!fine && (sbc > 0 || sbr > 0)) {
       // Polling with relaxed loads (they bypass the non-coherent cache levels by themselves) and ONE acquire once both conditions hold: an acquire
       // per poll invalidates this XCD's L2 every few hundred cycles for as long as any workgroup waits, under the feet of the ones at work.
       if (threadIdx.x == 0) {
@@ -1500,7 +1553,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     if constexpr (BU) RdPartBU<MAXN, MAXBS, 4, NW>::run(k, r, c); else RdPart<MAXN, MAXBS, 4, NW>::run(k, r, c, -1);
     WG_SYNC();                                                             // every wave's stores of this superblock are issued
     if (threadIdx.x == 0) {
-      __hip_atomic_store(prog, sbc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (!fine) __hip_atomic_store(prog, sbc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (sbr == nrows - 1 && sbc == ncols - 1) tc[1] = wall_clock64();
     }
 #if MI_PROFILE

@@ -72,6 +72,7 @@ template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(
 #define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
 #define __hip_atomic_store(ptr, v, order, scope) __atomic_store_n((ptr), (v), (order))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
+#define __hip_atomic_fetch_or(ptr, v, order, scope) __atomic_fetch_or((ptr), (v), (order))
 // wave ballot from the cross-lane shuffle the emulator has (butterfly OR of the lanes' own bits)
 inline unsigned long long emu_ballot64(bool p) {
   const int l = (int)(threadIdx.x & 63);
