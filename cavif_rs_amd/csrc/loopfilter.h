@@ -229,6 +229,29 @@ __device__ __forceinline__ int cdef_apply_taps(int x, const int *tap, unsigned v
   }
   return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx);
 }
+// The same filter in pieces, for the strength search: the clamp bounds and the secondary taps' sum do not depend on the primary strength, and the
+// fixed strength list repeats its secondary strengths (0, 0, 1, 1, 2, 3, 3, 3), so the search computes bounds once per sample and a secondary sum
+// once per distinct strength.  cdef_apply_taps(x, ...) == cdef_finish(x, cdef_pri_sum(...) + cdef_sec_sum(...), mn, mx).
+__device__ __forceinline__ void cdef_bounds(int x, const int *tap, unsigned valid, int *mn_, int *mx_) {
+  int mx = x, mn = x;
+#pragma unroll
+  for (int n = 0; n < 12; n++) if (valid & (1u << n)) { mx = imax_(mx, tap[n]); mn = imin_(mn, tap[n]); }
+  *mn_ = mn; *mx_ = mx;
+}
+__device__ __forceinline__ int cdef_pri_sum(int x, const int *tap, unsigned valid, int pri, int damping, int cs) {
+  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+  int sum = 0;
+#pragma unroll
+  for (int n = 0; n < 12; n += 3) if (valid & (1u << n)) sum += (n < 6 ? pt0 : pt1) * constrain_dev(tap[n] - x, pri, damping);
+  return sum;
+}
+__device__ __forceinline__ int cdef_sec_sum(int x, const int *tap, unsigned valid, int sec, int damping) {
+  int sum = 0;
+#pragma unroll
+  for (int n = 0; n < 12; n++) if (n % 3 != 0 && (valid & (1u << n))) sum += (n < 6 ? 2 : 1) * constrain_dev(tap[n] - x, sec, damping);
+  return sum;
+}
+__device__ __forceinline__ int cdef_finish(int x, int sum, int mn, int mx) { return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx); }
 // direction search for one 8x8 luma block by its 64 lanes (one pixel each): the 8 x 15 partial sums are
 // accumulated with LDS atomics, lanes 0..7 turn them into the 8 costs (spec 7.15.2)
 #define LDS_ADD(ptr, v) __hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -311,10 +334,13 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
         const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
         int tap[12]; unsigned valid;
         cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid);
+        int mn, mx, ssum = 0, ssec = 0;
+        cdef_bounds(un, tap, valid, &mn, &mx);
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
           int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
-          const int v = (pri == 0 && sec == 0) ? un : cdef_apply_taps(un, tap, valid, pri, sec, damping, cs);
+          if (sec != ssec) { ssec = sec; ssum = cdef_sec_sum(un, tap, valid, sec, damping); }     // wave-uniform: the list repeats its secondary strengths
+          const int v = (pri == 0 && sec == 0) ? un : cdef_finish(un, cdef_pri_sum(un, tap, valid, pri, damping, cs) + ssum, mn, mx);
           const int d = v - sv;
           long long sse = (long long)wave_sum_i32(__mul24(d, d));                // 64 samples * 1023^2 < 2^26
           // Tune::Psychovisual (rav1e rdo_loop_plane_error): luma through the cdef-dist kernel of the 8x8 block, chroma SSE x activity
