@@ -324,9 +324,9 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
       if (sk) continue;
       int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, part, &var);
       if (lane == 0) { dirvar[b][0] = ydir; dirvar[b][1] = var; }
-      long long cst[8];
-#pragma unroll
-      for (int idx = 0; idx < 8; idx++) cst[idx] = 0;
+      // candidate idx's cost lives on lane idx: the wave sums of a candidate are wave-uniform, lane idx keeps them, and the psychovisual pricing
+      // (integer square root and quotient, dev_common.h) runs once for the eight candidates side by side instead of eight times on every lane
+      long long cst = 0;
       const int cell = (r >> 1) * (f->pw >> 3) + (c >> 1);
       const uint32_t cell_sv = f->svar8[cell], cell_act = f->act[cell];
       for (int p = 0; p < f->np; p++) {
@@ -336,24 +336,26 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
         cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid);
         int mn, mx, ssum = 0, ssec = 0;
         cdef_bounds(un, tap, valid, &mn, &mx);
+        const bool psy = p == 0 && !f->tune_psnr;
+        uint32_t my_sse = 0, my_s = 0, my_q = 0;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
           int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
           if (sec != ssec) { ssec = sec; ssum = cdef_sec_sum(un, tap, valid, sec, damping); }     // wave-uniform: the list repeats its secondary strengths
           const int v = (pri == 0 && sec == 0) ? un : cdef_finish(un, cdef_pri_sum(un, tap, valid, pri, damping, cs) + ssum, mn, mx);
           const int d = v - sv;
-          long long sse = (long long)wave_sum_i32(__mul24(d, d));                // 64 samples * 1023^2 < 2^26
-          // Tune::Psychovisual (rav1e rdo_loop_plane_error): luma through the cdef-dist kernel of the 8x8 block, chroma SSE x activity
-          if (p == 0 && !f->tune_psnr) sse = psy_cell_dist((uint32_t)sse, (uint32_t)wave_sum_i32(v), (uint32_t)wave_sum_i32(__mul24(v, v)), cell_sv, cell_act, 8, f->bd);
-          else sse = (long long)(((unsigned long long)sse * cell_act + 8192) >> 14);
-          cst[idx] += (sse * f->wq[p]) >> 5;
+          const uint32_t sse = (uint32_t)wave_sum_i32(__mul24(d, d));             // 64 samples * 1023^2 < 2^26
+          if (lane == idx) my_sse = sse;
+          if (psy) { const uint32_t s1 = (uint32_t)wave_sum_i32(v), s2 = (uint32_t)wave_sum_i32(__mul24(v, v)); if (lane == idx) { my_s = s1; my_q = s2; } }
         }
+        // Tune::Psychovisual (rav1e rdo_loop_plane_error): luma through the cdef-dist kernel of the 8x8 block, chroma SSE x activity
+        long long e;
+        if (psy) e = psy_cell_dist(my_sse, my_s, my_q, cell_sv, cell_act, 8, f->bd);
+        else e = (long long)(((unsigned long long)my_sse * cell_act + 8192) >> 14);
+        cst += (e * f->wq[p]) >> 5;
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int idx = 0; idx < 8; idx++) atomicAdd(&costs[idx], (unsigned long long)cst[idx]);
-        any_blocks = 1;
-      }
+      if (lane < 8) atomicAdd(&costs[lane], (unsigned long long)cst);
+      if (lane == 0) any_blocks = 1;
     }
   }
   __syncthreads();
