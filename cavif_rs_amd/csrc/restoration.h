@@ -141,6 +141,10 @@ template <int R> __device__ inline void lr_box_AB(LrLds &L, const LrChunk &c, in
   }
   __syncthreads();
 }
+// flt[k]: the two filters' outputs of sample k, packed (pass 0 in the low, pass 1 in the high 16 bits: a filtered sample in Q4 is a convex combination of
+// samples << 4, at most 16 368 + rounding for 10-bit input) -- sixteen registers per thread instead of thirty-two across the least-squares solve
+__device__ __forceinline__ int lr_flt0(int v) { return (int)(short)(v & 0xFFFF); }
+__device__ __forceinline__ int lr_flt1(int v) { return v >> 16; }
 __device__ inline void lr_box_F(LrLds &L, const LrChunk &c, int pass, int flt[16]) {
   const int npx = c.w * c.h;
 #pragma unroll
@@ -166,7 +170,7 @@ __device__ inline void lr_box_F(LrLds &L, const LrChunk &c, int pass, int flt[16
       const int cd = L.win[(py + 3) * LR_WP + px + 3];
       out = round2_(a * cd + b, 4 + shift);
     }
-    flt[k] = out;
+    flt[k] = pass == 0 ? (out & 0xFFFF) : ((flt[k] & 0xFFFF) | (int)((uint32_t)out << 16));
   }
   __syncthreads();
 }
@@ -221,7 +225,8 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
   const int set = f->sgr_full ? si : reduced[si & 3];
   int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
   __syncthreads();
-  int flt0[16], flt1[16];
+  int flt[16];
+  for (int k = 0; k < 16; k++) flt[k] = 0;
   long long acc[6];
   int xq0 = 0, xq1 = 0;
   // sweep 0: normal equations; sweep 1: SSE with the solved weights
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
       const LrChunk c = ch[q];
       if (sweep == 0 || nch > 1) {
         lr_load_window(L, f, plane, c);
-        if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt0); }
-        if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt1); }
+        if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt); }
+        if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt); }
       }
       const int npx = c.w * c.h;
 #pragma unroll
@@ -243,10 +248,10 @@ __global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const Fram
           const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
           if (sweep == 0) {
             const int u = cd << 4, e = (sv << 4) - u;
-            const int f0 = r0 ? flt0[k] - u : 0, f1 = r1 ? flt1[k] - u : 0;
+            const int f0 = r0 ? lr_flt0(flt[k]) - u : 0, f1 = r1 ? lr_flt1(flt[k]) - u : 0;
             acc[0] += (long long)(f0 * f0); acc[1] += (long long)(f1 * f1); acc[2] += (long long)(f0 * f1); acc[3] += (long long)(f0 * e); acc[4] += (long long)(f1 * e);
           } else {
-            const int d = lr_project(cd, flt0[k], flt1[k], r0, r1, xq0, xq1, mx) - sv;
+            const int d = lr_project(cd, lr_flt0(flt[k]), lr_flt1(flt[k]), r0, r1, xq0, xq1, mx) - sv;
             acc[5] += (long long)(d * d);
           }
         }
@@ -341,19 +346,20 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *__restrict__ fr
     return;
   }
   int r0, s0, r1, s1; sgr_param(best_set, &r0, &s0, &r1, &s1);
-  int flt0[16], flt1[16];
+  int flt[16];
+  for (int k = 0; k < 16; k++) flt[k] = 0;
   for (int q = 0; q < nch; q++) {
     const LrChunk c = ch[q];
     lr_load_window(L, f, plane, c);
-    if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt0); }
-    if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt1); }
+    if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt); }
+    if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt); }
     const int npx = c.w * c.h;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int idx = threadIdx.x + 256 * k;
       if (idx < npx) {
         const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
-        out[o] = (uint16_t)lr_project(L.win[(py + 3) * LR_WP + px + 3], flt0[k], flt1[k], r0, r1, xq0, xq1, mx);
+        out[o] = (uint16_t)lr_project(L.win[(py + 3) * LR_WP + px + 3], lr_flt0(flt[k]), lr_flt1(flt[k]), r0, r1, xq0, xq1, mx);
       }
     }
     if (nch > 1) __syncthreads();
