@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import cavif_rs_amd as m
 from cavif_rs_amd.synth import synth_image
 gold = json.load(open('tests/golden/fullsize_golden.json'))
-CFG = {'2': ('config 2', 1920, 1080, False, 0, 4, 10, None), '3': ('config 3', 4096, 4096, True, 3, 4, 10, 'config3_4096x4096_rgba_s4_q80'),
+CFG = {'2': ('config 2', 1920, 1080, False, 0, 4, 10, 'config2_1920x1080_rgb_s4_q80'), '3': ('config 3', 4096, 4096, True, 3, 4, 10, 'config3_4096x4096_rgba_s4_q80'),
        '5': ('config 5', 7680, 4320, False, 5, 1, 10, 'config5_7680x4320_rgb_s1_q80')}
 for key in (sys.argv[1:] or ['2', '3']):
     name, w, h, alpha, index, speed, depth, gname = CFG[key]
