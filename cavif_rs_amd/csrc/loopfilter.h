@@ -438,16 +438,22 @@ __global__ __launch_bounds__(256) void segment_kernel(FrameDev *frames) {
   const int cw = f->pw >> 3, vw = (f->w + 7) >> 3, vh = (f->h + 7) >> 3;
   for (int i = tid; i < vw * vh; i += 256) { const int cy = i / vw, cx = i - cy * vw; atomicAdd(&cnt[seg_bucket(f->act[cy * cw + cx]) + 1], 1u); }
   __syncthreads();
-  if (tid == 0) {
-    int bmin = -1, bmax = -1;
-    unsigned long long ws = 0; uint32_t c = 0;
-    wsum[0] = 0;
-    for (int b = 0; b < MI_SEG_BINS; b++) {
-      const uint32_t m = cnt[b + 1];
-      if (m) { if (bmin < 0) bmin = b; bmax = b; }
-      ws += (unsigned long long)b * m; c += m; wsum[b + 1] = ws; cnt[b + 1] = c;
+  // prefix sums over the bins (count and bucket-weighted count): 16 bins per thread, the 256 partial sums scanned by thread 0
+  {
+    __shared__ uint32_t pc[256]; __shared__ unsigned long long pw[256]; __shared__ int pmin[256], pmax[256];
+    uint32_t c = 0; unsigned long long ws = 0; int bmin = -1, bmax = -1;
+    for (int b = tid * 16; b < tid * 16 + 16; b++) { const uint32_t m = cnt[b + 1]; if (m) { if (bmin < 0) bmin = b; bmax = b; } c += m; ws += (unsigned long long)b * m; }
+    pc[tid] = c; pw[tid] = ws; pmin[tid] = bmin; pmax[tid] = bmax;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cc = 0; unsigned long long ww = 0; int lo = -1, hi = -1;
+      for (int i = 0; i < 256; i++) { const uint32_t m = pc[i]; const unsigned long long w = pw[i]; pc[i] = cc; pw[i] = ww; cc += m; ww += w; if (pmin[i] >= 0) { if (lo < 0) lo = pmin[i]; hi = pmax[i]; } }
+      wsum[0] = 0;
+      var[0] = (lo == hi || cc < 2) ? 1 : 0;       // flag: one scale everywhere -> no segmentation
     }
-    var[0] = (bmin == bmax || c < 2) ? 1 : 0;       // flag: one scale everywhere -> no segmentation
+    __syncthreads();
+    c = pc[tid]; ws = pw[tid];
+    for (int b = tid * 16; b < tid * 16 + 16; b++) { const uint32_t m = cnt[b + 1]; ws += (unsigned long long)b * m; c += m; wsum[b + 1] = ws; cnt[b + 1] = c; }
   }
   __syncthreads();
   const bool off = var[0] != 0;
