@@ -1,5 +1,5 @@
 """One-off extended parity sweep on the GPU box: random sizes / depths / speeds / qualities / alpha modes, HIP == oracle bytes.
-Usage: python tools/gpu_random_sweep.py [N] [seed]"""
+Usage: python tools/gpu_random_sweep.py [N] [seed] [max_w max_h]"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import cavif_rs_amd as m
@@ -7,9 +7,10 @@ from tests.helpers import oracle
 from cavif_rs_amd.synth import synth_image
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+MAXW, MAXH = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (420, 300)
 bad = 0
 for i in range(N):
-    w, h = int(rng.integers(8, 420)), int(rng.integers(8, 300))
+    w, h = int(rng.integers(8, MAXW)), int(rng.integers(8, MAXH))
     speed = int(rng.integers(1, 11)); q = float(rng.integers(5, 100)); aq = float(rng.integers(5, 100))
     depth = int(rng.choice([8, 10])); cm = int(rng.integers(0, 2)); am = int(rng.integers(0, 3)); alpha = bool(rng.integers(0, 2))
     threads = int(rng.choice([0, 0, 1, 3])); passes = 2 if rng.integers(0, 5) == 0 else 1
