@@ -64,6 +64,9 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 #define K4_PEDGE(off, has_cols) ((uint32_t)(off) | ((uint32_t)(has_cols) << 16) | 0x20000000u)
 #define K4_LIT(v, nb) (0x80000000u | (uint32_t)(v) | ((uint32_t)(nb) << 20))
 #define K4_BOUNDS(fl6, fh6, nms) (0x40000000u | (uint32_t)(fl6) | ((uint32_t)(fh6) << 10) | ((uint32_t)(nms) << 20))
+// an equiprobable bool as bounds: (fl >> 6, fh >> 6, N - 1 - s) = (256, 0, 0) for a one, (512 = the top, 256, 1) for a zero -- sign bits, the most frequent
+// literals, reach the coder as ordinary records
+#define K4_BIT(b) ((b) ? K4_BOUNDS(256u, 0u, 0u) : K4_BOUNDS(512u, 256u, 1u))
 #ifndef MI_K4_ADAPTERS
 #define MI_K4_ADAPTERS 2
 #endif
@@ -75,6 +78,10 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 // neighbouring transform sizes land on different waves)
 __device__ __forceinline__ int k4_row_owner(uint32_t row) {
   static_assert((MI_K4_ADAPTERS & (MI_K4_ADAPTERS - 1)) == 0, "the low bits of the row offset pick the adapter");
+  // two adapters: the parity of (context index + table block) of the stride-5 tables -- the coefficient base-level rows are 85 % of all adaptive
+  // symbols and four of them (contexts 21 / 22 of the 16x16 luma and chroma blocks) carry 70 %; plain offset parity put 68 % of a 1080p tile's
+  // symbols on one wave, this puts 53 ... 58 % there (measured on the oracle's symbol stream, five images)
+  if (MI_K4_ADAPTERS == 2) return (int)((row / 5u + row / 210u) & 1u);
   return (int)(row & (uint32_t)(MI_K4_ADAPTERS - 1));
 }
 // exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
@@ -144,21 +151,21 @@ __device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, 
     const uint32_t cur = rv;
     if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
     const int m = imin_(64, n - cb);
-    // ONE coding step per iteration and one normalisation site: a literal's bits are steps of their own -- an equiprobable bool is the bounds
-    // (fl >> 6, fh >> 6, 4 * (N - s)) = (256, 0, 0) for a one and (512 = the top, 256, 4) for a zero
-    int j = 0, lit_left = 0; uint32_t lit_val = 0;
-    uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, 0);
-    while (j < m) {
-      uint32_t fl6, fh6, nms4;
-      if (lit_left == 0 && (rec >> 31)) { lit_left = (int)((rec >> 20) & 31u); lit_val = rec & 0xFFFFFu; }
-      bool advance = true;
-      if (lit_left) {
-        lit_left--;
-        const uint32_t bit = (lit_val >> lit_left) & 1u;
-        fl6 = bit ? 256u : 512u; fh6 = bit ? 0u : 256u; nms4 = bit ? 0u : 4u;
-        advance = lit_left == 0;
-      } else { fl6 = rec & 1023u; fh6 = (rec >> 10) & 1023u; nms4 = (rec >> 18) & 60u; }
-      if (advance) { j++; rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, imin_(j, m - 1)); }
+    // The common record carries its bounds: three field extractions and the range arithmetic.  Literals of two and more bits (Golomb tails, eob
+    // offsets, cdef / restoration parameters) are rare and take the inner loop, a step per bit: an equiprobable bool is the bounds (256, 0, 0) for
+    // a one and (512 = the top, 256, 4) for a zero.
+    for (int j = 0; j < m; j++) {
+      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, j);
+      if (rec >> 31) {
+        const uint32_t val = rec & 0xFFFFFu;
+        for (int left = (int)((rec >> 20) & 31u); left > 0; left--) {
+          const uint32_t bit = (val >> (left - 1)) & 1u, r = e->rng, half = (k4_smul(r >> 8, 256u) >> 1);
+          const uint32_t u = bit ? half + 4u : r, v = bit ? 0u : half + 4u;
+          re_normalize_dev(e, e->low + (r - u), u - v);
+        }
+        continue;
+      }
+      const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms4 = (rec >> 18) & 60u;
       const uint32_t r = e->rng, r8 = r >> 8;
       const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
       const uint32_t u = fl6 >= 512u ? r : (k4_smul(r8, fl6) >> 1) + nms4 + 4u;
@@ -230,7 +237,10 @@ struct TileWriter {                                                 // the produ
 // the producer's emitters (wave-uniform arguments; lane 0 stores)
 __device__ __forceinline__ void k4_put(TileWriter *w, uint32_t rec) { if (LANE == 0 && w->n < w->cap) w->out[w->n] = rec; w->n++; }
 __device__ __forceinline__ void k4_sym(TileWriter *w, int s, int off, int ns) { k4_put(w, K4_REC(uni32(off), uni32(s), uni32(ns))); }
-__device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) { const int nb = uni32(nbits); if (nb > 0) k4_put(w, K4_LIT((uint32_t)uni32((int)v), nb)); }
+__device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) {
+  const int nb = uni32(nbits); const uint32_t uv = (uint32_t)uni32((int)v);
+  if (nb == 1) k4_put(w, K4_BIT(uv & 1u)); else if (nb > 1) k4_put(w, K4_LIT(uv, nb));
+}
 #define CDF_LR_SWITCHABLE CDF_TOTAL                                 /* the switchable restoration_type row (3 symbols + counter) sits behind the tables in LDS */
 // K4 phase timers (probe builds, -DMI_PROFILE=2): cycles per phase and event counts, flushed into wave 3's slots of the tile's K1 record
 #ifndef MI_PROFILE
@@ -321,8 +331,8 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
     if (c < eob) { const uint32_t m = w->rec_lv[c]; a = (int)(m >> 1); neg = (int)(m & 1); if (a > 14) len = 32 - __clz(a - 14); cnt = (a ? 1 : 0) + (a > 14 ? (len > 1 ? 2 : 1) : 0); }
     int tot; uint32_t at = nrec + (uint32_t)wave_excl_scan_i32(cnt, &tot);
     if (a && at + (uint32_t)cnt <= cap) {
-      recs[at++] = c == 0 ? K4_REC(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, neg, 2) : K4_LIT(neg, 1);
-      if (a > 14) { if (len > 1) recs[at++] = K4_LIT(0, len - 1); recs[at] = K4_LIT((uint32_t)(a - 14), len); }
+      recs[at++] = c == 0 ? K4_REC(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, neg, 2) : K4_BIT(neg);
+      if (a > 14) { if (len > 1) recs[at++] = len == 2 ? K4_BIT(0) : K4_LIT(0, len - 1); recs[at] = len == 1 ? K4_BIT(1) : K4_LIT((uint32_t)(a - 14), len); }
     }
     nrec += (uint32_t)tot;
   }
