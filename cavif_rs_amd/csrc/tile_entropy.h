@@ -71,9 +71,13 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 #define MI_K4_ADAPTERS 2
 #endif
 #define MI_K4_THREADS (64 * (2 + MI_K4_ADAPTERS))
-// records a superblock can need at most: per coefficient the base level, four base-range symbols, the sign and two Golomb literals; per transform
-// block five header symbols; per block sixteen; the partition nodes and the restoration units
-#define MI_K4_SB_RECORDS(np) ((uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512))
+// records of a typical worst superblock: per coefficient the base level, four base-range symbols, the sign and two more; per transform
+// block five header symbols; per block sixteen; the partition nodes and the restoration units ...
+#define MI_K4_SB_RECORDS(np) ((uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512) > 2u * MI_K4_TXB_RECORDS ? (uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512) : 2u * MI_K4_TXB_RECORDS)
+// ... and what the records between two capacity checks (a block's header + one transform block of at most 1024 coefficients: per coefficient the base
+// level, four base-range symbols, the sign and a Golomb tail of up to 2 * 15 - 1 bit records) can need at most: the producer hands a buffer on early
+// when less than this is left (k4_room), so a buffer holds any superblock's records in as many pieces as it takes
+#define MI_K4_TXB_RECORDS ((uint32_t)(1024 * 36 + 1024))
 // which adapter owns a CDF row: the low bits of its offset (the hot tables have strides 5 and 3: neighbouring contexts and the same context of
 // neighbouring transform sizes land on different waves)
 __device__ __forceinline__ int k4_row_owner(uint32_t row) {
@@ -151,20 +155,10 @@ __device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, 
     const uint32_t cur = rv;
     if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
     const int m = imin_(64, n - cb);
-    // The common record carries its bounds: three field extractions and the range arithmetic.  Literals of two and more bits (Golomb tails, eob
-    // offsets, cdef / restoration parameters) are rare and take the inner loop, a step per bit: an equiprobable bool is the bounds (256, 0, 0) for
-    // a one and (512 = the top, 256, 4) for a zero.
+    // every record carries its bounds (the adapters turned the symbols into them, the producer wrote literal bits as such): three field
+    // extractions and the range arithmetic, one normalisation site
     for (int j = 0; j < m; j++) {
       const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, j);
-      if (rec >> 31) {
-        const uint32_t val = rec & 0xFFFFFu;
-        for (int left = (int)((rec >> 20) & 31u); left > 0; left--) {
-          const uint32_t bit = (val >> (left - 1)) & 1u, r = e->rng, half = (k4_smul(r >> 8, 256u) >> 1);
-          const uint32_t u = bit ? half + 4u : r, v = bit ? 0u : half + 4u;
-          re_normalize_dev(e, e->low + (r - u), u - v);
-        }
-        continue;
-      }
       const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms4 = (rec >> 18) & 60u;
       const uint32_t r = e->rng, r8 = r >> 8;
       const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
@@ -220,7 +214,8 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
 
 struct TileWriter {                                                 // the producer's state
   const FrameDev *f; TileB t;
-  uint32_t *out; uint32_t n, cap;                                   // the superblock's record buffer (HBM), records written so far, its capacity
+  uint32_t *out; uint32_t n, cap;                                   // the current record buffer (HBM), records written so far, its capacity
+  uint32_t *bufs; LDS uint32_t *nrec; LDS int *total; int chunk;    // the three rotating buffers, their published counts, the number of buffers of the tile (-1 while unknown), the current one's index
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
   LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient context rows / levels of the current transform block
   LDS int *lr_ref;                                                  // RefSgrXqd[plane][2]
@@ -237,9 +232,20 @@ struct TileWriter {                                                 // the produ
 // the producer's emitters (wave-uniform arguments; lane 0 stores)
 __device__ __forceinline__ void k4_put(TileWriter *w, uint32_t rec) { if (LANE == 0 && w->n < w->cap) w->out[w->n] = rec; w->n++; }
 __device__ __forceinline__ void k4_sym(TileWriter *w, int s, int off, int ns) { k4_put(w, K4_REC(uni32(off), uni32(s), uni32(ns))); }
-__device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) {
+// The producer hands its buffer to the adapters: publishes the count, meets the other stages at the workgroup barrier (they sit in the kernel's
+// stage loop; a barrier is a barrier wherever the wave executes it) and moves on to the next of the three buffers.  `last`: the tile ends here.
+__device__ __forceinline__ void k4_handoff(TileWriter *w, bool last) {
+  WAVE_SYNC();
+  if (LANE == 0) { w->nrec[w->chunk % 3] = w->n; if (last) *w->total = w->chunk + 1; }
+  __syncthreads();
+  w->chunk++;
+  w->out = w->bufs + (size_t)(w->chunk % 3) * w->cap; w->n = 0;
+}
+// room for a block header + one transform block, or the buffer goes on early (wave-uniform: the record counter is scalar)
+__device__ __forceinline__ void k4_room(TileWriter *w) { if (w->n + MI_K4_TXB_RECORDS > w->cap) k4_handoff(w, false); }
+__device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) {           // equiprobable bools, most significant first: a record per bit
   const int nb = uni32(nbits); const uint32_t uv = (uint32_t)uni32((int)v);
-  if (nb == 1) k4_put(w, K4_BIT(uv & 1u)); else if (nb > 1) k4_put(w, K4_LIT(uv, nb));
+  for (int q = nb - 1; q >= 0; q--) k4_put(w, K4_BIT((uv >> q) & 1u));
 }
 #define CDF_LR_SWITCHABLE CDF_TOTAL                                 /* the switchable restoration_type row (3 symbols + counter) sits behind the tables in LDS */
 // K4 phase timers (probe builds, -DMI_PROFILE=2): cycles per phase and event counts, flushed into wave 3's slots of the tile's K1 record
@@ -273,6 +279,7 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   const bool rect = txs > 4;                              // 5 = 4x8, 6 = 8x4 (dev_rect.h)
   const int bwl = rect ? (txs == 5 ? 2 : 3) : imin_(5, 2 + txs), bhl = rect ? (txs == 5 ? 3 : 2) : bwl, n = 1 << bwl, nh = 1 << bhl;
   const int pt = plane > 0, cls = tx_class_of(txtype), txs_ctx = rect ? 1 : txs;
+  k4_room(w);
   k4_sym(w, eob == 0, CDF_TXB_SKIP + (txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE, 2);
   K4CNT(9, 1); K4CNT(10, eob == 0);
   if (eob == 0) { K4PH(3); return; }
@@ -328,11 +335,14 @@ __device__ __forceinline__ void code_coeffs_lane0(TileWriter *w, int eob_in, int
   for (int cb = 0; cb < eob; cb += 64) {
     const int c = cb + LANE;
     int cnt = 0, a = 0, neg = 0, len = 0;
-    if (c < eob) { const uint32_t m = w->rec_lv[c]; a = (int)(m >> 1); neg = (int)(m & 1); if (a > 14) len = 32 - __clz(a - 14); cnt = (a ? 1 : 0) + (a > 14 ? (len > 1 ? 2 : 1) : 0); }
+    if (c < eob) { const uint32_t m = w->rec_lv[c]; a = (int)(m >> 1); neg = (int)(m & 1); if (a > 14) len = 32 - __clz(a - 14); cnt = (a ? 1 : 0) + (a > 14 ? 2 * len - 1 : 0); }
     int tot; uint32_t at = nrec + (uint32_t)wave_excl_scan_i32(cnt, &tot);
     if (a && at + (uint32_t)cnt <= cap) {
       recs[at++] = c == 0 ? K4_REC(CDF_DC_SIGN + (pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE, neg, 2) : K4_BIT(neg);
-      if (a > 14) { if (len > 1) recs[at++] = len == 2 ? K4_BIT(0) : K4_LIT(0, len - 1); recs[at] = len == 1 ? K4_BIT(1) : K4_LIT((uint32_t)(a - 14), len); }
+      if (a > 14) {                                          // Golomb tail: len - 1 zeros, then the len bits of a - 14, a record per bit
+        for (int q = 0; q < len - 1; q++) recs[at++] = K4_BIT(0);
+        for (int q = len - 1; q >= 0; q--) recs[at++] = K4_BIT(((uint32_t)(a - 14) >> q) & 1u);
+      }
     }
     nrec += (uint32_t)tot;
   }
@@ -350,6 +360,7 @@ __device__ __forceinline__ void k4_segment_id(TileWriter *w, int own, int up, in
 }
 
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
+  k4_room(w);
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   // The block's mode info and its neighbours' in ONE batch of unconditional loads (a neighbour outside the tile reads the block's
@@ -435,6 +446,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
 // 4x4 halves per luma block, one 2:1 transform per chroma plane.
 template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *w, int r, int c) {
   constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL;
+  k4_room(w);
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
@@ -600,7 +612,8 @@ template <int CS> struct EntropyLds {
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
   int lr_ref[6];
-  uint32_t nrec[3];                        // records in the three rotating superblock buffers
+  uint32_t nrec[3];                        // records in the three rotating buffers
+  int total;                               // buffers of the tile: -1 until the producer has handed on its last one
 };
 
 // recbuf: per tile job three record buffers of rec_cap entries (producer -> adapters -> coder, rotating per superblock)
@@ -647,31 +660,43 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
     w.pt = clock64();
 #endif
   } else if (wave == NA + 1) re_init_dev(&ec, precarry + (size_t)job * pre_cap, pre_cap);
+  if (threadIdx.x == 0) L.total = -1;
   __syncthreads();
   int overflow = 0;
-  for (int t = 0; t < nsb + 2; t++) {
+  // Stage loop.  Step t: the producer fills buffer t, the adapters work on buffer t - 1, the coder on buffer t - 2; a barrier per step hands them on.
+  // A buffer is one superblock's records, or a piece of it when the superblock needs more than a buffer holds (k4_room): the producer meets the
+  // barrier from inside its walk then, the other stages from here -- they run until two steps after the tile's last buffer.
+  if (wave == 0) {
+    w.bufs = bufs; w.nrec = (LDS uint32_t *)L.nrec; w.total = (LDS int *)&L.total; w.chunk = 0;
+    for (int sb = 0; sb < nsb; sb++) {
 #if MI_PROFILE == 2
-    const unsigned long long t0_ = clock64();
+      const unsigned long long t0_ = clock64(); w.pt = t0_;
 #endif
-    if (wave == 0) {
-      if (t < nsb) {
-        w.out = bufs + (size_t)(t % 3) * rec_cap; w.n = 0;
+      write_superblock<MAXBS>(&w, row0 + 16 * (sb / sbc), col0 + 16 * (sb % sbc));
 #if MI_PROFILE == 2
-        w.pt = clock64();
+      busy += clock64() - t0_;
 #endif
-        write_superblock<MAXBS>(&w, row0 + 16 * (t / sbc), col0 + 16 * (t % sbc));
-        WAVE_SYNC();
-        if (LANE == 0) L.nrec[t % 3] = w.n;
-      }
-    } else if (wave <= NA) {
-      if (t >= 1 && t <= nsb) k4_adapt_sb((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
-    } else {
-      if (t >= 2) { const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1; k4_code_sb(&ec, bufs + (size_t)((t - 2) % 3) * rec_cap, (int)imin_((int)n, (int)rec_cap)); }
+      k4_handoff(&w, sb == nsb - 1);
     }
+    __syncthreads(); __syncthreads();                         // the last buffer's two further steps
+  } else {
+    for (int t = 0;; t++) {
 #if MI_PROFILE == 2
-    busy += clock64() - t0_;
+      const unsigned long long t0_ = clock64();
 #endif
-    __syncthreads();                                            // the stages hand their superblocks on (workgroup scope: one CU, one L1)
+      const int total = L.total;                              // (any value read while the producer is still writing it gives the same decisions below)
+      if (wave <= NA) {
+        if (t >= 1 && (total < 0 || t - 1 < total)) k4_adapt_sb((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
+      } else {
+        if (t >= 2 && (total < 0 || t - 2 < total)) { const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1; k4_code_sb(&ec, bufs + (size_t)((t - 2) % 3) * rec_cap, (int)imin_((int)n, (int)rec_cap)); }   // (k4_room keeps n below the capacity: a guard, not a path)
+      }
+#if MI_PROFILE == 2
+      busy += clock64() - t0_;
+#endif
+      __syncthreads();
+      const int total2 = L.total;
+      if (total2 >= 0 && t >= total2 + 1) break;
+    }
   }
   if (wave == 0 && f->cdf_out != nullptr)                       // two-pass pricing: what this tile's CDFs have adapted to (every adapter is past the last barrier)
     for (int i = LANE; i < CDF_TOTAL; i += 64) f->cdf_out[(size_t)tile * CDF_TOTAL + i] = L.cdf[i];

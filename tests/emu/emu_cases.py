@@ -26,6 +26,7 @@ PLANE_CASES = {
 ok_all = True
 if which == 'quick':
     PLANE_CASES = [c + (1,) for c in PLANE_CASES] + [(136, 136, 8, 4, 121, False, 4, 2), (72, 40, 10, 1, 121, False, 2, 2)]      # + two-pass pricing (rdo_passes = 2)
+    NOISE_CASES = [(64, 64, 10, 4, 1)]            # near-lossless noise: a superblock's records exceed a buffer, the entropy stage's producer hands on mid-superblock
 else:
     PLANE_CASES = [c + (1,) for c in PLANE_CASES]
 for (w, h, bd, speed, q, mono, tiles, passes) in PLANE_CASES:
@@ -37,6 +38,16 @@ for (w, h, bd, speed, q, mono, tiles, passes) in PLANE_CASES:
     ok_all &= ok
     print(json.dumps({'case': 'planes %dx%d bd%d s%d q%d mono%d tiles%d passes%d' % (w, h, bd, speed, q, int(mono), tiles, passes), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
 
+if which == 'quick':
+    for (w, h, bd, speed, q) in NOISE_CASES:
+        rng = np.random.default_rng(q)
+        pl = [rng.integers(0, 1 << bd, (h, w)).astype(np.uint16) for _ in range(3)]
+        r = oracle.encode_planes(oracle.make_config(w, h, bd, False, q, speed), pl)
+        t = time.time()
+        obu, rec = m.encode_planes(pl, bd, q, speed, False)
+        ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
+        ok_all &= ok
+        print(json.dumps({'case': 'noise %dx%d bd%d s%d q%d' % (w, h, bd, speed, q), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
 if which == 'rect':
     sys.exit(0 if ok_all else 1)
 if which == 'batch':                               # batch API: several images, colour + alpha frames, bottom-up order (work lists spanning frames and block-size classes)

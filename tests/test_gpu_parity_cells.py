@@ -51,6 +51,22 @@ def test_segmentation_hip_equals_oracle(oracle, kind):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('bd,q', [(10, 1), (8, 3), (10, 20)])
+def test_entropy_record_buffers_hand_on_mid_superblock(oracle, bd, q):
+    """Pure noise at near-lossless quantisers: every coefficient carries a long Golomb tail (a record per bit), a superblock needs several times
+    the records one buffer holds, and K4's producer hands its buffer on from inside the superblock walk (tile_entropy.h k4_room / k4_handoff)."""
+    import cavif_rs_amd as m
+    w, h = 136, 72
+    rng = np.random.default_rng(bd * 100 + q)
+    pl = [rng.integers(0, 1 << bd, (h, w)).astype(np.uint16) for _ in range(3)]
+    r = oracle.encode_planes(oracle.make_config(w, h, bd, False, q, 4), pl)
+    assert len(r['obu']) > w * h * 3 * bd // 8 // 2          # (it really is near-lossless noise: more than half the raw size)
+    obu, rec = m.encode_planes(pl, bd, q, 4, False)
+    assert obu == r['obu']
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('depth,full_range,with_alpha', [(8, 0, False), (8, 1, True), (10, 0, True), (10, 1, False)])
 def test_raw_planes_entry_points(oracle, avifdec, depth, full_range, with_alpha):
     """encode_raw_planes_8_bit / _10_bit (av1encoder.rs:366,390) incl. PixelRange::Limited == oracle frames + container."""
