@@ -20,4 +20,5 @@ blocks, txb, empty, coefs = p[:, 8].sum(), p[:, 9].sum(), p[:, 10].sum(), p[:, 1
 print('per tile: blocks %.0f, transform blocks %.0f (empty %.0f), coefficients up to eob %.0f' % (blocks / len(p), txb / len(p), empty / len(p), coefs / len(p)))
 print('cycles per block header %.0f, per transform block staged %.0f, P per coded block %.0f, S per coefficient %.1f, signs per coefficient %.1f' % (
     p[:, 1].sum() / blocks, p[:, 2].sum() / txb, p[:, 3].sum() / max(1, txb - empty), p[:, 4].sum() / coefs, p[:, 5].sum() / coefs))
-print('stage busy cycles per tile (mean / max): ' + '  '.join('w%d %.3g / %.3g' % (i, stage[:, i].mean(), stage[:, i].max()) for i in range(8) if stage[:, i].max() > 0))
+names = ['producer', 'adapter 0', 'adapter 1', 'coder']            # MI_K4_ADAPTERS = 2: four waves per tile (slots 4..7 of the record belong to other probes)
+print('stage busy cycles per tile (mean / max): ' + '  '.join('%s %.3g / %.3g' % (names[i], stage[:, i].mean(), stage[:, i].max()) for i in range(4)))
