@@ -115,7 +115,7 @@ __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, in
       const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)rv, j);
       const int r = (int)(rec & 0xFFFFu);
       uint32_t out;
-      if (rec & 0x20000000u) {                              // partition node at the frame edge: P(the partitions that split this way), not adapted
+      if (__builtin_expect((rec & 0x20000000u) != 0u, 0)) {  // partition node at the frame edge (rare: kept off the straight path): P(the partitions that split this way), not adapted
         const int cv = cdf[r + imin_(i, 10)];
         uint32_t psum = 0;
         const uint32_t set = (rec & 0x10000u) ? 0x2DCu : 0x17Au;              // has_cols: partitions 2, 3, 4, 6, 7, 9; else 1, 3, 4, 5, 6, 8
