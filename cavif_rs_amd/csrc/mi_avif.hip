@@ -256,8 +256,15 @@ static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_fram
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
 static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const TileJob *d_jobs, int njobs, uint16_t *d_precarry, uint32_t pre_cap, uint32_t *d_recbuf, uint32_t rec_cap, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  if (maxbs <= 2) hipLaunchKernelGGL((tile_entropy_kernel<2>), dim3(njobs), dim3(MI_K4_THREADS), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
-  else hipLaunchKernelGGL((tile_entropy_kernel<4>), dim3(njobs), dim3(MI_K4_THREADS), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+  // a launch that leaves wave slots free (fewer than 512 tiles: 6 waves each still fit the device in one round) runs four adapter waves per tile
+  const bool sparse = njobs < 512;
+  if (maxbs <= 2) {
+    if (sparse) hipLaunchKernelGGL((tile_entropy_kernel<2, MI_K4_ADAPTERS_SPARSE>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS_SPARSE)), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+    else hipLaunchKernelGGL((tile_entropy_kernel<2, MI_K4_ADAPTERS>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS)), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+  } else {
+    if (sparse) hipLaunchKernelGGL((tile_entropy_kernel<4, MI_K4_ADAPTERS_SPARSE>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS_SPARSE)), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+    else hipLaunchKernelGGL((tile_entropy_kernel<4, MI_K4_ADAPTERS>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS)), sizeof(EntropyLds<32>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+  }
   return hipGetLastError();
 }
 

@@ -67,10 +67,11 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 // an equiprobable bool as bounds: (fl >> 6, fh >> 6, N - 1 - s) = (256, 0, 0) for a one, (512 = the top, 256, 1) for a zero -- sign bits, the most frequent
 // literals, reach the coder as ordinary records
 #define K4_BIT(b) ((b) ? K4_BOUNDS(256u, 0u, 0u) : K4_BOUNDS(512u, 256u, 1u))
-#ifndef MI_K4_ADAPTERS
+// adapter waves per tile: two when the launch fills the device (1024 tiles x 4 waves = every SIMD's four wave slots at K4's register count; four
+// adapters were measured slower there: a second round of workgroups), four when it does not (single images: the adapters are the busiest stage)
 #define MI_K4_ADAPTERS 2
-#endif
-#define MI_K4_THREADS (64 * (2 + MI_K4_ADAPTERS))
+#define MI_K4_ADAPTERS_SPARSE 4
+#define MI_K4_THREADS_OF(NA) (64 * (2 + (NA)))
 // records of a typical worst superblock: per coefficient the base level, four base-range symbols, the sign and two more; per transform
 // block five header symbols; per block sixteen; the partition nodes and the restoration units ...
 #define MI_K4_SB_RECORDS(np) ((uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512) > 2u * MI_K4_TXB_RECORDS ? (uint32_t)(4096 * 8 * (np) + 256 * 5 * (np) + 256 * 16 + 512) : 2u * MI_K4_TXB_RECORDS)
@@ -80,13 +81,12 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 #define MI_K4_TXB_RECORDS ((uint32_t)(1024 * 36 + 1024))
 // which adapter owns a CDF row: the low bits of its offset (the hot tables have strides 5 and 3: neighbouring contexts and the same context of
 // neighbouring transform sizes land on different waves)
-__device__ __forceinline__ int k4_row_owner(uint32_t row) {
-  static_assert((MI_K4_ADAPTERS & (MI_K4_ADAPTERS - 1)) == 0, "the low bits of the row offset pick the adapter");
-  // two adapters: the parity of (context index + table block) of the stride-5 tables -- the coefficient base-level rows are 85 % of all adaptive
-  // symbols and four of them (contexts 21 / 22 of the 16x16 luma and chroma blocks) carry 70 %; plain offset parity put 68 % of a 1080p tile's
-  // symbols on one wave, this puts 53 ... 58 % there (measured on the oracle's symbol stream, five images)
-  if (MI_K4_ADAPTERS == 2) return (int)((row / 5u + row / 210u) & 1u);
-  return (int)(row & (uint32_t)(MI_K4_ADAPTERS - 1));
+template <int NA> __device__ __forceinline__ int k4_row_owner(uint32_t row) {
+  static_assert(NA == 2 || NA == 4, "two or four adapters");
+  // the parity (or the low two bits) of (context index + table block) of the stride-5 tables -- the coefficient base-level rows are 85 % of all
+  // adaptive symbols and four of them (contexts 21 / 22 of the 16x16 luma and chroma blocks) carry 70 %; plain offset parity put 68 % of a 1080p
+  // tile's symbols on one of two waves, this puts 53 ... 58 % there, and 35 ... 43 % on the busiest of four (measured on the oracle's symbol stream)
+  return (int)((row / 5u + row / 210u) & (uint32_t)(NA - 1));
 }
 // exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
 __device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
@@ -102,12 +102,12 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int *total) {
 __device__ __forceinline__ unsigned long long k4_ballot(bool p) { return MI_BALLOT64(p); }
 // Adapter `a` over one superblock's records: only its own rows' records are visited (ballot of the chunk, lowest set bit first).  The row sits in a
 // register (lane i = entry i, lane nsyms = the adaptation counter) and stays there while consecutive records name it.
-__device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, int n_in, int a) {
+template <int NA> __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, int n_in, int a) {
   const int n = uni32(n_in), i = LANE;
   int row = -1, v = 0;
   for (int cb = 0; cb < n; cb += 64) {
     const uint32_t rv = cb + i < n ? buf[cb + i] : 0x80000000u;
-    const bool mine = (rv >> 30) == 0u && k4_row_owner(rv & 0xFFFFu) == a;
+    const bool mine = (rv >> 30) == 0u && k4_row_owner<NA>(rv & 0xFFFFu) == a;
     unsigned long long todo = k4_ballot(mine);
     uint32_t outv = rv;
     while (todo) {
@@ -617,10 +617,10 @@ template <int CS> struct EntropyLds {
 };
 
 // recbuf: per tile job three record buffers of rec_cap entries (producer -> adapters -> coder, rotating per superblock)
-template <int MAXBS>
-__global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap,
+template <int MAXBS, int NA>
+__global__ __launch_bounds__(MI_K4_THREADS_OF(NA)) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap,
                                                                    uint32_t *recbuf, uint32_t rec_cap) {
-  constexpr int CS = MAXBS <= 2 ? 16 : 32, NA = MI_K4_ADAPTERS;
+  constexpr int CS = MAXBS <= 2 ? 16 : 32, MI_K4_THREADS = MI_K4_THREADS_OF(NA);
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch
   EntropyLds<CS> &L = *(EntropyLds<CS> *)k4_smem;
   const int job = blockIdx.x;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(MI_K4_THREADS) void tile_entropy_kernel(const Frame
 #endif
       const int total = L.total;                              // (any value read while the producer is still writing it gives the same decisions below)
       if (wave <= NA) {
-        if (t >= 1 && (total < 0 || t - 1 < total)) k4_adapt_sb((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
+        if (t >= 1 && (total < 0 || t - 1 < total)) k4_adapt_sb<NA>((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
       } else {
         if (t >= 2 && (total < 0 || t - 2 < total)) { const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1; k4_code_sb(&ec, bufs + (size_t)((t - 2) % 3) * rec_cap, (int)imin_((int)n, (int)rec_cap)); }   // (k4_room keeps n below the capacity: a guard, not a path)
       }
