@@ -223,7 +223,7 @@ static void write_block(TileW *w, int r, int c, int bs) {
   /* residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not) */
   static int32_t qc[1024];
   for (int p = 0; p < f->np; p++) {
-    const int txs = p == 0 ? txs_y : bs, n = imin(32, 1 << dim_wl(txs)), nh = imin(32, 1 << dim_hl(txs));
+    const int txs = p == 0 ? txs_y : (bs == BS_64 ? TX_32X32 : bs) /* chroma transforms stop at 32x32 (spec get_tx_size) */, n = imin(32, 1 << dim_wl(txs)), nh = imin(32, 1 << dim_hl(txs));
     const int stepw = 1 << (dim_wl(txs) - 2), steph = 1 << (dim_hl(txs) - 2), nbw = 1 << (dim_wl(bs) - dim_wl(txs)), nbh = 1 << (dim_hl(bs) - dim_hl(txs));
     for (int by = 0; by < nbh; by++) for (int bx = 0; bx < nbw; bx++) {
       const int rr = r + by * steph, cc = c + bx * stepw, tmi = rr * ms + cc;

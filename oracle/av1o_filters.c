@@ -9,7 +9,8 @@
 /* transform size at a 4x4 position: luma from the block's tx size, chroma (4:4:4) always the block's largest transform */
 /* transform extent across the edge direction: width for vertical edges (pass 0), height for horizontal ones; chroma transforms = the block */
 static int tx_px(const Av1oFrame *f, int plane, int pass, int r, int c) {
-  const int code = plane == 0 ? f->m_txsize[r * f->mi_stride + c] : f->m_bsize[r * f->mi_stride + c];
+  int code = plane == 0 ? f->m_txsize[r * f->mi_stride + c] : f->m_bsize[r * f->mi_stride + c];
+  if (plane && code == BS_64) code = TX_32X32;                 /* the chroma transforms of a 64x64 block are 32x32 (spec get_tx_size) */
   return 1 << (pass == 0 ? dim_wl(code) : dim_hl(code));
 }
 

@@ -135,9 +135,6 @@ int av1o_encode(const Av1oConfig *cfg, const uint16_t *const planes[3], const in
   if (!cfg || cfg->width < 1 || cfg->height < 1 || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return 4;
   Av1oFrame *f = (Av1oFrame *)zalloc(sizeof(Av1oFrame));
   f->cfg = *cfg;
-  /* 64x64 blocks of a 4:4:4 frame carry four 32x32 chroma transform blocks (spec get_tx_size); the
-     single-tx-block-per-plane search does not model that yet, so colour frames stop at 32x32. */
-  if (!cfg->mono && f->cfg.part_max > 32) f->cfg.part_max = 32;
   if (f->cfg.part_min > f->cfg.part_max) f->cfg.part_min = f->cfg.part_max;
   f->w = cfg->width; f->h = cfg->height; f->bd = cfg->bit_depth; f->np = cfg->mono ? 1 : 3;
   f->mi_cols = 2 * ((f->w + 7) >> 3); f->mi_rows = 2 * ((f->h + 7) >> 3);

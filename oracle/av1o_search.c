@@ -58,6 +58,22 @@ static void area_copy(Av1oFrame *f, AreaSnap *s, int r, int c, int bs, int save)
     }
   }
 }
+/* the two chroma planes of a 64x64 block: reconstruction, levels and the contexts its four transform blocks per plane leave behind */
+typedef struct { uint16_t rec[2][64 * 64]; int32_t coef[2][64 * 64]; uint8_t lvl[2][256], dc[2][256]; uint16_t eob[2][256]; } ChromaSnap64;
+static void chroma_copy64(Av1oFrame *f, ChromaSnap64 *s, int r, int c, int save) {
+  for (int p = 1; p < 3; p++) {
+    for (int i = 0; i < 64; i++) {
+      uint16_t *fr = f->rec[p] + (r * 4 + i) * f->stride + c * 4; int32_t *fc = f->coef[p] + (r * 4 + i) * f->stride + c * 4;
+      if (save) { memcpy(s->rec[p - 1] + i * 64, fr, 128); memcpy(s->coef[p - 1] + i * 64, fc, 256); }
+      else { memcpy(fr, s->rec[p - 1] + i * 64, 128); memcpy(fc, s->coef[p - 1] + i * 64, 256); }
+    }
+    for (int i = 0; i < 16; i++) {
+      const int o = (r + i) * f->mi_stride + c;
+      if (save) { memcpy(s->lvl[p - 1] + i * 16, f->m_lvl[p] + o, 16); memcpy(s->dc[p - 1] + i * 16, f->m_dc[p] + o, 16); memcpy(s->eob[p - 1] + i * 16, f->m_eob[p] + o, 32); }
+      else { memcpy(f->m_lvl[p] + o, s->lvl[p - 1] + i * 16, 16); memcpy(f->m_dc[p] + o, s->dc[p - 1] + i * 16, 16); memcpy(f->m_eob[p] + o, s->eob[p - 1] + i * 16, 32); }
+    }
+  }
+}
 static void set_decoded(Av1oFrame *f, int r, int c, int bs, int v) {
   const int w4 = 1 << (dim_wl(bs) - 2), h4 = 1 << (dim_hl(bs) - 2);
   for (int i = 0; i < h4; i++) memset(f->m_decoded + (r + i) * f->mi_stride + c, v, (size_t)w4);
@@ -288,6 +304,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
     int64_t best_uv = INT64_MAX; int buv = DC_PRED, bdelta = 0, bsign = 0, bau = 0, bav = 0; TxRes btr[3];
     static uint16_t rec_c[3][64 * 64]; static int32_t qc_c[3][32 * 32];
+    static ChromaSnap64 uv_snap64; int uv_any64 = 0, uv_in_frame = 0;
     for (int ci = 0; ci < nc; ci++) {
       const int um = cands[ci];
       int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && big) ? best_delta : 0;
@@ -312,6 +329,35 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         }
       }
       if (!ok) continue;
+      if (bs == BS_64) {
+        /* a 64x64 block of a 4:4:4 frame carries four 32x32 chroma transform blocks per plane (spec get_tx_size: chroma transforms stop at
+         * 32x32), each predicted from the reconstruction of the ones before it (spec transform_block) in raster order, plane after plane
+         * (spec residual).  The candidate in progress lives in the frame; the best one so far waits in a snapshot of the two chroma planes. */
+        int c_any = 0;
+        for (int p = 1; p < 3; p++) {
+          for (int k = 0; k < 4; k++) {
+            const int rr = r + (k >> 1) * 8, cc = c + (k & 1) * 8;
+            if (rr >= f->mi_rows || cc >= f->mi_cols) continue;           /* (a 64x64 block never straddles the frame edge: must_split) */
+            const int sU = availU || (k >> 1), sL = availL || (k & 1);
+            const int s_ar = sU && (cc + 8 < t->mi_col_end) && f->m_decoded[(rr - 1) * ms + cc + 8];
+            const int s_bl = sL && (rr + 8 < t->mi_row_end) && f->m_decoded[(rr + 8) * ms + cc - 1];
+            av1o_predict_intra(f, t, p, cc * 4, rr * 4, 5, sL, sU, s_ar, s_bl, um, delta, ftype_uv, pred, 32);
+            TxRes tr;
+            j += eval_tx(s, p, rr, cc, TX_32X32, bs, pred, DCT_DCT, -1, 0, 0, rec_tmp, qc_tmp, &tr);
+            commit_plane(f, p, rr, cc, TX_32X32, rec_tmp, qc_tmp, &tr);
+            set_decoded(f, rr, cc, BS_32, 1);
+            c_any |= tr.eob > 0;
+          }
+          set_decoded(f, r, c, bs, 0);
+        }
+        j += ((int64_t)mode_rate * f->rdmult[0] + 256) >> 9;
+        if (j < best_uv) {
+          best_uv = j; buv = um; bdelta = delta; uv_any64 = c_any;
+          if (ci + 1 < nc) chroma_copy64(f, &uv_snap64, r, c, 1);
+          uv_in_frame = 1;
+        } else uv_in_frame = 0;
+        continue;
+      }
       for (int p = 1; p < 3; p++) {
         if (um == UV_CFL_PRED) {
           av1o_predict_intra_wh(f, t, p, x, y, wl, hl, availL, availU, have_ar, have_bl, DC_PRED, 0, ftype_uv, pred, n);
@@ -327,7 +373,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         for (int p = 1; p < 3; p++) { memcpy(rec_c[p], rec_best[p], 2 * (size_t)(n * bh)); memcpy(qc_c[p], qc_best[p], 4 * (size_t)imin(n * bh, 1024)); }
       }
     }
-    for (int p = 1; p < 3; p++) { commit_plane(f, p, r, c, bs, rec_c[p], qc_c[p], &btr[p]); any_coef |= btr[p].eob > 0; }
+    if (bs == BS_64) { if (!uv_in_frame) chroma_copy64(f, &uv_snap64, r, c, 0); any_coef |= uv_any64; }
+    else for (int p = 1; p < 3; p++) { commit_plane(f, p, r, c, bs, rec_c[p], qc_c[p], &btr[p]); any_coef |= btr[p].eob > 0; }
     fill_map2(f->m_uvmode, ms, r, c, w4, h4, buv);
     fill_map2((uint8_t *)f->m_angle_uv, ms, r, c, w4, h4, (uint8_t)(int8_t)bdelta);
     fill_map2(f->m_cfl_sign, ms, r, c, w4, h4, bsign);
