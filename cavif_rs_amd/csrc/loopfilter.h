@@ -76,7 +76,7 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
   const int ms = f->mi_stride;
   const uint8_t *txm = plane == 0 ? f->m_txsize : f->m_bsize;     // luma: the block's transform size; chroma (4:4:4): the block's largest transform
   // 2:1 transform codes (5 = 4x8, 6 = 8x4): the extent across the edge direction -- width for vertical edges, height for horizontal ones
-  auto ext = [&](int code) { return code <= 4 ? 4 << code : (((code == 5) == (pass == 0)) ? 4 : 8); };
+  auto ext = [&](int code) { return code <= 4 ? ((plane && code == 4) ? 32 : 4 << code) : (((code == 5) == (pass == 0)) ? 4 : 8); };   // (the chroma transforms of a 64x64 block are 32x32)
   const int cur = imin_(64, ext(txm[r * ms + c]));
   if (pass == 0 ? (x % cur) != 0 : (y % cur) != 0) return 0;
   const int prev = pass == 0 ? imin_(64, ext(txm[r * ms + c - 1])) : imin_(64, ext(txm[(r - 1) * ms + c]));

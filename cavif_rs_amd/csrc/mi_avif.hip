@@ -122,10 +122,9 @@ static void plan_geometry(FramePlan &p) {
   p.sb_cols = (p.mi_cols + 15) >> 4; p.sb_rows = (p.mi_rows + 15) >> 4;
   p.pw = p.sb_cols * 64; p.ph = p.sb_rows * 64; p.mi_stride = p.pw / 4; p.mi_h = p.ph / 4;
   int part_max = c.part_max, part_min = c.part_min;
-  if (p.np > 1 && part_max > 32) part_max = 32;       // 64x64 colour blocks need 4 chroma tx blocks: not modelled yet
   if (part_min > part_max) part_min = part_max;
   p.cfg.part_max = (uint8_t)part_max; p.cfg.part_min = (uint8_t)part_min;
-  p.maxbs = part_max <= 16 ? 2 : (part_max <= 32 ? 3 : 4);
+  p.maxbs = part_max <= 16 ? 2 : 4;                   // the search's two block-size classes (tile_search.h k1_maxn): up to 16x16, up to 64x64
   p.q = select_quantizers(c.quantizer, c.bit_depth, p.np);
   p.tiles = plan_tiles((int)c.width, (int)c.height, p.sb_cols, p.sb_rows, c.min_tile_size, c.threads, c.tiles_override);
   p.ntiles = p.tiles.cols * p.tiles.rows;
@@ -238,19 +237,17 @@ template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const Fr
   hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
   return hipGetLastError();
 }
-static size_t k1_snap_bytes(int maxbs) { return maxbs <= 2 ? MI_SNAP_BYTES_ALL(16) : (maxbs == 3 ? MI_SNAP_BYTES_ALL(32) : MI_SNAP_BYTES_ALL(64)); }
+static size_t k1_snap_bytes(int maxbs) { return MI_K1_POOL_BYTES(maxbs); }
 // every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch; the
 // jobs must all belong to frames of the same block-size class (one instantiation per class).  grid_out != nullptr: only report the grid.
 static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   if (nitems <= 0) { if (grid_out) *grid_out = 0; return hipSuccess; }
   if (bottomup) {
     if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-    if (maxbs == 3) return launch_search_t<3, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-    return launch_search_t<4, 1, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+    return launch_search_t<4, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
   }
   if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-  if (maxbs == 3) return launch_search_t<3, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-  return launch_search_t<4, 1, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);     // 64x64 blocks: alpha (4:0:0) frames only
+  return launch_search_t<4, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
 }
 // jobs must all belong to frames of the same block-size class
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)

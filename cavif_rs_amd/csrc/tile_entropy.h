@@ -412,7 +412,7 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   if (skip) return;                                    // wave-uniform
   // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
   for (int p = 0; p < w->np; p++) {
-    const int txs = p == 0 ? txs_y : BS, l2n = imin_(5, 2 + txs), n = 1 << l2n, step = 1 << txs, nblk = 1 << (BS - txs);
+    const int txs = p == 0 ? txs_y : (BS == BS_64 ? 3 : BS) /* chroma transforms stop at 32x32 (spec get_tx_size) */, l2n = imin_(5, 2 + txs), n = 1 << l2n, step = 1 << txs, nblk = 1 << (BS - txs);
     for (int bi = 0; bi < nblk * nblk; bi++) {
       const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step, tmi = rr * ms + cc;
       if (rr >= w->mi_rows || cc >= w->mi_cols) continue;

@@ -54,22 +54,33 @@
 #define MI_SNAP_BYTES_SQ(n) (2 * MI_SNAP_BYTES(n))            /* sum over the levels < 4/3 of the largest */
 #define MI_SNAP_BYTES_ALL(n) (MI_SNAP_BYTES_SQ(n) + 2 * MI_SNAP_BYTES(8))   /* + the 8x8 node's best rectangular / split candidates */
 
+// The 32x32 class also evaluates 64x64 blocks (dev_blk64.h): their candidates run one per wavefront too, on a leaner working set laid over the
+// wave's scratch -- the 64x64 prediction (reconstructed in place), the 32 rows of the column pass that the row pass keeps, the 32x32 coded area.
+struct Blk64Wave { uint16_t pred[64 * 64]; int32_t tbuf[32 * 65]; int32_t cbuf[32 * 32]; int32_t qc[32 * 32]; };
+struct Blk64None { uint8_t none_; };
+struct Blk64Shared { uint16_t src64[64 * 64], bnd[1024]; uint8_t cnb_top[2][16][2], cnb_left[2][16][2]; };
 template <int N> struct WaveScratch {            // private to one wavefront
-  static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N;
-  uint16_t wa[EDGE_LEN(N)], wl[EDGE_LEN(N)], etmp[2 * N + 16];
-  uint16_t pred[N * N], dcp[N * N];
-  union {                                          // one candidate at a time (all sizes) or four at a time (4x4 / 8x8, dev_group.h)
+  static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N, E = N == 32 ? 64 : N;   // E: the largest block whose edges the wave prepares
+  uint16_t wa[EDGE_LEN(E)], wl[EDGE_LEN(E)], etmp[2 * E + 16];
+  union {
     struct {
-      uint16_t rec[2][N * N];
-      int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];  // cbuf doubles as the dequantised block
+      uint16_t pred[N * N], dcp[N * N];
+      union {                                          // one candidate at a time (all sizes) or four at a time (4x4 / 8x8, dev_group.h)
+        struct {
+          uint16_t rec[2][N * N];
+          int32_t tbuf[N * (N + 1)], cbuf[CS * CS], qc[2][CS * CS];  // cbuf doubles as the dequantised block
+        };
+        GroupBuf8 grp[4];
+        GroupPredBuf gpred[4];                         // four directional predictions at a time (SATD stages of 4x4 / 8x8 blocks)
+      };
     };
-    GroupBuf8 grp[4];
-    GroupPredBuf gpred[4];                         // four directional predictions at a time (SATD stages of 4x4 / 8x8 blocks)
+    typename std::conditional<N == 32, Blk64Wave, Blk64None>::type b64;
   };
   uint8_t lev[LEV_BYTES(CS)];                     // one padded level map per coded size (dev_rate.h LEV_OFF)
 };
 template <int N> struct SharedScratch {          // shared by the waves of the tile
-  uint16_t ra[3][EDGE_LEN(N)], rl[3][EDGE_LEN(N)];
+  static constexpr int E = N == 32 ? 64 : N, NC = E >= 16 ? (E / 8) * (E / 8) : 1, SNC = E >= 32 ? (E / 16) * (E / 16) : 1;   // E: the class's largest block; its 8x8 cells; a sub-block's
+  uint16_t ra[3][EDGE_LEN(E)], rl[3][EDGE_LEN(E)];
   uint16_t srcb[3][N * N];
   uint16_t luma_rec[N * N];
   long long satd[13], dsd[7][6];
@@ -85,11 +96,14 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   long long lm_mode_j;   // (the trial's per-sub-block results alias dsd / satd, dead by then)
   // Tune::Psychovisual references of the block being evaluated: source variance + activity scale per 8x8 cell (a 4x4 block:
   // its own variance), the four 4x4 variances of an 8x8 block, and the block's mean activity for chroma
-  int psv[N >= 16 ? (N / 8) * (N / 8) : 1], pact[N >= 16 ? (N / 8) * (N / 8) : 1], psv4[4], spsv[N >= 32 ? (N / 16) * (N / 16) : 1], spact[N >= 32 ? (N / 16) * (N / 16) : 1], cact, seg, seg_nb;
-  uint16_t ssrc[N * N], spred[(N / 2) * (N / 2)];
+  int psv[NC], pact[NC], psv4[4], spsv[SNC], spact[SNC], cact, seg, seg_nb;
+  uint16_t ssrc[N * N], spred[(E / 2) * (E / 2)];
   uint8_t nb_top[16][2], nb_left[16][2];
   int32_t split_qc[N <= 16 ? 1 : (N >= 64 ? 4096 : N * N)];
   uint16_t split_rec[N <= 16 ? 1 : N * N];
+  // the 64x64 level of the 32x32 class (dev_blk64.h): the luma source, the chroma planes' outer neighbour contexts, and the bottom rows / right columns
+  // of the sub-blocks done so far (the transform blocks of a 64x64 block are predicted one from the other; their reconstructions wait in HBM)
+  typename std::conditional<N == 32, Blk64Shared, Blk64None>::type x64;
   TileB tile; uint8_t *snap;                       // the tile's bounds (mi units) and its snapshot area (per-tile constants of Ctx)
   int q_item;                                      // the work item the workgroup has just claimed
   int fine;                                        // the launch synchronises per root block instead of per superblock (root_wait / root_publish)
@@ -110,7 +124,7 @@ template <int N> __device__ __forceinline__ LDS unsigned long long &mi_prof_slot
 // struct on the kernel's stack passed by reference: every use inside the non-inlined block search was a flat load from scratch,
 // ~40 per call, each holding both wait counters.)
 template <int MAXN, int NW> struct Ctx {
-  static constexpr int MAXBS = MAXN == 16 ? 2 : (MAXN == 32 ? 3 : 4);
+  static constexpr int MAXBS = MAXN == 16 ? 2 : 4;     // the largest transform whose rate slices the class needs: the 32x32 class evaluates 64x64 blocks too (dev_blk64.h)
   static constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
   static constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
   static constexpr size_t LS_OFF = SH_BYTES + NW * WS_BYTES, CC_OFF = LS_OFF + SC_BYTES, F_OFF = CC_OFF + CC_BYTES;
@@ -1198,6 +1212,12 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   return total_j;
 }
 
+#include "dev_blk64.h"
+// the evaluation of one block: the generic search, or -- for the 64x64 level of the 32x32 class -- its cooperative form
+template <int MAXN, int BS, int NW> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+  if constexpr (MAXN == 32 && BS == 4) return try_block64<NW>(k, r, c, budget); else return try_block<MAXN, BS, NW>(k, r, c, budget);
+}
+
 // ---- area snapshot (NONE-vs-SPLIT comparison), kept in the workgroup's HBM scratch; whole workgroup ----
 // Wave p copies plane p (reconstruction + levels, four samples per lane: 8- and 16-byte accesses), the last wave the 17 mode-info byte maps (one
 // row of the area per lane, the map's pointer picked out of the LDS frame descriptor) and the eob maps.  m_decoded is not part of a snapshot.
@@ -1310,14 +1330,14 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
     const int can_split = px > f->part_min || must_split;
     if (known_j < 0 || must_split) set_decoded_wg<NW>(f, r, c, n4, 0);
     if (!can_split || (DBG_IS(f, 9) && BS == 1)) {
-      if constexpr (BS <= MAXBS) { if (known_j < 0) try_block<MAXN, BS, NW>(k, r, c); else set_decoded_wg<NW>(f, r, c, n4, 1); }
+      if constexpr (BS <= MAXBS) { if (known_j < 0) blk_eval<MAXN, BS, NW>(k, r, c); else set_decoded_wg<NW>(f, r, c, n4, 1); }
       return 0;
     }
     int do_split = must_split;
     long long sub_j[4] = { -1, -1, -1, -1 };
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        const long long j_blk = known_j >= 0 ? known_j : uni64(try_block<MAXN, BS, NW>(k, r, c));
+        const long long j_blk = known_j >= 0 ? known_j : uni64(blk_eval<MAXN, BS, NW>(k, r, c));
         const long long j_none = uni64(j_blk + (((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9));
         area_copy_dev<BS, NW>(f, k.snap(), r, c, 1);
         set_decoded_wg<NW>(f, r, c, n4, 0);
@@ -1327,13 +1347,13 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           if (!(j_split < j_none) || DBG_IS(f, 7)) break;
           const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
-          sub_j[q] = uni64(try_block<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split));
+          sub_j[q] = uni64(blk_eval<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split));
           j_split += sub_j[q];
           if (BS - 1 >= BS_8) j_split += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9);
         }
         if constexpr (BS == 1) {
           // PARTITION_HORZ / PARTITION_VERT (two 8x4 / 4x8 blocks) against the best of NONE / SPLIT so far (oracle rd_partition)
-          uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
+          uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(4 << MAXBS), *split_snap = best_snap + MI_SNAP_BYTES(8);
           long long j_best = j_none; int have_split = 0, rect_won = 0;
           if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
           {
@@ -1378,7 +1398,7 @@ template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     if (known_j >= 0) { set_decoded_wg<NW>(f, r, c, 1, 1); return 0; }
     set_decoded_wg<NW>(f, r, c, 1, 0);
-    try_block<MAXN, 0, NW>(k, r, c);
+    blk_eval<MAXN, 0, NW>(k, r, c);
     return 0;
   }
 };
@@ -1403,7 +1423,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
     long long j_none = J_INF;
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
-        j_none = uni64(try_block<MAXN, BS, NW>(k, r, c));
+        j_none = uni64(blk_eval<MAXN, BS, NW>(k, r, c));
         j_none += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9);
         if (!can_split) return j_none;
         area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 1);
@@ -1421,7 +1441,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       if constexpr (BS - 1 == MAXBS && MAXBS < 4) if (sync_root) root_publish<MAXBS>(k, rr, cc);
     }
     if constexpr (BS == 1) if (!must_split) {
-      uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(MAXN), *split_snap = best_snap + MI_SNAP_BYTES(8);
+      uint8_t *best_snap = k.snap() + MI_SNAP_BYTES_SQ(4 << MAXBS), *split_snap = best_snap + MI_SNAP_BYTES(8);
       long long j_best = j_none; int have_split = 0, rect_won = 0;
       if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
       {
@@ -1449,16 +1469,23 @@ template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     set_decoded_wg<NW>(f, r, c, 1, 0);
-    return uni64(try_block<MAXN, 0, NW>(k, r, c));
+    return uni64(blk_eval<MAXN, 0, NW>(k, r, c));
   }
 };
 
+// The two block-size classes of the search: MAXBS = 2 -- blocks up to 16x16 (MAXN = 16: every speed from 3 on, and the high-quality end of speeds 1 and 2) --
+// and MAXBS = 4 -- blocks up to 64x64: the generic one-candidate-per-wavefront search up to 32x32 (MAXN = 32) plus the 64x64 level of dev_blk64.h.
+constexpr int k1_maxn(int maxbs) { return maxbs <= 2 ? 16 : 32; }
+#define MI_K1_POOL_BYTES(maxbs) ((maxbs) <= 2 ? (size_t)MI_SNAP_BYTES_ALL(16) : (size_t)MI_SNAP_BYTES_ALL(64) + MI_BLK64_HBM_BYTES)   /* HBM scratch per persistent workgroup */
 template <int MAXBS, int NW> constexpr size_t k1_lds_bytes() {
-  return ((sizeof(SharedScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<(4 << MAXBS)>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(4 << MAXBS) * 2 +
+  constexpr int MAXN = k1_maxn(MAXBS);
+  return ((sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15) + NW * ((sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15) + SCAN_LDS_ENTRIES(MAXN) * 2 +
          ((COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15) + (size_t)FRAMEDEV_K1_BYTES;
 }
 
 static_assert(MI_PROFILE || k1_lds_bytes<2, 4>() <= 40960, "K1 <2,4> must fit four workgroups per CU (160 KB LDS)");
+static_assert(MI_PROFILE || k1_lds_bytes<4, 4>() <= 163840, "K1 <4,4> must fit the CU's 160 KB of LDS");
+static_assert(sizeof(Blk64Wave) <= offsetof(WaveScratch<32>, lev) - offsetof(WaveScratch<32>, pred), "the 64x64 candidate's working set lies over the wave's block scratch, not over its level maps");
 
 // ---- the launch: a work queue of superblocks ----
 // Persistent workgroups (as many as fit the GPU, or one per item when there are fewer) claim superblocks from one list per launch.  An item is
@@ -1475,7 +1502,7 @@ struct SbItem { uint32_t job; uint16_t sbr, sbc; };
 template <int MAXBS, int NW, bool BU>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
                                                                                                           const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
-  constexpr int MAXN = 4 << MAXBS;
+  constexpr int MAXN = k1_maxn(MAXBS);
   extern __shared__ __align__(16) uint8_t smem[];
   using K = Ctx<MAXN, NW>;
   K k;
@@ -1486,7 +1513,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
   // the scan tables once per workgroup; the frame descriptor head and the coefficient slices of the rate table whenever the frame changes
   if (WAVE_ID == 0) load_scans_to_lds(lsc, MAXN);
   for (int i = LANE; i < (int)sizeof(k.s()->lev); i += 64) k.s()->lev[i] = 0;        // level-map padding stays zero for the workgroup's life
-  if (threadIdx.x == 0) k.sh()->snap = snap_pool + (size_t)blockIdx.x * MI_SNAP_BYTES_ALL(MAXN);
+  if (threadIdx.x == 0) k.sh()->snap = snap_pool + (size_t)blockIdx.x * MI_K1_POOL_BYTES(MAXBS);
 #if MI_PROFILE
   if (threadIdx.x < 128) ((LDS unsigned long long *)k.sh()->prof)[threadIdx.x] = 0;
   const FrameDev *prof_f = nullptr;

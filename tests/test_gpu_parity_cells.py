@@ -29,6 +29,36 @@ def test_tool_switches_hip_equals_oracle(oracle, over):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('w,h,bd,q,mono,smooth,over', [
+    (256, 192, 10, 121, False, True, {}),                        # smooth picture: 64x64 colour blocks win (bottom-up walker, what speed 1 uses)
+    (200, 136, 8, 121, False, True, {}),
+    (192, 128, 10, 90, False, True, dict(encode_bottomup=0)),    # the top-down walker with the 64x64 level
+    (136, 200, 8, 100, False, True, {}),
+    (200, 120, 10, 121, False, False, {}),                       # textured: the 64x64 level is evaluated and mostly loses
+    (328, 264, 10, 100, False, True, dict(tiles_override=4)),    # tiles; 328 = 5 superblocks + 8: a 64x64 block must split at the frame edge
+    (200, 136, 10, 66, True, True, {}),                          # 4:0:0 (alpha-like) planes take the same path without the chroma stage
+    (192, 192, 10, 110, False, True, dict(rdo_tx_decision=0)),
+    (192, 192, 8, 110, False, True, dict(complex_pred_modes=0, fine_directional_intra=0, tune_psnr=1)),
+])
+def test_64x64_blocks_hip_equals_oracle(oracle, w, h, bd, q, mono, smooth, over):
+    """R-4: partition_range (4, 64) (speed <= 1 below the high-quality threshold, ravif/src/av1encoder.rs:556-566).  The 64x64 level of the tile search
+    (dev_blk64.h: four 32x32 chroma transform blocks per plane, the tx-size trial through HBM scratch) against oracle/av1o_search.c, bytes + reconstruction;
+    on the smooth pictures 64x64 blocks must actually be chosen."""
+    import cavif_rs_amd as m
+    from tests.test_oracle_dav1d import smooth_planes
+    pl = smooth_planes(h, w, bd, w + h) if smooth else planes(h, w, seed=w + h, bd=bd, mono=mono)
+    if mono: pl = pl[:1]
+    names = {'rdo_tx_decision': 'rdo_tx', 'encode_bottomup': 'bottomup', 'complex_pred_modes': 'complex_modes', 'fine_directional_intra': 'fine_directional', 'tiles_override': 'tiles'}
+    cfg = oracle.make_config(w, h, bd, mono, q, 1, **{names.get(k, k): v for k, v in over.items()})
+    assert cfg.part_max == 64
+    r = oracle.encode_planes(cfg, pl)
+    if smooth: assert int((r['m_bsize'] == 4).sum()) >= 256, 'no 64x64 block was chosen'
+    obu, rec = m.encode_planes(pl, bd, q, 1, mono, **over)
+    assert obu == r['obu']
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('kind', ['textured', 'flat', 'two_regions', 'noise_tiles'])
 def test_segmentation_hip_equals_oracle(oracle, kind):
     """segment_kernel's fit (histogram, k-means, indices, thresholds), the per-block quantiser switch in K1 and the segment ids K4 codes: the frame
