@@ -47,26 +47,60 @@ def hbm_traffic_bytes(kernel, cfg):
         return None
 
 
+def _synth_cache_dir():
+    """Per-user cache of the synthetic inputs, keyed by the generator's source: a changed cavif_rs_amd/synth.py (or somebody else's files
+    under a shared /tmp) can never stand in for the images the sha256 manifest was made from."""
+    import hashlib
+    with open(os.path.join(ROOT, 'cavif_rs_amd', 'synth.py'), 'rb') as fh:
+        gen = hashlib.sha256(fh.read()).hexdigest()[:16]
+    base = os.environ.get('MI_SYNTH_CACHE') or os.path.join(os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache'), 'mi_synth_cache')
+    d = os.path.join(base, gen)
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    except OSError:
+        d = os.path.join(tempfile.gettempdir(), 'mi_synth_cache_%d' % os.getuid(), gen)
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
 def _synth_to_cache(job):
-    """One synthetic image into the .npy cache (worker process): the generator is 0.6 s of numpy per 1080p image."""
+    """One synthetic image into the .npy cache (worker process) with its sha256 beside it: the generator is 0.6 s of numpy per 1080p image."""
     path, w, h, idx = job
     sys.path.insert(0, ROOT)
+    import hashlib
     import numpy as np
     from cavif_rs_amd.synth import synth_image
+    img = synth_image(w, h, index=idx)
     tmp = '%s.%d.tmp.npy' % (path, os.getpid())
-    np.save(tmp, synth_image(w, h, index=idx))
+    np.save(tmp, img)
+    with open(tmp + '.sha', 'w') as fh:
+        fh.write(hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest())
+    os.replace(tmp + '.sha', path + '.sha')
     os.replace(tmp, path)
     return path
 
 
-def synth_images(w, h, indices):
-    """The synthetic inputs `synth_image(w, h, index=i)`, generated on all host cores and kept as .npy files under
-    $MI_SYNTH_CACHE (default /tmp/mi_synth_cache) so that repeated runs on one box do not regenerate them."""
+def _load_cached(path):
+    """A cached image, or None when the file or its checksum is missing or does not match (it is then regenerated)."""
+    import hashlib
     import numpy as np
-    d = os.environ.get('MI_SYNTH_CACHE', '/tmp/mi_synth_cache')
-    os.makedirs(d, exist_ok=True)
+    try:
+        img = np.load(path)
+        with open(path + '.sha') as fh:
+            want = fh.read().strip()
+        return img if hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == want else None
+    except Exception:
+        return None
+
+
+def synth_images(w, h, indices):
+    """The synthetic inputs `synth_image(w, h, index=i)`, generated on all host cores and kept as checksummed .npy files in a per-user cache
+    directory named after the generator's source hash (_synth_cache_dir; $MI_SYNTH_CACHE overrides the base), so that repeated runs on one
+    box do not regenerate them."""
+    d = _synth_cache_dir()
     paths = {i: os.path.join(d, 'synth_%dx%d_%05d.npy' % (w, h, i)) for i in indices}
-    missing = [(paths[i], w, h, i) for i in indices if not os.path.exists(paths[i])]
+    out = {i: _load_cached(paths[i]) for i in indices}
+    missing = [(paths[i], w, h, i) for i in indices if out[i] is None]
     if len(missing) > 2:
         import multiprocessing as mp
         with mp.get_context('spawn').Pool(max(1, min(os.cpu_count() or 1, 16, len(missing)))) as pool:
@@ -74,14 +108,18 @@ def synth_images(w, h, indices):
     else:
         for job in missing:
             _synth_to_cache(job)
-    return {i: np.load(paths[i]) for i in indices}
+    for (path, _, _, i) in missing:
+        out[i] = _load_cached(path)
+        if out[i] is None:
+            raise SystemExit('bench.py: could not produce %s' % path)
+    return out
 
 
-def check_identity(batches, image_index, B, cfg):
-    """sha256 of every .avif the batch slots hold (their last encode) against the committed oracle manifest."""
+def check_identity(batches, image_index, B, cfg, manifest=None):
+    """sha256 of every .avif the batch slots hold (their last encode) against the committed oracle manifest (or --manifest: same format, made by a test)."""
     import hashlib
     try:
-        with open(os.path.join(ROOT, 'tests', 'golden', 'bench_manifest.json')) as fh:
+        with open(manifest or os.path.join(ROOT, 'tests', 'golden', 'bench_manifest.json')) as fh:
             man = json.load(fh)
     except Exception as e:
         return {"status": "unchecked: no manifest (%s)" % e}
@@ -219,14 +257,31 @@ def main():
     ap.add_argument('--depth', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-identity-check', action='store_true')
+    ap.add_argument('--manifest', default=None, help='sha256 manifest to check the outputs against (default: tests/golden/bench_manifest.json, the default workload)')
     ap.add_argument('--no-pcie-loop', action='store_true', help='skip the second timed loop (H2D inside the region)')
     ap.add_argument('--secondary', action='store_true', help='also time BASELINE configs 2, 3 and 5 (single images; config 5 takes a while)')
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 96 at N=1 GPU, 0 = skip)')
     ap.add_argument('--pipeline', type=int, default=3, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 3 measured best on MI355X)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Not under a launcher: become one.  `python bench.py --gpus N` alone must measure N GPUs, one rank per GPU (the driver's own launch line is the
+        # same command under torch.distributed.run and takes the other branch).  MI_BENCH_SHARE_DEVICES=1 lets ranks share devices (CPU tests against
+        # the emulator library: one emulated device).
+        import socket
+        import cavif_rs_amd as m0
+        ndev0 = m0.device_count()
+        if ndev0 < args.gpus and os.environ.get('MI_BENCH_SHARE_DEVICES') != '1':
+            raise SystemExit('bench.py: --gpus %d asked for, %d HIP device(s) visible' % (args.gpus, ndev0))
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(1, args.gpus):
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     if world > 1:
@@ -244,6 +299,8 @@ def main():
     ndev = m.device_count()
     if ndev < 1:
         raise SystemExit('bench.py: no HIP device visible; the HIP path is mandatory (no CPU fallback)')
+    if ndev < world and os.environ.get('MI_BENCH_SHARE_DEVICES') != '1':
+        raise SystemExit('bench.py: %d ranks but %d HIP device(s) visible: one rank per GPU' % (world, ndev))
     device = local_rank % ndev
     enc = m.Encoder().with_quality(args.quality).with_speed(args.speed).with_bit_depth(args.depth).with_device(device)
     w, h, B = args.width, args.height, args.batch
@@ -288,19 +345,28 @@ def main():
         barrier()
         t0 = time.perf_counter()
         stats = run_steps(args.steps, with_h2d)
+        own_done[0] = time.perf_counter()
         barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
         if dist is not None:
             import torch
+            # the clock the contract asks for: barrier, K steps, barrier, MAX over ranks.  Each rank's own time up to its last wait (before the closing
+            # barrier) is gathered too, so that a straggler is visible in the line.
             tt = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt[0])
-        return elapsed, stats
+            mine = torch.tensor([own_done[0] - t0], dtype=torch.float64)
+            allr = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [float(x[0]) for x in allr]
+        return elapsed, stats, per_rank
 
-    elapsed, stats = timed(False)                                # `value`: inputs resident in HBM
+    own_done = [0.0]
+    elapsed, stats, per_rank = timed(False)                      # `value`: inputs resident in HBM
     elapsed_pcie = None
     if not args.no_pcie_loop:
-        elapsed_pcie, _ = timed(True)                            # `value_pcie_inclusive`: H2D from pinned host memory inside the region
+        elapsed_pcie, _, _ = timed(True)                            # `value_pcie_inclusive`: H2D from pinned host memory inside the region
     search_ms, stage_acc = [], {}
     for st in stats:
         search_ms.append(st['tile_search'])
@@ -315,7 +381,7 @@ def main():
     # every file of every slot of this rank against the oracle's sha256 manifest (tests/golden/bench_manifest.json); no oracle run here
     identity = None
     if not args.no_identity_check:
-        identity = check_identity(batches, image_index, B, {"width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth})
+        identity = check_identity(batches, image_index, B, {"width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth}, args.manifest)
         if dist is not None:
             import torch
             tt = torch.tensor([identity.get("checked", 0), identity.get("equal", 0)], dtype=torch.int64)
@@ -347,6 +413,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
                          "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
                          "overlapped_launch_ms": round(k1_overlapped, 3)},
+            "ms_per_step_per_rank": {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3), "ranks": len(per_rank),
+                                     "note": "each rank's own clock from the opening barrier to its last wait; ms_per_step is the MAX over ranks around both barriers"},
             "stage_ms_per_step": {k_: round(v_ / args.steps, 3) for k_, v_ in stage_acc.items()},
         }
         if elapsed_pcie is not None:

@@ -55,7 +55,8 @@ struct FrameDev {
   const uint32_t *act, *svar8, *svar4; int tune_psnr;
   int seg_n;                 // segments in use (0 = segmentation off); written by segment_kernel, like *seg
   const SegTab *seg;
-  int *sb_prog;              // K1 work queue: superblocks finished per (frame SB row, tile column); zeroed before every encode
+  int *sb_prog;              // K1 work queue: superblocks finished per (frame SB row, tile column), then one word of finished-root bits per superblock, then the frame's
+                             // sticky error word (search_error_word): a wait that gave up; all zeroed before every encode
   int dbg;                   // debug bisect level (0 = off; probe builds only)
   const uint16_t *cost;      // static rate table [CDF_TOTAL] (cost per symbol in 1/512 bit, same flat layout as the CDF context)
   // ---- tail: frame-level stages and the entropy coder ----
@@ -91,6 +92,7 @@ struct FrameDev {
   // once (no host round trip between the front end and the tile search).  nullptr: always active.
   const int *active;
 };
+template <typename FP> __device__ __forceinline__ int *search_error_word(FP f) { return f->sb_prog + f->sb_rows * f->tile_cols + f->sb_rows * f->sb_cols; }
 __device__ __forceinline__ bool frame_idle(const FrameDev *f) { return f->active != nullptr && *f->active == 0; }
 #define FRAMEDEV_K1_BYTES ((int)(offsetof(FrameDev, fin) + 15) & ~15)
 

@@ -114,7 +114,7 @@ struct FramePlan;
 static size_t zeroed_bytes(const FramePlan &p);
 
 static int lr_units_host(uint32_t size) { const int n = ((int)size + 32) / 64; return n < 1 ? 1 : n; }
-static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + ((size_t)p.sb_rows * p.tiles.cols + (size_t)p.sb_rows * p.sb_cols) * sizeof(int); }   // decoded flags, deblock tallies, K1's per-row counters and per-superblock root masks
+static size_t zeroed_bytes(const FramePlan &p) { return align_up((size_t)p.mi_stride * p.mi_h, 256) + align_up(6 * 65 * sizeof(long long), 256) + ((size_t)p.sb_rows * p.tiles.cols + (size_t)p.sb_rows * p.sb_cols + 1) * sizeof(int); }   // decoded flags, deblock tallies, K1's per-row counters and per-superblock root masks
 static void plan_geometry(FramePlan &p) {
   const mi_av1_config &c = p.cfg;
   p.np = c.chroma == 1 ? 1 : 3;
@@ -162,7 +162,7 @@ static size_t carve(FramePlan &p, uint8_t *base, uint32_t tile_cap) {
   d.tile_len = (uint32_t *)take((size_t)p.ntiles * 4);
   d.tile_clk = (unsigned long long *)take((size_t)p.ntiles * 32);
   d.tile_cost = nullptr; d.cdf_out = nullptr; d.tile_cost_buf = nullptr;
-  if (p.cfg.rdo_passes >= 2) { d.cdf_out = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); d.tile_cost_buf = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); }
+  if (p.cfg.rdo_passes == 2) { d.cdf_out = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); d.tile_cost_buf = (uint16_t *)take((size_t)p.ntiles * CDF_TOTAL * 2); }
   d.prof_out = nullptr;
   d.tile_out_cap = tile_cap;
   return off;
@@ -385,7 +385,7 @@ static int batch_plan(mi_batch *b, bool with_alpha_frames) {
     FramePlan p; p.image = image; p.is_alpha = alpha;
     mi_av1_config &c = p.cfg;
     c.width = b->w; c.height = b->h; c.bit_depth = (uint8_t)b->depth; c.quantizer = (uint8_t)(alpha ? aquant : quantizer);
-    c.chroma = alpha ? 1 : 0; c.pixel_range = 1; c.threads = b->enc.threads; c.device = b->device; c.tiles_override = b->enc.tiles_override; c.rdo_passes = (uint8_t)(b->enc.rdo_passes >= 2 ? 2 : 1);
+    c.chroma = alpha ? 1 : 0; c.pixel_range = 1; c.threads = b->enc.threads; c.device = b->device; c.tiles_override = b->enc.tiles_override; c.rdo_passes = (uint8_t)(b->enc.rdo_passes == 2 ? 2 : 1);
     c.has_color_desc = alpha ? 0 : 1; c.primaries = 1; c.transfer = 13; c.matrix = b->enc.color_model == 1 ? 0 : 6;
     tweaks_from_preset(b->enc.speed, c.quantizer, &c);
     plan_geometry(p);
@@ -629,7 +629,7 @@ int mi_batch_encode_async(mi_batch *b) {
   // A two-pass encode (rdo_passes = 2) runs the chain twice: between the passes every tile's final CDFs become its rate table, the frames switch
   // over to them, and the activity kernel clears the per-encode state again; the events time the last pass.
   int max_cells = 0; for (auto &p : b->frames) max_cells = std::max(max_cells, (p.pw / 8) * (p.ph / 8));
-  const int passes = b->frames[0].cfg.rdo_passes >= 2 ? 2 : 1;
+  const int passes = b->frames[0].cfg.rdo_passes == 2 ? 2 : 1;
   const bool bottomup = b->frames[0].cfg.encode_bottomup != 0;
   for (int pass = 0; pass < passes; pass++) {
     if (pass == 1) {
@@ -671,7 +671,7 @@ int mi_batch_wait(mi_batch *b) {
   auto idle = [&](const FramePlan &p) { return p.is_alpha && !b->alpha_flags[p.image]; };
   size_t total = 0;
   for (int j = 0; j < njobs; j++) {
-    if (b->h_lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer\n", j); return MI_ENCODING_ERROR; }
+    if (b->h_lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer (or its frame's tile search gave up waiting for a neighbour)\n", j); return MI_ENCODING_ERROR; }
     offsets[j] = (uint32_t)total; total += b->h_lens[j];
   }
   if (total > b->packed_max) return MI_ENCODING_ERROR;
@@ -692,7 +692,9 @@ int mi_batch_wait(mi_batch *b) {
     if (idle(p)) { p.obu.clear(); continue; }
     std::vector<std::pair<const uint8_t *, size_t>> tl;
     for (int t = 0; t < p.ntiles; t++) { const int j = p.dev.tile_base + t; tl.push_back({ b->h_packed + offsets[j], (size_t)b->h_lens[j] }); }
-    for (int i = 0; i < 13; i++) p.hdr.lf_level[i] = b->h_lf[13 * k + i];      // levels, then seg_n and seg_qidx (contiguous in FrameHeaderInfo)
+    static_assert(offsetof(FrameHeaderInfo, seg_n) == offsetof(FrameHeaderInfo, lf_level) + 4 * sizeof(int) && offsetof(FrameHeaderInfo, seg_qidx) == offsetof(FrameHeaderInfo, seg_n) + sizeof(int),
+                  "FrameDev::lf_out reports 13 ints: lf_level[4], seg_n, seg_qidx[8]");
+    memcpy((char *)&p.hdr + offsetof(FrameHeaderInfo, lf_level), b->h_lf + 13 * k, 13 * sizeof(int));
     p.obu = assemble_obus(p.hdr, tl);
   }
   for (int i = 0; i < b->n; i++) {
@@ -764,7 +766,7 @@ struct PoolKey {
   }
 };
 static PoolKey pool_key(const mi_ravif_encoder *e, int cap, uint32_t w, uint32_t h, int channels) {
-  return PoolKey{ e->device, cap, channels, w, h, e->quality, e->alpha_quality, e->speed, e->color_model, e->depth, e->alpha_mode, e->threads, e->tiles_override, e->rdo_passes >= 2 ? 2 : 1 };
+  return PoolKey{ e->device, cap, channels, w, h, e->quality, e->alpha_quality, e->speed, e->color_model, e->depth, e->alpha_mode, e->threads, e->tiles_override, e->rdo_passes == 2 ? 2 : 1 };
 }
 static std::mutex g_pool_mu;
 static std::vector<std::pair<PoolKey, mi_batch *>> g_pool;          // oldest first; never destroyed at process exit (the runtime may be gone by then)
@@ -863,6 +865,7 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
     std::future<int> warm = std::async(std::launch::async, [dev]() { return hipSetDevice(dev) == hipSuccess ? ensure_tables(dev) : (int)MI_ENCODING_ERROR; });
     size_t budget = (size_t)48 << 30;
     { size_t fr = 0, tot = 0; if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = fr / 10 * 6; }
+    { int sharing = 0; for (int d2 : devs) sharing += d2 == dev; budget /= (size_t)std::max(1, sharing); }      // workers on the same ordinal (devices = [0, 0]) split what is free
     constexpr int NSLOT = 3;
     struct Slot { mi_batch *b = nullptr; std::future<mi_batch *> making; std::vector<size_t> idx; bool busy = false; size_t bytes = 0; };
     struct Shape { uint32_t w, h; int ch; size_t cap; Slot slot[NSLOT]; int next = 0; size_t runs = 0, last_use = 0; };
@@ -914,6 +917,7 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
       collect(sl);                                           // the slot's previous run, if any
       ensure_slot(sh, j);
       if (sl.making.valid()) sl.b = sl.making.get();
+      if (!sl.b) { live_bytes -= std::min(live_bytes, sl.bytes); sl.bytes = 0; }      // the object could not be made: nothing of it is resident
       int rc = sl.b ? mi_batch_set_count(sl.b, (int)run.size()) : MI_ENCODING_ERROR;
       if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d ready\n", since(), dev, j);
       if (rc == MI_OK) {
@@ -1031,7 +1035,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
     int class_begin[6] = { 0, 0, 0, 0, 0, 0 };
     for (int cls = std::max(p.maxbs, 2) + 1; cls <= 5; cls++) class_begin[cls] = njobs;
     std::vector<FramePlan> one(1, p);
-    for (int pass = 0; pass < (p.cfg.rdo_passes >= 2 ? 2 : 1); pass++) {
+    for (int pass = 0; pass < (p.cfg.rdo_passes == 2 ? 2 : 1); pass++) {
       if (pass == 1) {                                          // two-pass pricing: the tiles' final CDFs become their rate tables
         hipLaunchKernelGGL(cdf_cost_kernel, dim3(njobs, 1), dim3(256), 0, s, d_frame);
         hipLaunchKernelGGL(pass_flip_kernel, dim3(1), dim3(64), 0, s, d_frame, 1);
@@ -1051,7 +1055,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
   HIP_OK(hipStreamSynchronize(s));
   std::vector<std::vector<uint8_t>> td(njobs); std::vector<std::pair<const uint8_t *, size_t>> tl;
   for (int j = 0; j < njobs; j++) {
-    if (lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer\n", j); return MI_ENCODING_ERROR; }
+    if (lens[j] == 0xFFFFFFFFu) { fprintf(stderr, "mi_avif: tile %d overflowed its output buffer (or its frame's tile search gave up waiting for a neighbour)\n", j); return MI_ENCODING_ERROR; }
     td[j].resize(lens[j]);
     HIP_OK(hipMemcpy(td[j].data(), p.dev.tile_out + (size_t)j * cap, lens[j], hipMemcpyDeviceToHost));
     tl.push_back({ td[j].data(), td[j].size() });
@@ -1078,7 +1082,7 @@ static int raw_planes(const mi_ravif_encoder *e, uint32_t w, uint32_t h, const v
     if (depth == 8) pl[c][i] = ((const uint8_t *)yuv)[i * 3 + c]; else ((uint16_t *)pl[c].data())[i] = ((const uint16_t *)yuv)[i * 3 + c];
   }
   mi_av1_config c{}; c.width = w; c.height = h; c.bit_depth = (uint8_t)depth; c.quantizer = (uint8_t)quality_to_quantizer(e->quality);
-  c.chroma = 0; c.pixel_range = range; c.threads = e->threads; c.has_color_desc = 1; c.primaries = 1; c.transfer = 13; c.matrix = matrix; c.device = e->device; c.tiles_override = e->tiles_override; c.rdo_passes = (uint8_t)(e->rdo_passes >= 2 ? 2 : 1);
+  c.chroma = 0; c.pixel_range = range; c.threads = e->threads; c.has_color_desc = 1; c.primaries = 1; c.transfer = 13; c.matrix = matrix; c.device = e->device; c.tiles_override = e->tiles_override; c.rdo_passes = (uint8_t)(e->rdo_passes == 2 ? 2 : 1);
   if (int st = tweaks_from_preset(e->speed, c.quantizer, &c)) return st;
   const void *pp[3] = { pl[0].data(), pl[1].data(), pl[2].data() }; const size_t sb[3] = { w * bps, w * bps, w * bps };
   uint8_t *cobu = nullptr, *aobu = nullptr; size_t clen = 0, alen = 0;

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(MI_K4_THREADS_OF(NA)) void tile_entropy_kernel(cons
   if (wave == NA + 1) {
     uint8_t *out = f->tile_out + (size_t)tile * f->tile_out_cap;
     uint32_t out_len = re_finish_dev(&ec, out, f->tile_out_cap);       // whole wave
-    if (overflow) out_len = 0xFFFFFFFFu;
+    if (overflow || *search_error_word(f) != 0) out_len = 0xFFFFFFFFu;     // (a tile search that gave up waiting: tile_search.h root_wait)
     if (LANE == 0) {
       f->tile_len[tile] = out_len;
       unsigned long long *tc = f->tile_clk + (size_t)tile * 4; tc[2] = clk0; tc[3] = wall_clock64();

@@ -719,9 +719,9 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
 #pragma unroll
                 for (int k2 = 0; k2 < half; k2++) {
                   int l, d;
-                  if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; }
+                  if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
                   top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-                  if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; }
+                  if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
                   left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
                 }
                 sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
@@ -824,9 +824,10 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
 #pragma unroll
             for (int k2 = 0; k2 < half; k2++) {
               int l, d;
-              if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; }
+              // (a 32x32 block may reach past the frame's last 8x8 column / row: the oracle's av1o_txb_ctx leaves out neighbour cells beyond the frame; smaller blocks never do)
+              if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
               top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-              if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; }
+              if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
               left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
             }
             sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
@@ -1302,8 +1303,12 @@ template <int MAXBS, int MAXN, int NW> __device__ inline void root_wait(const Ct
       const int sr2 = rr >> 4, sc2 = cc >> 4, z2 = root_z((gr + dr) & (G - 1), (gc + dc) & (G - 1));
       if (only_if_earlier && !(sr2 < sr || (sr2 == sr && (sc2 < sc || (sc2 == sc && z2 < zc))))) return;
       const int *w = mask + sr2 * f->sb_cols + sc2;
-      // (bounded: a protocol error must end in wrong bytes that the parity tests catch, not in a hung device; ~2^25 polls are tens of seconds)
-      for (unsigned spin = 0; !((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25); spin++) __builtin_amdgcn_s_sleep(16);
+      // Bounded (~2^25 polls are tens of seconds: a protocol error, a preempted or shared device must not hang the GPU), and a wait that gives up marks the frame:
+      // the entropy stage then reports every tile of it as failed (tile_len = 0xFFFFFFFF) and the host returns MI_ENCODING_ERROR instead of a stream whose
+      // reconstruction the search did not see.
+      unsigned spin = 0;
+      while (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; }
+      if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(f), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     need(0, -1, false); need(-1, 0, false); need(-1, -1, false); need(-1, 1, true); need(1, -1, true);
   }

@@ -43,7 +43,9 @@ typedef struct mi_av1_config {
   int32_t tiles_override;   /* >0 forces the tile target (tests) */
   int32_t device;           /* HIP ordinal */
   uint8_t tune_psnr;        /* 0 = Tune::Psychovisual, what ravif always sets (:694); 1 = Tune::Psnr (plain SSE; ablation only) */
-  uint8_t rdo_passes;       /* <= 1: the tile search prices against the table of the frame's initial CDFs.  2 (an extension, not in ravif): the
+  uint8_t rdo_passes;       /* exactly 2 selects two-pass pricing, ANY other value means one pass (the struct grew by this field: a caller that fills it field by field
+                               without zeroing must not switch modes by accident -- zero-initialise the struct, or start from mi_av1_tweaks_from_preset).
+                               One pass: the tile search prices against the table of the frame's initial CDFs.  2 (an extension, not in ravif): the
                                whole encode runs twice and the second search prices every tile against the CDFs that tile ended the first
                                pass with -- a step towards rav1e's adaptive pricing that keeps tiles and superblock rows independent */
 } mi_av1_config;
@@ -72,7 +74,8 @@ typedef struct mi_ravif_encoder {
   const uint8_t *exif; size_t exif_len;   /* with_exif :208; copied by mi_batch_create / every encode call, need not outlive it */
   int32_t device;
   int32_t tiles_override;
-  int32_t rdo_passes;             /* extension: see mi_av1_config.rdo_passes (0 / 1 = one pass, ravif's behaviour) */
+  int32_t rdo_passes;             /* extension: see mi_av1_config.rdo_passes (exactly 2 = two passes; anything else = one pass, ravif's behaviour).  The struct must be
+                                     zero-initialised or come from mi_ravif_encoder_default: both structs have grown at the tail and may grow again */
 } mi_ravif_encoder;
 
 typedef struct mi_encoded_image { uint8_t *avif_file; size_t avif_len, color_byte_size, alpha_byte_size; } mi_encoded_image;

@@ -92,3 +92,26 @@ def test_two_ranks_encode_their_shards(oracle, tmp_path):
     for i, sha in res['files']:
         ref, _, _ = oracle.ravif_encode(synth_image(192, 128, index=i), quality=80, speed=4, depth=10)
         assert hashlib.sha256(ref).hexdigest() == sha
+
+
+def test_bench_gpus_2_spawns_two_ranks_by_itself(oracle, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run (one rank per GPU; here both ranks share the
+    SIMT emulator's one device): n_gpus == 2, every file of both ranks' slots == the oracle, both ranks' clocks in the line."""
+    import hashlib, json
+    from tests import emu
+    from cavif_rs_amd.synth import synth_image
+    w, h, B, slots = 64, 48, 1, 2
+    man = {'config': {'width': w, 'height': h, 'speed': 4, 'quality': 80.0, 'bit_depth': 10},
+           'sha256': [hashlib.sha256(oracle.ravif_encode(synth_image(w, h, index=i), quality=80, speed=4, depth=10)[0]).hexdigest() for i in range(2 * slots * B)]}
+    mpath = tmp_path / 'manifest.json'
+    mpath.write_text(json.dumps(man))
+    env = dict(emu.env(), MI_BENCH_SHARE_DEVICES='1', MI_SYNTH_CACHE=str(tmp_path / 'cache'))
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0', '--batch', str(B), '--width', str(w), '--height', str(h),
+                          '--pipeline', str(slots), '--no-cpu-baseline', '--no-pcie-loop', '--end-to-end', '0', '--manifest', str(mpath)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['n_gpus'] == 2 and res['ms_per_step_per_rank']['ranks'] == 2
+    assert res['ms_per_step_per_rank']['max'] <= res['ms_per_step'] * 1.001 + 1e-3
+    assert res['output_identity']['checked'] == 2 * slots * B and res['output_identity']['equal'] == 2 * slots * B
+    assert abs(res['value'] - 2 * B * w * h * 2 / 1e6 / (res['ms_per_step'] * 2 / 1e3)) < 1e-2 * res['value'] + 1e-3
