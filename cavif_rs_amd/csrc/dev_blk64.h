@@ -86,12 +86,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int can_ar = availU && (c + n4 < t->mi_col_end), can_bl = availL && (r + n4 < t->mi_row_end);
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
-  const int v_ar = f->m_decoded[can_ar ? (r - 1) * ms + c + n4 : mi], v_bl = f->m_decoded[can_bl ? (r + n4) * ms + c - 1 : mi];
   const int v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL];
   const int v_uvU = f->np > 1 ? f->m_uvmode[iU] : 0, v_uvL = f->np > 1 ? f->m_uvmode[iL] : 0;
   const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
   const int v_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];
-  const int have_ar = can_ar && uni32(v_ar), have_bl = can_bl && uni32(v_bl);
+  const int have_ar = can_ar, have_bl = 0;                     // (decoded_before: the superblock above-right is final, the one below-left never is)
   const int amode = availU ? uni32(v_ymU) : DC_PRED, lmode = availL ? uni32(v_ymL) : DC_PRED;
   const int nb_skip = (availU ? uni32(v_skU) & 1 : 0) + (availL ? uni32(v_skL) & 1 : 0);
   const int seg_nb = (availU && availL ? (uni32(v_skUL) >> 1) + 1 : 0) | ((availU ? (uni32(v_skU) >> 1) + 1 : 0) << 4) | ((availL ? (uni32(v_skL) >> 1) + 1 : 0) << 8);
@@ -513,7 +512,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k
   if (W == 0) {
     fill_map_dev(f->m_skip, ms, r, c, n4, skip | (seg_fin << 1));
     if (skip) for (int pp = 0; pp < f->np; pp++) { fill_map_dev(f->m_lvl[pp], ms, r, c, n4, 0); fill_map_dev(f->m_dc[pp], ms, r, c, n4, 0); }
-    fill_map_dev(f->m_decoded, ms, r, c, n4, 1);
   }
   total_j += ((long long)k.cost()[CDF_SKIP + nb_skip * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
   if (f->seg_n && !skip) total_j += ((long long)k.cost()[CDF_SEG_ID + seg_ctx * CDF_SEG_ID_STRIDE + seg_symbol(seg_own, seg_p, f->seg_n)] * f->rdmult + 256) >> 9;

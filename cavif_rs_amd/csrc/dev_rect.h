@@ -544,7 +544,8 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
   const int can_ar = availU && (c + w4 < t->mi_col_end), can_bl = availL && (r + h4 < t->mi_row_end);
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
-  const int have_ar = can_ar && uni32(f->m_decoded[can_ar ? (r - 1) * ms + c + w4 : mi]), have_bl = can_bl && uni32(f->m_decoded[can_bl ? (r + h4) * ms + c - 1 : mi]);
+  constexpr int SHAPE = BSR == BS_8X4 ? 1 : 2;                 // (decoded_before: the halves of the node in coding order)
+  const int have_ar = can_ar && decoded_before(r, c, SHAPE, r - 1, c + w4), have_bl = can_bl && decoded_before(r, c, SHAPE, r + h4, c - 1);
   const int amode = availU ? uni32(f->m_ymode[iU]) : DC_PRED, lmode = availL ? uni32(f->m_ymode[iL]) : DC_PRED;
   const int uvU = f->np > 1 ? uni32(f->m_uvmode[iU]) : 0, uvL = f->np > 1 ? uni32(f->m_uvmode[iL]) : 0;
   const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];        // bit 0 = skip, the rest = segment id
@@ -707,7 +708,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
         if (W == 0) {
           // availability of the halves' above-right / below-left runs (oracle: the decoded flags of the cells they start in)
           const bool c_ar = sU && cc + 1 < t->mi_col_end, c_bl = sL && rr + 1 < t->mi_row_end;
-          const int s_ar = c_ar && uni32(f->m_decoded[c_ar ? (rr - 1) * ms + cc + 1 : mi]), s_bl = c_bl && uni32(f->m_decoded[c_bl ? (rr + 1) * ms + cc - 1 : mi]);
+          const int s_ar = c_ar && decoded_before(r, c, SHAPE, rr - 1, cc + 1), s_bl = c_bl && decoded_before(r, c, SHAPE, rr + 1, cc - 1);   // (both cells lie outside the block)
           LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
           const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
           const uint16_t *grec = f->rec[0];
@@ -990,7 +991,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, 
   if (W == 0) {
     fill_rect<WL, HL>(f->m_skip, ms, r, c, skip | (seg_fin << 1));
     if (skip) for (int p = 0; p < f->np; p++) { fill_rect<WL, HL>(f->m_lvl[p], ms, r, c, 0); fill_rect<WL, HL>(f->m_dc[p], ms, r, c, 0); }
-    fill_rect<WL, HL>(f->m_decoded, ms, r, c, 1);
   }
   total_j += ((long long)k.cost()[CDF_SKIP + nb_skip * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
   WG_SYNC();

@@ -17,12 +17,16 @@
 #include "dev_rate.h"
 #include "dev_group.h"
 
+// The shape of the search's code, fixed explicitly (left to the inliner's cost model it flips with unrelated edits: with the block searches inlined into
+// separate partition functions K1 <2,4> went from 116 to 142 ms): the block searches are functions of their own -- entered with every argument in registers
+// and, not being tail-called, given LLVM's no-callee-saved-registers treatment --, the partition walkers are inlined into the kernel.
 #ifndef MI_K1_TRY_ATTR
-#define MI_K1_TRY_ATTR __attribute__((not_tail_called))
+#define MI_K1_TRY_ATTR __attribute__((noinline, not_tail_called))
 #endif
 #ifndef MI_K1_INLINE
 #define MI_K1_INLINE
 #endif
+#define MI_K1_WALK_INLINE __forceinline__
 #ifndef MI_K1_WG_PER_CU
 #define MI_K1_WG_PER_CU 4
 #endif
@@ -85,7 +89,8 @@ template <int N> struct SharedScratch {          // shared by the waves of the t
   uint16_t luma_rec[N * N];
   long long satd[13], dsd[7][6];
   long long wbest_j[4], cj[16][2], pbest_j[2];
-  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], cok[16], ldelta[7];
+  int order[13], wbest_e[4], pbest_c[2], calpha[2][2], ldelta[7];
+  uint16_t part_cost[40];                          // the partition symbols the walker prices (part_cost_idx): the slice of the rate table it needs, per frame / tile like the coefficient slices
   uint16_t lpred[N <= 32 ? 768 : 4];               // final luma predictions of the surviving modes, n*n samples each (three at 16x16, up to seven at 8x8 / 4x4)
   long long ca_sse[2][2]; int ca_idx[2][2];                  // CfL alpha search, [plane][half of the alpha range]
   int lm_mode, lm_delta, lm_tx, lm_eob, ceob[2], sctx[3], dctx[3];
@@ -164,10 +169,20 @@ template <typename SHT> __device__ __forceinline__ void seg_select(const LDS Fra
 __device__ inline void fill_map_dev(uint8_t *m, int ms, int r, int c, int n4, int v) {
   for (int i = LANE; i < n4 * n4; i += 64) m[(r + i / n4) * ms + c + (i % n4)] = (uint8_t)v;
 }
-// whole workgroup
-template <int NW> __device__ inline void set_decoded_wg(const LDS FrameDev *f, int r, int c, int n4, int v) {
-  for (int i = threadIdx.x; i < n4 * n4; i += 64 * NW) f->m_decoded[(r + i / n4) * f->mi_stride + c + (i % n4)] = (uint8_t)v;
-  WG_SYNC();
+// "Was the 4x4 cell (pr, pc) decoded before the block at (cur_r, cur_c)?" -- the spec's BlockDecoded flag (7.11.2: above-right / below-left availability), which the
+// oracle keeps as a map (m_decoded).  In this search it is a function of the two positions: tiles are walked superblock by superblock, a superblock in quadtree order,
+// every trial of a node (NONE, SPLIT, HORZ, VERT) evaluates its blocks in coding order with the node's area considered undecoded, and everything a work item reads of
+// other superblocks is final before it starts (the queue's dependencies).  So a cell of an earlier superblock row, or of a superblock further left in the same row, is
+// decoded; a later one is not; inside the superblock the quadtree (Morton) order of the 4x4 cells decides -- except inside the current block's own 8x8 node when that
+// node is being tried as two 8x4 (rows in order) or two 4x8 blocks (columns in order: the left half's lower cell precedes the right half although its Morton index
+// is larger).  Callers check the tile bounds (cells outside the tile are unavailable whatever their order).  shape: 0 = square block, 1 = 8x4, 2 = 4x8.
+__device__ __forceinline__ int morton4_(int v) { v = (v | (v << 2)) & 0x33; return (v | (v << 1)) & 0x55; }
+__device__ __forceinline__ int decoded_before(int cur_r, int cur_c, int shape, int pr, int pc) {
+  const int dsr = (pr >> 4) - (cur_r >> 4), dsc = (pc >> 4) - (cur_c >> 4);
+  if (dsr != 0) return dsr < 0;
+  if (dsc != 0) return dsc < 0;
+  if (shape != 0 && (pr >> 1) == (cur_r >> 1) && (pc >> 1) == (cur_c >> 1)) return shape == 1 ? pr < cur_r : pc < cur_c;
+  return ((morton4_(pr & 15) << 1) | morton4_(pc & 15)) < ((morton4_(cur_r & 15) << 1) | morton4_(cur_c & 15));
 }
 
 // 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n.
@@ -321,12 +336,11 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   // load sat in its own branch with its own s_waitcnt -- a dozen serial round trips to L2 at the head of every block evaluation.
   const int can_ar = availU && (c + n4 < t->mi_col_end), can_bl = availL && (r + n4 < t->mi_row_end);
   const int iU = availU ? mi - ms : mi, iL = availL ? mi - 1 : mi;
-  const int v_ar = f->m_decoded[can_ar ? (r - 1) * ms + c + n4 : mi], v_bl = f->m_decoded[can_bl ? (r + n4) * ms + c - 1 : mi];
   const int v_ymU = f->m_ymode[iU], v_ymL = f->m_ymode[iL];
   const int v_uvU = f->np > 1 ? f->m_uvmode[iU] : 0, v_uvL = f->np > 1 ? f->m_uvmode[iL] : 0;
   const int v_skU = f->m_skip[iU], v_skL = f->m_skip[iL], v_txU = f->m_txsize[iU], v_txL = f->m_txsize[iL];
   const int v_skUL = f->m_skip[availU && availL ? mi - ms - 1 : mi];                                  // (segment id of the above-left neighbour)
-  const int have_ar = can_ar && uni32(v_ar), have_bl = can_bl && uni32(v_bl);
+  const int have_ar = can_ar && decoded_before(r, c, 0, r - 1, c + n4), have_bl = can_bl && decoded_before(r, c, 0, r + n4, c - 1);
   const int amode = availU ? uni32(v_ymU) : DC_PRED, lmode = availL ? uni32(v_ymL) : DC_PRED;
   const int nb_skip = (availU ? uni32(v_skU) & 1 : 0) + (availL ? uni32(v_skL) & 1 : 0);              // skip context (bit 0 of the map)
   // neighbours' segment ids + 1 (0 = outside the tile), packed: needed again when the block's skip flag is known -- parked in LDS, not in registers
@@ -652,8 +666,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           if (hn == 4 && n == 16 && LANE < 16) psv16[LANE] = (int)f->svar4[(r + (LANE >> 2)) * ms + c + (LANE & 3)];
           if (LANE >= 1 && LANE < G) {
             const bool ca = c + n4 < t->mi_col_end, cb = r + n4 < t->mi_row_end;
-            const int va = f->m_decoded[ca ? (r + LANE * half - 1) * ms + c + n4 : mi], vb = f->m_decoded[cb ? (r + n4) * ms + c + LANE * half - 1 : mi];
-            sfl_r[LANE] = ca && va; sfl_b[LANE] = cb && vb;
+            sfl_r[LANE] = ca && decoded_before(r, c, 0, r + LANE * half - 1, c + n4); sfl_b[LANE] = cb && decoded_before(r, c, 0, r + n4, c + LANE * half - 1);
           }
         }
         WG_SYNC();
@@ -1154,7 +1167,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
           if (LANE == 0) SH->cj[ci2][p - 1] = jp;
         }
       }
-      if (valid && LANE == 0 && (W & 1) == 0) SH->cok[ci2] = ok;
       PH(9);
       WG_SYNC();                                            // (B) both planes' costs visible
       PH(2);
@@ -1202,7 +1214,6 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   if (W == 0) {
     fill_map_dev(f->m_skip, ms, r, c, n4, skip | (seg_fin << 1));
     if (skip) for (int p = 0; p < f->np; p++) { fill_map_dev(f->m_lvl[p], ms, r, c, n4, 0); fill_map_dev(f->m_dc[p], ms, r, c, n4, 0); }
-    fill_map_dev(f->m_decoded, ms, r, c, n4, 1);
   }
   const int sctx = nb_skip;
   total_j += ((long long)k.cost()[CDF_SKIP + sctx * CDF_SKIP_STRIDE + skip] * f->rdmult + 256) >> 9;
@@ -1271,11 +1282,34 @@ template <int BS, int NW> __device__ inline void area_copy_dev(const LDS FrameDe
 #endif
 }
 
-__device__ inline uint32_t partition_rate_dev(const uint16_t *cost, const LDS FrameDev *f, const LDS TileB *t, int r, int c, int bs, int part) {
-  const int ms = f->mi_stride;
-  const int availU = r > t->mi_row_start, availL = c > t->mi_col_start;
-  const int above = availU && dim_wl(f->m_bsize[(r - 1) * ms + c]) < 2 + bs, left = availL && dim_hl(f->m_bsize[r * ms + c - 1]) < 2 + bs;
-  return cost[CDF_PARTITION + ((bs - 1) * 4 + left * 2 + above) * CDF_PARTITION_STRIDE + part];
+// ---- partition symbol rates for the walkers ----
+// The walker used to price every partition symbol with two dependent round trips to L2 (the neighbours' block sizes, then the rate table) executed by all four waves
+// with nothing else to do: ~20 of them per 16x16 root, a tenth of the kernel.  Now the slice of the rate table the walker can ask for sits in LDS (8x8 nodes: NONE, HORZ,
+// VERT, SPLIT per context; larger nodes: NONE and SPLIT), and a node fetches the block sizes of its outer neighbours -- above / left of its two halves -- in one batch
+// when it is entered; inside a split trial the siblings are undivided blocks of the child size, which never count as narrower / lower than the child.
+__device__ __forceinline__ int part_cost_idx(int bs, int ctx, int part) { return bs == 1 ? ctx * 4 + part : 16 + (bs - 2) * 8 + ctx * 2 + (part == 3); }
+template <typename SHT> __device__ inline void load_part_cost(LDS SHT *SH, const uint16_t *cost, int tid) {
+  if (tid < 40) {
+    const int bs = tid < 16 ? 1 : 2 + (tid - 16) / 8, e = tid < 16 ? tid : (tid - 16) % 8, ctx = tid < 16 ? e >> 2 : e >> 1, part = tid < 16 ? (e & 3) : ((e & 1) ? 3 : 0);
+    SH->part_cost[tid] = cost[CDF_PARTITION + ((bs - 1) * 4 + ctx) * CDF_PARTITION_STRIDE + part];
+  }
+}
+// partition context of a node of size code `bs` from the block-size codes above / left of it (spec 8.3.2: is the above block narrower, the left block lower than the node)
+__device__ __forceinline__ int part_ctx_of(int bs, int availU, int availL, int code_above, int code_left) {
+  return ((availL && dim_hl(code_left) < 2 + bs) ? 2 : 0) + ((availU && dim_wl(code_above) < 2 + bs) ? 1 : 0);
+}
+struct PartNb { int a0, a1, l0, l1, availU, availL; };          // block-size codes above the node's left / right half and left of its upper / lower half
+template <int BS> __device__ __forceinline__ PartNb part_neighbours(const LDS FrameDev *f, const LDS TileB *t, int r, int c, bool halves) {
+  constexpr int half = (1 << BS) >> 1;
+  const int ms = f->mi_stride, mi = r * ms + c;
+  PartNb n; n.availU = r > t->mi_row_start; n.availL = c > t->mi_col_start;
+  const int v0 = f->m_bsize[n.availU ? mi - ms : mi], v1 = f->m_bsize[(n.availU && halves) ? mi - ms + half : mi];
+  const int v2 = f->m_bsize[n.availL ? mi - 1 : mi], v3 = f->m_bsize[(n.availL && halves) ? mi + half * ms - 1 : mi];
+  n.a0 = uni32(v0); n.a1 = uni32(v1); n.l0 = uni32(v2); n.l1 = uni32(v3);
+  return n;
+}
+template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SHT *SH, const LDS FrameDev *f, int bs, int ctx, int part) {
+  return ((long long)SH->part_cost[part_cost_idx(bs, ctx, part)] * f->rdmult + 256) >> 9;
 }
 
 // `known_j` >= 0: the parent's split trial has just evaluated this block undivided, every earlier sibling kept
@@ -1326,27 +1360,27 @@ template <int MAXBS, int MAXN, int NW> __device__ inline void root_publish(const
 }
 
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
-  static __device__ MI_K1_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+  static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
     const int must_split = px > f->part_max || !has_rows || !has_cols;
     const int can_split = px > f->part_min || must_split;
-    if (known_j < 0 || must_split) set_decoded_wg<NW>(f, r, c, n4, 0);
     if (!can_split || (DBG_IS(f, 9) && BS == 1)) {
-      if constexpr (BS <= MAXBS) { if (known_j < 0) blk_eval<MAXN, BS, NW>(k, r, c); else set_decoded_wg<NW>(f, r, c, n4, 1); }
+      if constexpr (BS <= MAXBS) { if (known_j < 0) blk_eval<MAXN, BS, NW>(k, r, c); }
       return 0;
     }
     int do_split = must_split;
     long long sub_j[4] = { -1, -1, -1, -1 };
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
+        const PartNb nb = part_neighbours<BS>(f, k.t(), r, c, BS - 1 >= BS_8);
+        const int pctx = part_ctx_of(BS, nb.availU, nb.availL, nb.a0, nb.l0);
         const long long j_blk = known_j >= 0 ? known_j : uni64(blk_eval<MAXN, BS, NW>(k, r, c));
-        const long long j_none = uni64(j_blk + (((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9));
+        const long long j_none = uni64(j_blk + part_j(k.sh(), f, BS, pctx, 0));
         area_copy_dev<BS, NW>(f, k.snap(), r, c, 1);
-        set_decoded_wg<NW>(f, r, c, n4, 0);
-        long long j_split = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 3) * f->rdmult + 256) >> 9);
+        long long j_split = uni64(part_j(k.sh(), f, BS, pctx, 3));
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (!(j_split < j_none) || DBG_IS(f, 7)) break;
@@ -1354,7 +1388,11 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           if (rr >= f->mi_rows || cc >= f->mi_cols) continue;
           sub_j[q] = uni64(blk_eval<MAXN, BS - 1, NW>(k, rr, cc, j_none - j_split));
           j_split += sub_j[q];
-          if (BS - 1 >= BS_8) j_split += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), rr, cc, BS - 1, 0) * f->rdmult + 256) >> 9);
+          if (BS - 1 >= BS_8) {
+            // the child's own partition symbol (NONE): above / left of it lie the node's outer neighbours or a sibling of its own size (never narrower / lower)
+            const int cctx = part_ctx_of(BS - 1, (q >> 1) ? 1 : nb.availU, (q & 1) ? 1 : nb.availL, (q >> 1) ? BS - 1 : ((q & 1) ? nb.a1 : nb.a0), (q & 1) ? BS - 1 : ((q >> 1) ? nb.l1 : nb.l0));
+            j_split += uni64(part_j(k.sh(), f, BS - 1, cctx, 0));
+          }
         }
         if constexpr (BS == 1) {
           // PARTITION_HORZ / PARTITION_VERT (two 8x4 / 4x8 blocks) against the best of NONE / SPLIT so far (oracle rd_partition)
@@ -1362,26 +1400,23 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           long long j_best = j_none; int have_split = 0, rect_won = 0;
           if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
           {
-            set_decoded_wg<NW>(f, r, c, n4, 0);
-            long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 1) * f->rdmult + 256) >> 9);
+            long long j = uni64(part_j(k.sh(), f, BS, pctx, 1));
             for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
             if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
           }
           {
-            set_decoded_wg<NW>(f, r, c, n4, 0);
-            long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 2) * f->rdmult + 256) >> 9);
+            long long j = uni64(part_j(k.sh(), f, BS, pctx, 2));
             for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
             if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
           }
-          if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return 1; }   // 1: the later siblings' trial results are stale
+          if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); return 1; }   // 1: the later siblings' trial results are stale
           if (have_split) area_copy_dev<BS, NW>(f, split_snap, r, c, 0);
         }
         if (j_split < j_none && !DBG_IS(f, 7) && !DBG_IS(f, 8) && !(DBG_IS(f, 10) && BS == 1)) do_split = 1;
-        else { area_copy_dev<BS, NW>(f, k.snap(), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
+        else { area_copy_dev<BS, NW>(f, k.snap(), r, c, 0); }
       }
     }
     if (do_split) {
-      set_decoded_wg<NW>(f, r, c, n4, 0);
       int chain = !must_split && !DBG_IS(f, 11);      // the four trial results are in place until a sibling decides to split
 #pragma unroll
       for (int q = 0; q < 4; q++)
@@ -1398,11 +1433,10 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+  static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
-    if (known_j >= 0) { set_decoded_wg<NW>(f, r, c, 1, 1); return 0; }
-    set_decoded_wg<NW>(f, r, c, 1, 0);
+    if (known_j >= 0) return 0;
     blk_eval<MAXN, 0, NW>(k, r, c);
     return 0;
   }
@@ -1417,25 +1451,25 @@ template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(i
   return o;
 }
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
-  static __device__ MI_K1_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+  static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
     const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
     const int must_split = px > f->part_max || !has_rows || !has_cols;
     const int can_split = px > f->part_min || must_split;
-    set_decoded_wg<NW>(f, r, c, n4, 0);
     long long j_none = J_INF;
+    int pctx = 0;
+    if (!must_split) { const PartNb nb = part_neighbours<BS>(f, k.t(), r, c, false); pctx = part_ctx_of(BS, nb.availU, nb.availL, nb.a0, nb.l0); }
     if constexpr (BS <= MAXBS) {
       if (!must_split) {
         j_none = uni64(blk_eval<MAXN, BS, NW>(k, r, c));
-        j_none += uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 0) * f->rdmult + 256) >> 9);
+        j_none += uni64(part_j(k.sh(), f, BS, pctx, 0));
         if (!can_split) return j_none;
         area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 1);
-        set_decoded_wg<NW>(f, r, c, n4, 0);
       }
     }
-    long long j_split = must_split ? 0 : uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 3) * f->rdmult + 256) >> 9);
+    long long j_split = must_split ? 0 : uni64(part_j(k.sh(), f, BS, pctx, 3));
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
       if (!must_split && j_split >= j_none) break;
@@ -1450,30 +1484,27 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       long long j_best = j_none; int have_split = 0, rect_won = 0;
       if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
       {
-        set_decoded_wg<NW>(f, r, c, n4, 0);
-        long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 1) * f->rdmult + 256) >> 9);
+        long long j = uni64(part_j(k.sh(), f, BS, pctx, 1));
         for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
         if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
       }
       {
-        set_decoded_wg<NW>(f, r, c, n4, 0);
-        long long j = uni64(((long long)partition_rate_dev(k.cost(), f, k.t(), r, c, BS, 2) * f->rdmult + 256) >> 9);
+        long long j = uni64(part_j(k.sh(), f, BS, pctx, 2));
         for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
         if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
       }
-      if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_best; }
-      if (have_split) { area_copy_dev<BS, NW>(f, split_snap, r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); return j_split; }
+      if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); return j_best; }
+      if (have_split) { area_copy_dev<BS, NW>(f, split_snap, r, c, 0); return j_split; }
     }
     if (must_split || j_split < j_none) return j_split;
-    if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); set_decoded_wg<NW>(f, r, c, n4, 1); }
+    if constexpr (BS <= MAXBS) { area_copy_dev<BS, NW>(f, k.snap() + snap_level_off<MAXN>(BS, MAXBS), r, c, 0); }
     return j_none;
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+  static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
-    set_decoded_wg<NW>(f, r, c, 1, 0);
     return uni64(blk_eval<MAXN, 0, NW>(k, r, c));
   }
 };
@@ -1545,6 +1576,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     if (tj.frame != cur_frame) {
       for (int i = threadIdx.x; i < FRAMEDEV_K1_BYTES / 4; i += 64 * NW) ((LDS uint32_t *)lf)[i] = ((const uint32_t *)gf)[i];   // only the head: K1 never reads the tail through `lf`
       load_coef_cost(k.cc_base(), gf->cost, MAXBS, threadIdx.x, 64 * NW);
+      load_part_cost(k.sh(), gf->cost, (int)threadIdx.x);
       cur_frame = tj.frame;
     }
     if (job != cur_job) {
@@ -1562,6 +1594,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
       const uint16_t *tc = gf->tile_cost + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * CDF_TOTAL;
       if (threadIdx.x == 0) lf->cost = tc;
       load_coef_cost(k.cc_base(), tc, MAXBS, threadIdx.x, 64 * NW);
+      load_part_cost(k.sh(), tc, (int)threadIdx.x);
       WG_SYNC();
     }
     const int row0 = k.t()->mi_row_start, row1 = k.t()->mi_row_end, col0 = k.t()->mi_col_start, col1 = k.t()->mi_col_end;
