@@ -45,6 +45,17 @@ static void kmeans(const uint32_t *cnt, const uint64_t *wsum, int k, int *c) {
   }
 }
 
+/* The quantiser index of a segment whose scale lies `dev` (1/256 octave) above the frame's mean scale: the index (>= 1) whose AC step is nearest, in the log
+ * domain and with the lower index on ties, to base_step / sqrt(scale / mean).  Exported for tests/test_independent_checks.py (checked against a float restatement). */
+int av1o_seg_qidx_for_dev(int base_q_idx, int bd, int dev) {
+  const int16_t *ac = bd == 8 ? av1_ac_q8 : av1_ac_q10;
+  const int target = av1o_ilog2_q11((uint32_t)ac[base_q_idx]) - dev * 4;    /* Q11: minus half the scale's log */
+  int qi = 1, best = 1 << 30;
+  for (int q = 1; q < 256; q++) { const int d = iabs(av1o_ilog2_q11((uint32_t)ac[q]) - target); if (d < best) { best = d; qi = q; } }
+  return qi;
+}
+int av1o_ac_step(int bd, int qidx) { return (bd == 8 ? av1_ac_q8 : av1_ac_q10)[iclamp(qidx, 0, 255)]; }
+
 void av1o_segmentation(Av1oFrame *f) {
   f->seg_n = 0;
   for (int i = 0; i < 8; i++) { f->seg_qidx[i] = f->base_q_idx; for (int p = 0; p < 3; p++) { f->seg_dcq[i][p] = f->dc_q[p]; f->seg_acq[i][p] = f->ac_q[p]; } }
@@ -56,7 +67,7 @@ void av1o_segmentation(Av1oFrame *f) {
   for (int b = 0; b < AV1O_SEG_BINS; b++) if (cnt[b + 1]) { if (bmin < 0) bmin = b; bmax = b; }
   for (int b = 0; b < AV1O_SEG_BINS; b++) { wsum[b + 1] = wsum[b] + (uint64_t)b * cnt[b + 1]; cnt[b + 1] += cnt[b]; }
   const uint32_t n = cnt[AV1O_SEG_BINS];
-  if (bmin == bmax || n < 2) { free(cnt); free(wsum); return; }            /* one scale everywhere (flat image, Tune::Psnr): no segmentation */
+  if (bmin == bmax || n < 2 || getenv("AV1O_NO_SEGMENTATION")) { free(cnt); free(wsum); return; }            /* one scale everywhere (flat image, Tune::Psnr): no segmentation; the environment switch: ablation runs of the tests only */
   const int mean = (int)((wsum[AV1O_SEG_BINS] + n / 2) / n);
   int best_k = 0, best_c[8]; uint64_t best_var = 0;
   for (int k = 8; k >= 3; k--) {
@@ -70,13 +81,9 @@ void av1o_segmentation(Av1oFrame *f) {
   }
   /* quantiser index per segment: nearest step (log domain, lower index on ties) to base / sqrt(scale / mean scale) */
   const int16_t *ac = f->bd == 8 ? av1_ac_q8 : av1_ac_q10, *dc = f->bd == 8 ? av1_dc_q8 : av1_dc_q10;
-  const int lbase = av1o_ilog2_q11((uint32_t)ac[f->base_q_idx]);
   f->seg_n = best_k; f->seg_mean = mean;
   for (int i = 0; i < best_k; i++) {
-    const int dev = best_c[best_k - 1 - i] - mean;                            /* 1/256 octave */
-    const int target = lbase - dev * 4;                                       /* Q11: minus half the scale's log */
-    int qi = 1; int bd_ = 1 << 30;
-    for (int q = 1; q < 256; q++) { const int d = iabs(av1o_ilog2_q11((uint32_t)ac[q]) - target); if (d < bd_) { bd_ = d; qi = q; } }
+    const int qi = av1o_seg_qidx_for_dev(f->base_q_idx, f->bd, best_c[best_k - 1 - i] - mean);   /* deviation from the mean scale in 1/256 octave */
     f->seg_qidx[i] = qi;
     for (int p = 0; p < f->np; p++) {
       f->seg_dcq[i][p] = dc[iclamp(qi + f->dc_qi[p] - f->base_q_idx, 0, 255)];

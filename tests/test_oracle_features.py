@@ -151,3 +151,44 @@ def test_quality_plausibility_against_libaom(oracle):
     theirs = psnr(np.array(PIL_Image.open(io.BytesIO(best[1])).convert('RGB')), img)
     assert 0.7 < best[0] / len(data) < 1.4
     assert ours > theirs - 2.5 and ours > 30.0, (ours, theirs, len(data), best[0])
+
+
+def test_segmentation_on_off_against_libaom_band(oracle):
+    """what `SegmentationLevel::Simple` (as recalled) costs or buys on this encoder.  The same pictures with the fit on and off (AV1O_NO_SEGMENTATION,
+    an ablation switch of the oracle): both must stay inside the libaom plausibility band, and the on/off difference is reported in BASELINE.md section 5
+    (bytes at equal quantiser: segmentation redistributes bits from busy to flat regions, so PSNR alone is not its yardstick)."""
+    import io, subprocess, json
+    PIL_Image = pytest.importorskip('PIL.Image')
+    import PIL._avif as _avif
+    if not _avif.encoder_codec_available('aom'):
+        pytest.skip('no aom encoder in Pillow')
+    code = ("import sys, json, io, numpy as np; sys.path.insert(0, %r)\n"
+            "from tests.helpers import oracle\nfrom cavif_rs_amd.synth import synth_image\nfrom PIL import Image\n"
+            "out = []\n"
+            "for idx in (2, 7):\n"
+            "    img = synth_image(384, 216, index=idx)\n"
+            "    data, cs, _ = oracle.ravif_encode(img, quality=80, speed=4, depth=8)\n"
+            "    dec = np.array(Image.open(io.BytesIO(data)).convert('RGB'))\n"
+            "    out.append([len(data), float(10 * np.log10(255.0 ** 2 / np.mean((dec.astype(float) - img.astype(float)) ** 2)))])\n"
+            "print(json.dumps(out))\n") % ROOT
+    res = {}
+    for label, env in (('on', {}), ('off', {'AV1O_NO_SEGMENTATION': '1'})):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[label] = json.loads(p.stdout.strip().splitlines()[-1])
+    sys.path.insert(0, ROOT)
+    from cavif_rs_amd.synth import synth_image
+    for k, idx in enumerate((2, 7)):
+        img = synth_image(384, 216, index=idx)
+        (b_on, p_on), (b_off, p_off) = res['on'][k], res['off'][k]
+        assert b_on != b_off                                                  # the switch really switches
+        assert 0.9 < b_on / b_off < 1.1 and abs(p_on - p_off) < 1.0, (b_on, b_off, p_on, p_off)
+        best = None
+        for aq in range(40, 96, 5):
+            b = io.BytesIO(); PIL_Image.fromarray(img, 'RGB').save(b, format='AVIF', quality=aq, speed=8, codec='aom', subsampling='4:4:4')
+            if best is None or abs(b.tell() - b_on) < abs(best[0] - b_on):
+                best = (b.tell(), b.getvalue())
+        dec = np.array(PIL_Image.open(io.BytesIO(best[1])).convert('RGB'))
+        theirs = 10 * np.log10(255.0 ** 2 / np.mean((dec.astype(float) - img.astype(float)) ** 2))
+        assert min(p_on, p_off) > theirs - 2.5, (p_on, p_off, theirs)
+        print('segmentation on/off, image %d: %d / %d bytes (%+.2f %%), PSNR %.2f / %.2f dB; libaom at %d bytes: %.2f dB' % (idx, b_on, b_off, 100.0 * (b_on - b_off) / b_off, p_on, p_off, best[0], theirs))
