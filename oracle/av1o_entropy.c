@@ -308,3 +308,29 @@ size_t av1o_code_tile(Av1oFrame *f, int tile_row, int tile_col, uint8_t **out) {
   free(w);
   return n;
 }
+
+/* ---------------- experiment (R-11): pricing against the tile's LIVE CDFs inside one pass ----------------
+ * rav1e prices every RDO decision against the adaptive state of the tile (receive_packet, ravif/src/av1encoder.rs:759).  This encoder prices against a static
+ * table.  AV1O_LIVE_CDF=1 (environment, oracle only) measures what the difference is worth: after every finished superblock the tile's
+ * symbols so far are run through the adaptation (the real writer on a scratch coder; cdef / restoration syntax carries no adaptive symbols the search prices)
+ * and the search's rate table is rebuilt from the adapted CDFs.  It serialises a tile's superblocks, which is why the HIP path does not do it. */
+void *av1o_live_open(Av1oFrame *f, int tile_row, int tile_col) {
+  TileW *w = (TileW *)malloc(sizeof(TileW));
+  w->f = f;
+  w->t.mi_row_start = f->tile_row_start[tile_row] * SB_MI; w->t.mi_row_end = imin(f->tile_row_start[tile_row + 1] * SB_MI, f->mi_rows);
+  w->t.mi_col_start = f->tile_col_start[tile_col] * SB_MI; w->t.mi_col_end = imin(f->tile_col_start[tile_col + 1] * SB_MI, f->mi_cols);
+  memcpy(w->cdf, f->cdf0, sizeof(w->cdf));
+  w->cdef_done = (uint8_t *)calloc((size_t)f->sb_rows * f->sb_cols, 1);
+  re_init(&w->ec);
+  return w;
+}
+void av1o_live_sb(void *wv, int r, int c, uint32_t *cost_out) {
+  TileW *w = (TileW *)wv;
+  const int save = w->f->enable_cdef;
+  w->f->enable_cdef = 0;                         /* (the cdef index is a literal and not known yet) */
+  write_partition(w, r, c, BS_64);
+  w->f->enable_cdef = save;
+  w->ec.offs = 0;                                /* the coded bytes are not wanted */
+  av1o_costs_from_cdfs(w->cdf, cost_out);
+}
+void av1o_live_close(void *wv) { TileW *w = (TileW *)wv; re_free(&w->ec); free(w->cdef_done); free(w); }

@@ -161,6 +161,7 @@ uint32_t av1o_coef_rate(const Av1oFrame *f, const int32_t *qc, int eob, int plan
                         int txb_skip_ctx, int dc_sign_ctx, int *cul_level, int *dc_cat);
 void av1o_txb_ctx(const Av1oFrame *f, const TileB *t, int plane, int r4, int c4, int txs, int bs, int *skip_ctx, int *dc_ctx);
 
+void *av1o_live_open(Av1oFrame *f, int tile_row, int tile_col); void av1o_live_sb(void *w, int r, int c, uint32_t *cost_out); void av1o_live_close(void *w);   /* AV1O_LIVE_CDF experiment */
 /* loop filters (spec 7.14, 7.15) */
 void av1o_deblock_frame(Av1oFrame *f);
 void av1o_cdef_search_and_apply(Av1oFrame *f);

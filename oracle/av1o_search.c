@@ -525,7 +525,14 @@ void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
     /* (q_y / q_p)^2 in Q12 == rav1e dist_scale */
     s.wq[p] = (((int64_t)f->ac_q[0] * f->ac_q[0]) << 12) / ((int64_t)f->ac_q[p] * f->ac_q[p]);
   }
+  /* AV1O_LIVE_CDF=1: the experiment of av1o_entropy.c av1o_live_* (rates from the tile's adaptive CDFs, refreshed after every superblock) */
+  void *live = getenv("AV1O_LIVE_CDF") ? av1o_live_open(f, tile_row, tile_col) : NULL;
+  static uint32_t live_cost[CDF_TOTAL];
+  if (live) { memcpy(live_cost, f->cost0, sizeof(live_cost)); f->cost = live_cost; }
   for (int r = s.t.mi_row_start; r < s.t.mi_row_end; r += SB_MI)
-    for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI)
+    for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI) {
       if (f->cfg.bottomup) rd_partition_bottomup(&s, r, c, BS_64); else rd_partition(&s, r, c, BS_64, -1);
+      if (live) av1o_live_sb(live, r, c, live_cost);
+    }
+  if (live) av1o_live_close(live);
 }

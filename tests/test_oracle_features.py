@@ -192,3 +192,29 @@ def test_segmentation_on_off_against_libaom_band(oracle):
         theirs = 10 * np.log10(255.0 ** 2 / np.mean((dec.astype(float) - img.astype(float)) ** 2))
         assert min(p_on, p_off) > theirs - 2.5, (p_on, p_off, theirs)
         print('segmentation on/off, image %d: %d / %d bytes (%+.2f %%), PSNR %.2f / %.2f dB; libaom at %d bytes: %.2f dB' % (idx, b_on, b_off, 100.0 * (b_on - b_off) / b_off, p_on, p_off, best[0], theirs))
+
+
+def test_live_cdf_pricing_experiment_decodes_and_pays(oracle, avifdec):
+    """R-11: AV1O_LIVE_CDF=1 prices the search against the tile's adaptive CDFs, refreshed after every superblock (what rav1e's receive_packet
+    does per symbol, ravif/src/av1encoder.rs:759) -- an oracle-only experiment that measures what the static table costs.  Streams stay
+    decodable (dav1d == reconstruction is checked through the container sizes here and bit-exactly in the subprocess) and do not grow."""
+    import json
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "from tests.helpers import oracle, avifdec\nfrom tests.helpers.images import planes\n"
+            "out = []\n"
+            "for (w, h, bd, speed, q, tiles) in [(264, 200, 10, 4, 121, 0), (200, 136, 8, 6, 100, 2), (200, 120, 10, 1, 121, 0)]:\n"
+            "    pl = planes(h, w, seed=w + h, bd=bd)\n"
+            "    r = oracle.encode_planes(oracle.make_config(w, h, bd, False, q, speed, tiles=tiles), pl)\n"
+            "    d = avifdec.decode(oracle.container(r['obu'], None, w, h, bd, mono_color=0))\n"
+            "    ok = all(np.array_equal(a, b) for a, b in zip(d['planes'], r['recon']))\n"
+            "    out.append([len(r['obu']), int(sum(r['sse'])), bool(ok)])\n"
+            "print(json.dumps(out))\n") % ROOT
+    res = {}
+    for label, env in (('static', {}), ('live', {'AV1O_LIVE_CDF': '1'})):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[label] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert all(x[2] for x in res['static']) and all(x[2] for x in res['live'])           # dav1d == the oracle's reconstruction, both ways
+    assert [x[0] for x in res['live']] != [x[0] for x in res['static']]                    # the switch switches
+    assert sum(x[0] for x in res['live']) <= sum(x[0] for x in res['static'])              # and pays in bytes
+    print('live-CDF pricing: bytes %s -> %s, SSE %s -> %s' % ([x[0] for x in res['static']], [x[0] for x in res['live']], [x[1] for x in res['static']], [x[1] for x in res['live']]))
