@@ -13,7 +13,7 @@ holds DIFFERENT images.  Rank 0 prints one JSON line; `roofline` is for the domi
 a launch with nothing else in flight, `cpu_baseline` is the scalar C oracle (a port, not the reference) on this box's host
 cores, `cpu_baseline_standin` is libaom (through Pillow) at its matching speed on the same inputs -- both stand-ins: the
 reference itself (rav1e) cannot be built in this image.  `--secondary` adds single-image latency lines for BASELINE
-configs 2, 3 and 5; `--end-to-end N` adds the PNG-file -> .avif-file clock of the command line on N synthetic PNGs.
+configs 2, 3 and 5; `--end-to-end N` adds the PNG-file -> .avif-file clock of the command line on N synthetic PNGs (256 by default at one GPU).
 """
 import argparse
 import json
@@ -260,7 +260,7 @@ def main():
     ap.add_argument('--manifest', default=None, help='sha256 manifest to check the outputs against (default: tests/golden/bench_manifest.json, the default workload)')
     ap.add_argument('--no-pcie-loop', action='store_true', help='skip the second timed loop (H2D inside the region)')
     ap.add_argument('--secondary', action='store_true', help='also time BASELINE configs 2, 3 and 5 (single images; config 5 takes a while)')
-    ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 96 at N=1 GPU, 0 = skip)')
+    ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
     ap.add_argument('--pipeline', type=int, default=3, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 3 measured best on MI355X)')
     args = ap.parse_args()
 
@@ -435,7 +435,7 @@ def main():
                 single_image_line(m, "config 3: 1 x 4096x4096 RGBA (alpha plane = second frame), speed 4, q80", 4096, 4096, True, 3, 4, 80.0, aq, 10, device),
                 single_image_line(m, "config 5: 1 x 7680x4320 RGB, speed 1, q80, 10-bit (reference asks for <= 7 tiles -> 8)", 7680, 4320, False, 5, 1, 80.0, aq, 10, device, reps=1),
             ]
-        n_e2e = args.end_to_end if args.end_to_end >= 0 else (96 if world == 1 else 0)
+        n_e2e = args.end_to_end if args.end_to_end >= 0 else (256 if world == 1 else 0)
         if n_e2e:
             out["end_to_end"] = end_to_end(n_e2e, w, h, args.speed, args.quality, args.depth)
         print(json.dumps(out), flush=True)

@@ -75,7 +75,7 @@ __device__ inline void inv_txfm64_add_dev(const LDS int32_t *dq, LDS int32_t *tb
 }
 
 template <int NW>
-__device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int c, long long budget = J_INF) {
+__device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int c, long long budget = J_INF) {
   static_assert(NW == 4, "the 64x64 level deals its candidates to four wavefronts");
   constexpr int MAXN = 32, BS = 4, n = 64, n4 = 16, log2w = 6, nn = n * n;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();

@@ -8,9 +8,7 @@
 #include "av1_tables.h"
 
 // rav1e rdo_tx_size_type searches tx_depth 0..2 (rdo_tx_depth = 2) when rdo_tx_decision is on; 1 = one level only (oracle AV1O_TX_DEPTH_MAX)
-#ifndef MI_TX_DEPTH_MAX
 #define MI_TX_DEPTH_MAX 2
-#endif
 // Block / transform size codes 5 (4x8) and 6 (8x4) appear in m_bsize / m_txsize: PARTITION_HORZ / PARTITION_VERT of 8x8 nodes (dev_rect.h).
 #define MI_MAX_TILE_COLS 64
 #define MI_MAX_TILE_ROWS 64

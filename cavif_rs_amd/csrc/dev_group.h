@@ -55,6 +55,133 @@ __device__ __forceinline__ int group_transpose4(int v) { return __shfl(v, (LANE 
 
 struct GroupRes { int eob, cul, dcc, sse; uint32_t rate; };
 
+// A 4x4 candidate from its forward coefficients on, WITHOUT leaving the registers: the group's 16 lanes hold the block in raster order (lane gl = position gl), so
+// the quantiser, the level-map contexts and the rate work on the lane's own coefficient and on its neighbours' levels fetched with DPP row shifts (right: +1 .. +3,
+// below: +4, +8, +12, diagonal: +5; a shift that leaves the 16-lane row reads zero like the level map's padding did) -- where the generic form wrote coefficients,
+// levels and a padded level map to LDS and read them back through the scan order (three round trips and a map reset per candidate).  The scan index a rate context
+// needs is the inverse scan of the lane's position (a packed constant for the default scan, arithmetic for the row / column scans).  Sums over the block do not depend
+// on the lane order, so every result is the generic path's bit for bit.  LDS is touched for the cost tables and for the two things the caller reads: levels and pixels.
+template <int CTRL> __device__ __forceinline__ int dpp_row_z(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }   // source outside the row: 0
+template <typename FP>
+__device__ __forceinline__ void eval_group4_tail(const CoefCost &cc, FP f, LDS GroupBuf8 *gb, int coef, int t_src, int t_rec, int tidx, int plane, int txs, int txtype, int ck, int rk,
+                                                 int skip_ctx, int dc_ctx, int tx_off, uint32_t tx_cost, int psy_sv, int psy_act, GroupRes *res) {
+  constexpr int N = 4, nc = 16;
+  const int gl = GROUP_LANE, row = gl >> 2, col = gl & 3, bd = f->bd;
+  const int dcq = f->dc_q[plane], acq = f->ac_q[plane];
+  const uint32_t dc_recip = f->dc_recip[plane], ac_recip = f->ac_recip[plane];
+  const int cls = tx_class_of(txtype), pt = plane > 0, txs_ctx = txs;
+  const uint32_t dc_off = (uint32_t)(dcq * 109 / 256), off0 = (uint32_t)(acq * 98 / 256), off1 = (uint32_t)(acq * 109 / 256), off_eob = (uint32_t)(acq * 88 / 256);
+  const uint32_t thr = (uint32_t)acq - off_eob, uq = (uint32_t)acq;
+  // scan index of raster position gl: inverse of av1_default_scan_4x4 (2-D), the position itself (row scan), the transposed position (column scan)
+  const int c = cls == TXC_2D ? lut4(0xFEA9DB83C7426510ULL, gl) : (cls == TXC_VERT ? gl : col * 4 + row);
+  const uint32_t mag = (uint32_t)iabs_(coef); const int neg = coef < 0;
+  const int last = row_max_i32((c >= 1 && mag >= thr) ? c + 1 : 0);
+  int l0 = 0;
+  if (gl == 0) {                                                   // the DC level (scan position 0 = raster position 0 in every scan)
+    const uint32_t x0 = mag + dc_off;
+    uint32_t l0u = __umulhi(x0, dc_recip);
+    if (x0 - l0u * (uint32_t)dcq >= (uint32_t)dcq) l0u++;
+    l0 = (int)l0u;
+  }
+  l0 = row_max_i32(l0);
+  int eob = last;
+  if (eob == 0) eob = l0 ? 1 : 0;
+  int lv = 0;
+  if (c < eob) {
+    if (c == 0) lv = l0;
+    else {
+      uint32_t lv0 = __umulhi(mag, ac_recip);
+      if (mag - lv0 * uq >= uq) lv0++;
+      const uint32_t off = lv0 > 0 ? off1 : off0;
+      lv = (int)lv0 + ((mag + off) >= (lv0 + 1) * uq);
+    }
+  }
+  gb->qc[gl] = neg ? -lv : lv;
+  int dq;
+  {
+    const int dmx = (1 << (7 + bd)) - 1, dmn = -(1 << (7 + bd));
+    uint32_t m = (uint32_t)lv * (uint32_t)(gl == 0 ? dcq : acq);
+    m &= 0xFFFFFF;
+    const int v = neg ? -(int)m : (int)m;
+    dq = v < dmn ? dmn : (v > dmx ? dmx : v);
+  }
+  // neighbours' levels (clipped at 15: the contexts clip at 3 or 15), zero beyond the block
+  const int l15 = imin_(lv, 15);
+  // (every lane executes every shift -- a lane that skipped one would not lend its value either -- and masks what wrapped into the next row of the block afterwards)
+  const int s1 = dpp_row_z<0x101>(l15), s2 = dpp_row_z<0x102>(l15), s3 = dpp_row_z<0x103>(l15), s5 = dpp_row_z<0x105>(l15);
+  const int b1 = dpp_row_z<0x104>(l15), b2 = dpp_row_z<0x108>(l15), b3 = dpp_row_z<0x10C>(l15);
+  const int r1 = col < 3 ? s1 : 0, r2 = col < 2 ? s2 : 0, r3 = col < 1 ? s3 : 0, d1 = col < 3 ? s5 : 0;
+  uint32_t head = cc.txb[(txs_ctx * 13 + skip_ctx) * CDF_TXB_SKIP_STRIDE + (eob == 0)];
+  int bits = 0, cul = 0, dcc = 0;
+  if (eob > 0) {
+    if (tx_off >= 0) head += tx_cost;
+    const int eob_pt = eob_to_pt(eob);
+    head += cc.eobpt[0][(pt * 2 + (cls == TXC_2D ? 0 : 1)) * CDF_EOB_PT_16_STRIDE + eob_pt - 1];
+    if (eob_pt >= 3) {
+      const int nb = eob_pt - 2, rem = eob - ((1 << (eob_pt - 2)) + 1), hi = (rem >> (nb - 1)) & 1;
+      head += cc.eobx[((txs_ctx * 2 + pt) * 9 + (eob_pt - 3)) * CDF_EOB_EXTRA_STRIDE + hi];
+      head += 512u * (uint32_t)(nb - 1);
+    }
+    if (c < eob) {
+      const int level = lv;
+      if (c == eob - 1) {
+        const int ctx = c == 0 ? 0 : (c <= nc / 8 ? 1 : (c <= nc / 4 ? 2 : 3));
+        bits += cc.beob[((txs_ctx * 2 + pt) * 4 + ctx) * CDF_COEFF_BASE_EOB_STRIDE + imin_(level, 3) - 1];
+      } else {
+        // base_ctx (dev_rate.h) on the fetched neighbours
+        int mag2 = imin_(r1, 3) + imin_(b1, 3), ctx;
+        if (cls == TXC_2D) {
+          mag2 += imin_(d1, 3) + imin_(r2, 3) + imin_(b2, 3);
+          const int m = imin_((mag2 + 1) >> 1, 4);
+          ctx = (row == 0 && col == 0) ? 0 : (row + col < 2 ? m + 1 : (row + col < 4 ? m + 6 : m + 21));
+        } else if (cls == TXC_VERT) {
+          mag2 += imin_(b2, 3) + imin_(b3, 3);                    // (the fifth tap lies four rows below: outside a 4x4 block)
+          const int m = imin_((mag2 + 1) >> 1, 4);
+          ctx = m + (row == 0 ? 26 : (row == 1 ? 31 : 36));
+        } else {
+          mag2 += imin_(r2, 3) + imin_(r3, 3);
+          const int m = imin_((mag2 + 1) >> 1, 4);
+          ctx = m + (col == 0 ? 26 : (col == 1 ? 31 : 36));
+        }
+        bits += cc.base[((txs_ctx * 2 + pt) * 42 + ctx) * CDF_COEFF_BASE_STRIDE + imin_(level, 3)];
+      }
+      if (level > 2) {
+        // br_ctx (dev_rate.h)
+        int mg = r1 + b1, ctx;
+        if (cls == TXC_2D) { mg = imin_((mg + d1 + 1) >> 1, 6); ctx = c == 0 ? mg : ((row < 2 && col < 2) ? mg + 7 : mg + 14); }
+        else if (cls == TXC_HORIZ) { mg = imin_((mg + r2 + 1) >> 1, 6); ctx = c == 0 ? mg : (col == 0 ? mg + 7 : mg + 14); }
+        else { mg = imin_((mg + b2 + 1) >> 1, 6); ctx = c == 0 ? mg : (row == 0 ? mg + 7 : mg + 14); }
+        const int off = ((imin_(txs_ctx, 3) * 2 + pt) * 21 + ctx) * CDF_COEFF_BR_STRIDE;
+        int rem = level - 3;
+        for (int idx = 0; idx < 4; idx++) { const int s2 = imin_(rem, 3); bits += cc.br[off + s2]; rem -= s2; if (s2 < 3) break; }
+      }
+      if (level) {
+        if (c == 0) { bits += cc.dcs[(pt * 3 + dc_ctx) * CDF_DC_SIGN_STRIDE + neg]; dcc = neg ? 1 : 2; }
+        else bits += 512;
+        if (level > 14) { const int len = 32 - __clz(level - 14); bits += 512 * (2 * len - 1); }
+      }
+      cul += level;
+    }
+  }
+  bits = row_sum_i32(bits);
+  cul = row_sum_i32(imin_(cul, 1 << 20));
+  dcc = row_max_i32(dcc);
+  res->eob = eob; res->cul = imin_(cul, 63); res->dcc = dcc; res->rate = head + (uint32_t)bits;
+  // inverse transform + reconstruction (this lane's sample sits at the transposed index, see tx4_tab)
+  if (eob > 0) {
+    const int cbits = imax_(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
+    int v = iclamp_(tx4_inv(dq, rk), cmin, cmax);                  // row pass (no intermediate shift at this size)
+    v = group_transpose4(v);
+    t_rec = iclamp_(t_rec + round2_(tx4_inv(v, ck), 4), 0, (1 << bd) - 1);
+  }
+  gb->rec[tidx] = (uint16_t)t_rec;
+  WAVE_SYNC();
+  const int d = t_src - t_rec;
+  const int s = row_sum_i32(__mul24(d, d));
+  if (psy_sv >= 0) { const int sd = row_sum_i32(t_rec), qd = row_sum_i32(__mul24(t_rec, t_rec)); res->sse = psy_cell_dist((uint32_t)s, (uint32_t)sd, (uint32_t)qd, (uint32_t)psy_sv, (uint32_t)psy_act, 4, bd); }
+  else res->sse = (int)(((unsigned long long)(uint32_t)s * (uint32_t)psy_act + 8192) >> 14);
+}
+
 // All arguments may differ between the four groups of the wave (they are uniform inside a group).  `live` = false groups
 // run the same code on their own buffers with a harmless input (keeps the wave converged); their result is ignored.
 template <int N, typename CostPtr>
@@ -70,12 +197,11 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
   [[maybe_unused]] const int tidx = ((gl & 3) << 2) | (gl >> 2);
   if constexpr (N == 4) {
     t_src = src[tidx]; t_rec = pred[tidx];
-    gb->rec[tidx] = (uint16_t)t_rec;
-    for (int i = gl; i < 36; i += 16) ((LDS uint32_t *)gb->lev)[i] = 0;
     int v = tx4_fwd((int)((uint32_t)(t_src - t_rec) << 2), ck);    // column pass: the quad holds one column
     v = group_transpose4(v);
-    gb->cbuf[gl] = tx4_fwd(v, rk);                                  // row pass: the quad holds one row; the lane's coefficient is raster position gl
-    WAVE_SYNC();
+    const int coef = tx4_fwd(v, rk);                                // row pass: the quad holds one row; the lane's coefficient is raster position gl
+    eval_group4_tail(cc, f, gb, coef, t_src, t_rec, tidx, plane, txs, txtype, ck, rk, skip_ctx, dc_ctx, tx_off, tx_cost, psy_sv, psy_act, res);
+    return;
   } else {
   // ---- residual, reconstruction seed, level-map reset
 #pragma unroll

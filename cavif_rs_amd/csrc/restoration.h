@@ -203,10 +203,7 @@ __device__ __forceinline__ int lr_chunks(const FrameDev *f, int ur, int uc, int 
 // One candidate of the search: (unit, plane, parameter set) -> least-squares weights, activity-scaled SSE, RD cost.
 // grid = (units, planes * nsets, frames).  Results go to f->lr_cand[(plane * units + unit) * 16 + set index].
 struct LrCand { long long cost; int xq0, xq1; };
-#ifndef LR_WG_PER_CU
-#define LR_WG_PER_CU 4
-#endif
-__global__ __launch_bounds__(256, LR_WG_PER_CU) void lr_search_kernel(const FrameDev *__restrict__ frames) {
+__global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__restrict__ frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int nsets = f->sgr_full ? 16 : 4;
   const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;

@@ -259,14 +259,7 @@ __device__ __forceinline__ void k4_lit(TileWriter *w, uint32_t v, int nbits) {  
 #define K4PH(i) do {} while (0)
 #define K4CNT(i, n) do {} while (0)
 #endif
-#ifndef MI_K4_UNIFORM
-#define MI_K4_UNIFORM 1
-#endif
-#if MI_K4_UNIFORM
-#define U_(v) uni32((int)(v))
-#else
-#define U_(v) ((int)(v))
-#endif
+#define U_(v) uni32((int)(v))                              /* wave-uniform values loaded from memory: pinned to SGPRs (the coder runs on the scalar unit) */
 
 // One transform block's symbols (levels + padded level map already staged in LDS).  (P) every lane derives the CDF rows (contexts) of its own
 // scan positions -- they depend only on the level map -- into LDS; (R) the records in coding order: the header symbols (lane 0), then per scan

@@ -20,16 +20,9 @@
 // The shape of the search's code, fixed explicitly (left to the inliner's cost model it flips with unrelated edits: with the block searches inlined into
 // separate partition functions K1 <2,4> went from 116 to 142 ms): the block searches are functions of their own -- entered with every argument in registers
 // and, not being tail-called, given LLVM's no-callee-saved-registers treatment --, the partition walkers are inlined into the kernel.
-#ifndef MI_K1_TRY_ATTR
 #define MI_K1_TRY_ATTR __attribute__((noinline, not_tail_called))
-#endif
-#ifndef MI_K1_INLINE
-#define MI_K1_INLINE
-#endif
 #define MI_K1_WALK_INLINE __forceinline__
-#ifndef MI_K1_WG_PER_CU
-#define MI_K1_WG_PER_CU 4
-#endif
+#define MI_K1_WG_PER_CU 4                            /* the 16x16 class: 40.9 KB of LDS and 128 VGPRs per workgroup -> exactly four per CU */
 #define WAVE_ID ((int)(threadIdx.x >> 6))
 #ifndef MI_PROFILE
 #define MI_PROFILE 0
@@ -325,7 +318,7 @@ template <int MAXN, int BS, int NW>
 // not_tail_called: with every argument in registers the calls would be marked `tail`, and LLVM's interprocedural register
 // allocation then refuses its no-callee-saved-registers treatment for this function (TargetFrameLowering::isSafeForNoCSROpt):
 // the prologue / epilogue would spill and reload 46 VGPRs + 34 SGPRs per call.
-__device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+__device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -484,10 +477,7 @@ __device__ MI_K1_INLINE MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
-#ifndef TRIALDBG
-#define TRIALDBG 0
-#endif
-  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx && !(TRIALDBG == 1 && BS == 1) && !(TRIALDBG == 2 && BS == 2) && TRIALDBG != 3;        // one-level-smaller luma transforms are tried after the mode decision
+  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx;        // one-level-smaller luma transforms are tried after the mode decision
   LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;
   LDS uint16_t *split_rec = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->split_rec;
   LDS uint16_t *spred = SH->spred;

@@ -1,4 +1,4 @@
-"""K4 (entropy coder) phase profile: needs a library built with -DMI_PROFILE=2 -DMI_K1_WG_PER_CU=3, pointed to by MI_AVIF_LIB."""
+"""K4 (entropy coder) phase profile: needs a library built with -DMI_PROFILE=2, pointed to by MI_AVIF_LIB."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import cavif_rs_amd as m
