@@ -103,40 +103,49 @@ __device__ inline void lr_load_window(LrLds &L, const FrameDev *f, int plane, co
   __syncthreads();
 }
 // Box filter process of a chunk (spec 7.17.3) in two steps:
-//   AB : per thread, the (sum of squares, sum) box sums of its positions of the (w + 2) x (h + 2) grid -> (A, B) of one parameter
-//        set (its s), into LDS.  Radius 2 (pass 0) weights rows of odd parity only, so only those rows are computed.
-//   F  : the 3x3 weighting of (A, B) -> filtered value of the thread's 16 samples (tid + 256 k, row-major over w x h).
+//   AB : the (sum of squares, sum) box sums of the (w + 2) x (h + 2) grid -> (A, B) of one parameter set (its s), into LDS.  Radius 2 (pass 0) weights rows of
+//        odd parity only, so only those rows are computed.
+//   F  : the 3x3 weighting of (A, B) -> filtered value of the thread's 16 samples.
+// Both steps walk ROW SEGMENTS (round 4): a thread owns a run of neighbouring positions of one row and slides its window along it -- the box sums as running sums
+// of column sums (5 + 5 window samples fetched per new position at radius 2 instead of 25, 3 instead of 9 at radius 1), the 3x3 weighting as running sums of the
+// (A, B) columns (3 + 3 fetched per sample instead of 9 + 9).  The kernel was bound by the LDS pipeline (SQ_LDS_IDX_ACTIVE = every cycle of its 12.7 ms,
+// profiles/r04_pmc_summary.json); the arithmetic -- integer sums -- and so every result is unchanged.
+// A thread's 16 samples: row tid / 4 of the chunk, columns 16 * (tid % 4) .. + 15 (a chunk is at most 64 x 64).
 // (Keeping the box sums in registers across the parameter sets of one unit was tried: 258 VGPRs, one wave per SIMD, no gain.)
-template <int R> struct LrRaw { static constexpr int NP = R == 2 ? 9 : 18; };
-template <int R> __device__ __forceinline__ bool lr_pos(const LrChunk &c, int k, int *pi, int *pj) {
-  const int aw = c.w + 2, ah = c.h + 2;
-  const int nrows = R == 2 ? (ah - (c.y0 & 1) + 1) >> 1 : ah;
-  const int pos = threadIdx.x + 256 * k;
-  if (pos >= nrows * aw) return false;
-  const int row = c.w == 64 ? pos / 66 : pos / aw;             // the usual chunk is 64 wide: division by a constant
-  *pj = pos - row * aw; *pi = R == 2 ? (c.y0 & 1) + 2 * row : row;           // pi = i + 1, pj = j + 1
-  return true;
-}
-// raw + map fused (nothing kept between parameter sets): (A, B) of one (radius, s) straight into LDS
+#define LR_SEG 11                                  /* positions per box-sum task: 66 = 6 x 11 */
 template <int R> __device__ inline void lr_box_AB(LrLds &L, const LrChunk &c, int sparam, int bd) {
-  constexpr int n = (2 * R + 1) * (2 * R + 1), one_by_n = ((1 << 12) + n / 2) / n;
+  constexpr int n = (2 * R + 1) * (2 * R + 1), one_by_n = ((1 << 12) + n / 2) / n, NC = LR_SEG + 2 * R;
   const int s2 = 2 * (bd - 8), s1 = bd - 8;
-#pragma unroll 2
-  for (int k = 0; k < LrRaw<R>::NP; k++) {
-    int pi, pj;
-    if (lr_pos<R>(c, k, &pi, &pj)) {
+  const int aw = c.w + 2, ah = c.h + 2;
+  const int nrows = R == 2 ? (ah - (c.y0 & 1) + 1) >> 1 : ah, nseg = (aw + LR_SEG - 1) / LR_SEG;
+  for (int task = threadIdx.x; task < nrows * nseg; task += 256) {
+    const int row = task / nseg, seg = task - row * nseg;
+    const int pi = R == 2 ? (c.y0 & 1) + 2 * row : row, pj0 = seg * LR_SEG;       // pi = i + 1, pj = j + 1
+    const uint16_t *wp = L.win + (pi + 2 - R) * LR_WP + pj0 + 2 - R;          // top-left sample of the first position's box
+    const int ncol = imin_(NC, aw - pj0 + 2 * R);                                  // window columns this segment touches (all inside the staged window)
+    uint32_t cs[NC], cq[NC];
+#pragma unroll
+    for (int x = 0; x < NC; x++) {
       uint32_t a = 0, b = 0;
-      const int wy = pi + 2, wx = pj + 2;
+      if (x < ncol) {
 #pragma unroll
-      for (int dy = -R; dy <= R; dy++)
+        for (int dy = 0; dy <= 2 * R; dy++) { const uint32_t v = wp[dy * LR_WP + x]; a += v * v; b += v; }
+      }
+      cq[x] = a; cs[x] = b;
+    }
 #pragma unroll
-        for (int dx = -R; dx <= R; dx++) { const uint32_t v = L.win[(wy + dy) * LR_WP + wx + dx]; a += v * v; b += v; }
-      const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
-      const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
-      const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
-      const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
-      const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
-      L.A[pi * LR_AP + pj] = (uint16_t)a2; L.B[pi * LR_AP + pj] = (b2 + (1u << 11)) >> 12;
+    for (int j = 0; j < LR_SEG; j++) {
+      if (pj0 + j < aw) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int dx = 0; dx <= 2 * R; dx++) { a += cq[j + dx]; b += cs[j + dx]; }
+        const uint32_t ar = s2 ? (a + (1u << (s2 - 1))) >> s2 : a, d = s1 ? (b + (1u << (s1 - 1))) >> s1 : b;
+        const uint32_t p = ar * (uint32_t)n > d * d ? ar * (uint32_t)n - d * d : 0;
+        const uint32_t z = (uint32_t)(((unsigned long long)p * (unsigned)sparam + (1u << 19)) >> 20);
+        const uint32_t a2 = z >= 255 ? 256 : L.a2tab[z];
+        const uint32_t b2 = (256 - a2) * b * (uint32_t)one_by_n;
+        L.A[pi * LR_AP + pj0 + j] = (uint16_t)a2; L.B[pi * LR_AP + pj0 + j] = (b2 + (1u << 11)) >> 12;
+      }
     }
   }
   __syncthreads();
@@ -145,26 +154,39 @@ template <int R> __device__ inline void lr_box_AB(LrLds &L, const LrChunk &c, in
 // samples << 4, at most 16 368 + rounding for 10-bit input) -- sixteen registers per thread instead of thirty-two across the least-squares solve
 __device__ __forceinline__ int lr_flt0(int v) { return (int)(short)(v & 0xFFFF); }
 __device__ __forceinline__ int lr_flt1(int v) { return v >> 16; }
+__device__ __forceinline__ int lr_row_of_thread() { return (int)(threadIdx.x >> 2); }
+__device__ __forceinline__ int lr_col_of_thread() { return (int)(threadIdx.x & 3) * 16; }
 __device__ inline void lr_box_F(LrLds &L, const LrChunk &c, int pass, int flt[16]) {
-  const int npx = c.w * c.h;
+  const int py = lr_row_of_thread(), px0 = lr_col_of_thread(), yabs = c.y0 + py;
+  const bool rowok = py < c.h;
+  // column terms of the 3x3 weighting at (A, B) column x (x = px + 1): `m` = the sample's own row, `u` = the rows above + below
+  const int o0 = (py + 1) * LR_AP + px0;                                           // column px0 - 1 + 1 of the sample's row
+  const bool odd = (yabs & 1) != 0;
+  int am[3] = { 0, 0, 0 }, au[3] = { 0, 0, 0 }, bm[3] = { 0, 0, 0 }, bu[3] = { 0, 0, 0 };
+  auto fetch = [&](int x, int slot) {                                              // x: offset from o0
+    if (pass == 0) {
+      if (odd) { am[slot] = L.A[o0 + x]; bm[slot] = (int)L.B[o0 + x]; }
+      else { au[slot] = L.A[o0 + x - LR_AP] + L.A[o0 + x + LR_AP]; bu[slot] = (int)(L.B[o0 + x - LR_AP] + L.B[o0 + x + LR_AP]); }
+    } else {
+      am[slot] = L.A[o0 + x]; bm[slot] = (int)L.B[o0 + x];
+      au[slot] = L.A[o0 + x - LR_AP] + L.A[o0 + x + LR_AP]; bu[slot] = (int)(L.B[o0 + x - LR_AP] + L.B[o0 + x + LR_AP]);
+    }
+  };
+  if (rowok && px0 < c.w) { fetch(0, 0); fetch(1, 1); }
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int idx = threadIdx.x + 256 * k;
     int out = 0;
-    if (idx < npx) {
-      const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w, yabs = c.y0 + py;
-      const int o = (py + 1) * LR_AP + px + 1;
+    const int px = px0 + k;
+    if (rowok && px < c.w) {
+      const int l = k % 3, m = (k + 1) % 3, r = (k + 2) % 3;                       // slots of columns px - 1, px, px + 1
+      fetch(k + 2, r);
       int a, b, shift;
       if (pass == 0) {
-        if (yabs & 1) { a = 6 * L.A[o] + 5 * (L.A[o - 1] + L.A[o + 1]); b = 6 * (int)L.B[o] + 5 * (int)(L.B[o - 1] + L.B[o + 1]); shift = 4; }
-        else {
-          a = 6 * (L.A[o - LR_AP] + L.A[o + LR_AP]) + 5 * (L.A[o - LR_AP - 1] + L.A[o - LR_AP + 1] + L.A[o + LR_AP - 1] + L.A[o + LR_AP + 1]);
-          b = 6 * (int)(L.B[o - LR_AP] + L.B[o + LR_AP]) + 5 * (int)(L.B[o - LR_AP - 1] + L.B[o - LR_AP + 1] + L.B[o + LR_AP - 1] + L.B[o + LR_AP + 1]);
-          shift = 5;
-        }
+        if (odd) { a = 6 * am[m] + 5 * (am[l] + am[r]); b = 6 * bm[m] + 5 * (bm[l] + bm[r]); shift = 4; }
+        else { a = 6 * au[m] + 5 * (au[l] + au[r]); b = 6 * bu[m] + 5 * (bu[l] + bu[r]); shift = 5; }
       } else {
-        a = 4 * (L.A[o] + L.A[o - 1] + L.A[o + 1] + L.A[o - LR_AP] + L.A[o + LR_AP]) + 3 * (L.A[o - LR_AP - 1] + L.A[o - LR_AP + 1] + L.A[o + LR_AP - 1] + L.A[o + LR_AP + 1]);
-        b = 4 * (int)(L.B[o] + L.B[o - 1] + L.B[o + 1] + L.B[o - LR_AP] + L.B[o + LR_AP]) + 3 * (int)(L.B[o - LR_AP - 1] + L.B[o - LR_AP + 1] + L.B[o + LR_AP - 1] + L.B[o + LR_AP + 1]);
+        a = 4 * (am[m] + am[l] + am[r] + au[m]) + 3 * (au[l] + au[r]);
+        b = 4 * (bm[m] + bm[l] + bm[r] + bu[m]) + 3 * (bu[l] + bu[r]);
         shift = 5;
       }
       const int cd = L.win[(py + 3) * LR_WP + px + 3];
@@ -236,12 +258,12 @@ __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__res
         if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt); }
         if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt); }
       }
-      const int npx = c.w * c.h;
+      const int py = lr_row_of_thread(), px0 = lr_col_of_thread();
 #pragma unroll
       for (int k = 0; k < 16; k++) {
-        const int idx = threadIdx.x + 256 * k;
-        if (idx < npx) {
-          const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+        const int px = px0 + k;
+        if (py < c.h && px < c.w) {
+          const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
           const int cd = L.win[(py + 3) * LR_WP + px + 3], sv = src[o];
           if (sweep == 0) {
             const int u = cd << 4, e = (sv << 4) - u;
@@ -350,12 +372,12 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *__restrict__ fr
     lr_load_window(L, f, plane, c);
     if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt); }
     if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt); }
-    const int npx = c.w * c.h;
+    const int py = lr_row_of_thread(), px0 = lr_col_of_thread();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int idx = threadIdx.x + 256 * k;
-      if (idx < npx) {
-        const int py = c.w == 64 ? idx >> 6 : idx / c.w, px = idx - py * c.w; const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
+      const int px = px0 + k;
+      if (py < c.h && px < c.w) {
+        const size_t o = (size_t)(c.y0 + py) * st + c.x0 + px;
         out[o] = (uint16_t)lr_project(L.win[(py + 3) * LR_WP + px + 3], lr_flt0(flt[k]), lr_flt1(flt[k]), r0, r1, xq0, xq1, mx);
       }
     }
