@@ -48,6 +48,19 @@ if which == 'quick':
         ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
         ok_all &= ok
         print(json.dumps({'case': 'noise %dx%d bd%d s%d q%d' % (w, h, bd, speed, q), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
+if which == 'blk64':                               # the 64x64 level (dev_blk64.h): smooth pictures on which 64x64 blocks win, bottom-up (speed 1) and top-down, 4:4:4 and 4:0:0
+    from tests.test_oracle_dav1d import smooth_planes
+    ok_all = True
+    for (w, h, bd, q, mono, over) in [(200, 136, 8, 121, False, {}), (192, 128, 10, 90, False, {'encode_bottomup': 0}), (192, 128, 10, 90, True, {'encode_bottomup': 0})]:
+        pl = smooth_planes(h, w, bd, w + h)[:1 if mono else 3]
+        names = {'encode_bottomup': 'bottomup'}
+        r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, 1, **{names[k]: v for k, v in over.items()}), pl)
+        t = time.time()
+        obu, rec = m.encode_planes(pl, bd, q, 1, mono, **over)
+        ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
+        ok_all &= ok
+        print(json.dumps({'case': 'blk64 %dx%d bd%d q%d mono%d %s' % (w, h, bd, q, int(mono), over), 'ok': bool(ok), 'n64': int((r['m_bsize'] == 4).sum()) // 256, 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
+    sys.exit(0 if ok_all else 1)
 if which == 'rect':
     sys.exit(0 if ok_all else 1)
 if which == 'batch':                               # batch API: several images, colour + alpha frames, bottom-up order (work lists spanning frames and block-size classes)

@@ -46,6 +46,15 @@ def test_emulated_kernels_rect_partition_cases(emu_env):
     assert rows and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
+def test_emulated_kernels_64x64_level(emu_env):
+    """dev_blk64.h without a GPU: pictures on which 64x64 blocks are chosen (asserted from the oracle's block map), bottom-up and top-down walkers, 4:4:4 with its
+    four 32x32 chroma transform blocks per plane and 4:0:0; once more with the lanes and waves of the emulator running in reverse order."""
+    for extra in ({}, {'MI_EMU_REVERSE': '1'}):
+        p, rows = _run(emu_env, 'blk64', 900, **extra)
+        assert len(rows) == 3 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
+        assert sum(r['n64'] for r in rows) >= 2, rows
+
+
 def test_emulated_batch_api_equals_oracle(emu_env):
     """The batch entry points under the emulator's thread pool: work lists that span several frames (colour and colour + alpha images, two block-size
     classes in one encode, top-down and bottom-up order) equal the oracle byte for byte."""
