@@ -74,8 +74,8 @@ __device__ inline void inv_txfm64_add_dev(const LDS int32_t *dq, LDS int32_t *tb
   WAVE_SYNC();
 }
 
-template <int NW>
-__device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int c, long long budget = J_INF) {
+template <int NW, bool FULL>
+__device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r, int c, long long budget = J_INF) {
   static_assert(NW == 4, "the 64x64 level deals its candidates to four wavefronts");
   constexpr int MAXN = 32, BS = 4, n = 64, n4 = 16, log2w = 6, nn = n * n;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
@@ -99,6 +99,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);
   const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uni32(v_uvU))) || (availL && IS_SMOOTH_(uni32(v_uvL))));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
+  PH_BEGIN();
 
   // ---- stage: luma source (all waves), raw edges + transform contexts of every plane (plane p by wave p + 1), psychovisual references (wave 0) ----
   {
@@ -132,7 +133,9 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
     if (LANE == 0) { SH->cact = cact; SH->seg_nb = seg_nb; }
     seg_select(f, SH, cact);
   }
+  PH(1);
   WG_SYNC();
+  PH(2);
   const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
 
@@ -149,7 +152,9 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
       }
     }
   }
+  PH(3);
   WG_SYNC();
+  PH(2);
   if (LANE < 13) {
     const long long mine = SH->satd[LANE];
     int rank = 0;
@@ -157,7 +162,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
     SH->order[rank] = LANE;
   }
   WAVE_SYNC();
-  const int ncand = f->complex_modes ? 7 : 3;
+  const int ncand = FULL ? 7 : 3;
   auto dl_of = [](int q) { const int a = (q >> 1) + 1; return (q & 1) ? a : -a; };
   const int refine = f->fine_directional;
   if (refine) {
@@ -170,7 +175,9 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
         if (LANE == 0) SH->dsd[ci][q] = sd;
       }
     }
+    PH(5);
     WG_SYNC();
+    PH(2);
   }
   // ---- full RD over the surviving (mode, delta): candidate e by wave e % NW; a 64x64 transform is always DCT_DCT and its type is not coded ----
   const bool tx_trial = f->tx_mode_select && f->rdo_tx;
@@ -205,7 +212,9 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
     }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
+  PH(6);
   WG_SYNC();
+  PH(2);
   int win = 0;
   for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
   const long long best_j = SH->wbest_j[win];
@@ -363,6 +372,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
       if constexpr (MI_TX_DEPTH_MAX >= 2) if (trial(std::integral_constant<int, 2>{})) return luma_j;
     }
   }
+  PH(13);
   if (luma_j >= budget) return luma_j;
   long long total_j = luma_j;
 
@@ -373,7 +383,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     const int pair = ((W >> 1) & 1) ^ 1, p = (W & 1) + 1;
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_buf = 0, pb_any = 0, pb_eob = 0, pb_cul = 0, pb_dcc = 0;   // per transform block: eob 16 bits (two words), cul 8 bits, dcc 2 bits
     int pb_eob_hi = 0, cbuf_i = 0;
@@ -504,6 +514,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW> k, int r, int 
     any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
     total_j += best_uv;
   }
+  PH(9);
   // ---- skip flag, segment id ----
   const int skip = !any_coef;
   int seg_ctx = 0;

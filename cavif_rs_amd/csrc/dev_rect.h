@@ -286,8 +286,8 @@ __device__ inline int rect_quant_rate(CostPtr cost, LDS int32_t *cbuf, LDS int32
 
 // One 2:1 transform block by one wave (eval_tx for the rectangular sizes).  psv2 / act: the two 4x4 cells' source variances and the activity of the
 // 8x8 cell the block lies in (luma, Tune::Psychovisual); cact: the same activity for chroma.
-template <int MAXN, int WL, int HL, int NW>
-__device__ inline long long eval_rect(const Ctx<MAXN, NW> k, int plane, int sctx, int dctx, const LDS uint16_t *src, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+template <int MAXN, int WL, int HL, int NW, bool FULL>
+__device__ inline long long eval_rect(const Ctx<MAXN, NW, FULL> k, int plane, int sctx, int dctx, const LDS uint16_t *src, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                       LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, int psv_a, int psv_b, int act) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W + 1, NN = W * H;
   const LDS FrameDev *f = k.f(); LDS WaveScratch<MAXN> *S = k.s();
@@ -535,8 +535,8 @@ template <typename FP, typename TP> __device__ inline void txb_ctx_wh(FP f, TP t
   } else *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (whole ? 0 : 3);
 }
 
-template <int MAXN, int BSR, int NW>
-__device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+template <int MAXN, int BSR, int NW, bool FULL>
+__device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
   constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL, NN = W_ * H_, w4 = W_ >> 2, h4 = H_ >> 2;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -592,7 +592,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW> k, int r,
   }
   WG_SYNC();
   // ---- full RD over the surviving modes x tx types (no angle deltas below 8x8): evaluation e = ci * ntx + ti by wave e % NW ----
-  const int ncand = f->complex_modes ? 7 : 3;
+  const int ncand = FULL ? 7 : 3;
   int tx_ns = 0, tx_set = 0;
   const int tx_off0 = rect_tx_cdf(f, 0, &tx_ns, &tx_set);
   const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
@@ -814,7 +814,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW> k, int r,
   // ---- chroma with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four waves (plane x half of the range), then every
   // candidate of a plane in one grouped evaluation (waves 0 and 2, one candidate per 16-lane row) -- the square path's scheme (tile_search.h) ----
   bool cgrouped = false;
-  if constexpr (CAN_GROUP) cgrouped = f->np > 1 && !f->complex_modes;
+  if constexpr (CAN_GROUP) cgrouped = f->np > 1 && !FULL;
   if constexpr (CAN_GROUP) if (cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = f->reduced_tx_set ? 2 : 1;
@@ -904,78 +904,125 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW> k, int r,
     any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
     total_j += best_uv;
   }
-  // ---- chroma: the candidates one after the other, plane p on wave p - 1 (oracle order: DC, the luma mode, [the other modes,] CfL) ----
-  if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
+  // ---- chroma with the FULL candidate set of speed <= 1 (oracle order: DC, the luma mode, the other eleven modes, CfL), in the kernels instantiated for that set
+  // (Ctx::FULL): the CfL alpha scan on all four waves (plane x half of the range), then the candidates four per wavefront (eval_group_wh, one candidate per 16-lane
+  // row): wave W takes plane W / 2 + 1 and the candidates of parity W % 2, eight candidates of a plane per round, two rounds -- the later candidates first, so that
+  // the likely winners (DC, the luma mode) are still in the wave's buffers at the end; the first round's best waits in LDS (rec + levels: 192 B per plane).  Until
+  // round 4 this set ran one candidate per ROUND on two waves (14 rounds of predict + evaluate + three barriers): half of config 5's critical path. ----
+  if constexpr (FULL) if (f->np > 1 && !cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     unsigned long long cand_pack = 0; int nc = 0;
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     push(UV_CFL_PRED);
     const int uvset = f->reduced_tx_set ? 2 : 1;
-    const int p = W + 1, mine = W < 2;
-    long long best_uv = J_INF; int b_um = DC_PRED, b_sign = 0, b_au = 0, b_av = 0, ccur = 0; TxRes b_tr = { 0, 0, 0, 0, 0 };
-    for (int ci = 0; ci < nc; ci++) {
-      const int um = lut4(cand_pack, ci);
-      int txtype = mode_to_txtype(um);
-      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
-      TxRes tr = { 0, 0, 0, 0, 0 };
-      if (mine) {
-        if (um == UV_CFL_PRED) {
-          predict_block_wh(f, x, y, WL, HL, availL, availU, DC_PRED, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->dcp);
-          // rdo_cfl_alpha: oracle cfl_best_alpha -- alpha 0, then +1, -1, +2, -2, ... +16, -16; the first strictly smaller SSE wins
-          int lsum = LANE < NN ? (int)SH->luma_rec[LANE] << 3 : 0;
-          lsum = wave_sum_i32(lsum);
-          const int avg = round2_(lsum, WL + HL), mx = (1 << f->bd) - 1;
-          const int l = LANE < NN ? ((int)SH->luma_rec[LANE] << 3) - avg : 0, dcv = LANE < NN ? (int)S->dcp[LANE] : 0, sv = LANE < NN ? (int)SH->srcb[p][LANE] : 0;
-          int d0 = LANE < NN ? sv - dcv : 0;
-          long long bsse = (long long)wave_sum_i32(d0 * d0); int balpha = 0;
-          for (int mag = 1; mag <= 16; mag++) for (int sg = 0; sg < 2; sg++) {
-            const int alpha = sg ? -mag : mag, v = alpha * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
-            const int d = LANE < NN ? sv - iclamp_(dcv + sc, 0, mx) : 0;
-            const long long e = (long long)wave_sum_i32(d * d);
-            if (e < bsse) { bsse = e; balpha = alpha; }
-          }
-          if (LANE == 0) SH->calpha[0][p - 1] = balpha;
+    const int mx = (1 << f->bd) - 1;
+    const int p = (W >> 1) + 1, half = W & 1;
+    const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
+    int lavg;
+    {
+      // rdo_cfl_alpha (oracle cfl_best_alpha: alpha 0, then +1, -1, +2, -2, ... +16, -16; the first strictly smaller SSE wins): this wave scans one half of the range
+      const LDS uint16_t *luma = SH->luma_rec;
+      int lsum = LANE < NN ? (int)luma[LANE] << 3 : 0;
+      lsum = wave_sum_i32(lsum);
+      lavg = round2_(lsum, WL + HL);
+      predict_block_wh(f, x, y, WL, HL, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->dcp);
+      long long best_sse = J_INF; int best_idx = 1 << 20;
+      const int l = LANE < NN ? ((int)luma[LANE] << 3) - lavg : 0, dcv = LANE < NN ? (int)S->dcp[LANE] : 0, sv = LANE < NN ? (int)SH->srcb[p][LANE] : 0;
+      if (half == 0) { const int d = sv - dcv; best_sse = (long long)wave_sum_i32(LANE < NN ? d * d : 0); best_idx = -1; }
+      const int la = iabs_(l), ng = l < 0;
+#pragma unroll
+      for (int kq = 0; kq < 8; kq++) {                                       // scan position 2k is alpha +(k + 1), 2k + 1 is -(k + 1)
+        const int mag = half * 8 + kq + 1;
+        const int rr = round2_(__mul24(mag, la), 6), sc = ng ? -rr : rr;
+        const int dp = sv - iclamp_(dcv + sc, 0, mx), dm = sv - iclamp_(dcv - sc, 0, mx);
+        const long long ep = (long long)wave_sum_i32(LANE < NN ? __mul24(dp, dp) : 0), em = (long long)wave_sum_i32(LANE < NN ? __mul24(dm, dm) : 0);
+        if (ep < best_sse) { best_sse = ep; best_idx = half * 16 + 2 * kq; }
+        if (em < best_sse) { best_sse = em; best_idx = half * 16 + 2 * kq + 1; }
+      }
+      if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
+    }
+    WG_SYNC();
+    int alpha_u = 0, alpha_v = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) {
+      const int idx = SH->ca_sse[pp][1] < SH->ca_sse[pp][0] ? SH->ca_idx[pp][1] : SH->ca_idx[pp][0];
+      const int al = idx < 0 ? 0 : ((idx & 1) ? -((idx >> 1) + 1) : ((idx >> 1) + 1));
+      if (pp == 0) alpha_u = al; else alpha_v = al;
+    }
+    const int cfl_ok = alpha_u != 0 || alpha_v != 0;
+    // what waits in LDS across the rounds: the first round's best candidate of each plane (reconstruction, levels, eob / cul / dcc)
+    LDS uint16_t *park_rec = (LDS uint16_t *)SH->lpred + (p - 1) * 96; LDS int32_t *park_qc = (LDS int32_t *)(park_rec + 32); LDS int *park_meta = (LDS int *)SH->order + (p - 1) * 3;
+    long long best_uv = J_INF; int b_ci = 1 << 30, b_sign = 0, b_round = 0;
+    const int ns = nc <= 4 ? 1 : 2, nrounds = nc > 4 * ns ? 2 : 1, dealt = half < ns;
+    GroupRes gr = { 0, 0, 0, 0, 0 };
+    const int g = GROUP_ID;
+#pragma unroll 1
+    for (int rd = 0; rd < nrounds; rd++) {
+      const int base = nrounds == 2 && rd == 0 ? 4 * ns : 0;                  // candidates base .. base + 4 ns - 1 of the list
+      // this wave's (at most four) predictions of the round, side by side in S->pred (the DC candidate reads S->dcp)
+#pragma unroll 1
+      for (int g2 = 0; g2 < 4; g2++) {
+        const int ci = base + half + ns * g2;
+        if (dealt && ci < nc) {
+          const int um = lut4(cand_pack, ci);
+          LDS uint16_t *cp = S->pred + g2 * NN;
+          if (um == UV_CFL_PRED) {
+            const int al = p == 1 ? alpha_u : alpha_v;
+            if (LANE < NN) { const int l = ((int)SH->luma_rec[LANE] << 3) - lavg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6); cp[LANE] = (uint16_t)iclamp_((int)S->dcp[LANE] + sc, 0, mx); }
+            WAVE_SYNC();
+          } else if (um != DC_PRED) predict_block_wh(f, x, y, WL, HL, availL, availU, um, 0, ftype_uv, pra, prl, wa, wl, S->etmp, cp);
         }
       }
-      if (um == UV_CFL_PRED) WG_SYNC();
-      const int alpha_u = um == UV_CFL_PRED ? SH->calpha[0][0] : 0, alpha_v = um == UV_CFL_PRED ? SH->calpha[0][1] : 0;
-      const int ok = !(um == UV_CFL_PRED && alpha_u == 0 && alpha_v == 0);
-      if (mine && ok) {
-        if (um == UV_CFL_PRED) {
-          const int al = p == 1 ? alpha_u : alpha_v;
-          if (al) {
-            int lsum = LANE < NN ? (int)SH->luma_rec[LANE] << 3 : 0;
-            lsum = wave_sum_i32(lsum);
-            const int avg = round2_(lsum, WL + HL), mx = (1 << f->bd) - 1;
-            if (LANE < NN) { const int l = ((int)SH->luma_rec[LANE] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6); S->pred[LANE] = (uint16_t)iclamp_((int)S->dcp[LANE] + sc, 0, mx); }
-          } else if (LANE < NN) S->pred[LANE] = S->dcp[LANE];
-          WAVE_SYNC();
-        } else predict_block_wh(f, x, y, WL, HL, availL, availU, um, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->pred);
-        const long long jp = eval_rect<MAXN, WL, HL, NW>(k, p, SH->sctx[p], SH->dctx[p], SH->srcb[p], S->pred, txtype, -1, 0, S->rec[ccur], S->qc[ccur], &tr, 0, 0, SH->cact);
-        if (LANE == 0) SH->cj[ci][p - 1] = jp;
-      }
+      const int ci = base + half + ns * g, live = dealt && ci < nc;
+      const int um = lut4(cand_pack, live ? ci : 0);
+      int txtype = mode_to_txtype(um);
+      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
+      if (dealt) eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[p], um == DC_PRED ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + g * NN), p, txtype,
+                            SH->sctx[p], SH->dctx[p], -1, 0, -1, 0, SH->cact, &gr);
+      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      if (GROUP_LANE == 0 && live) SH->cj[ci][p - 1] = jp;
       WG_SYNC();
-      if (ok) {
+      // every wave: the best of the round's candidates, in list order (strictly smaller wins: the oracle's loop)
+      long long r_best = J_INF; int r_ci = 1 << 30, r_sign = 0;
+      for (int cc = base; cc < imin_(nc, base + 4 * ns); cc++) {
+        const int um2 = lut4(cand_pack, cc), is_cfl = um2 == UV_CFL_PRED;
+        if (is_cfl && !cfl_ok) continue;
         int jsign = 0;
-        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, false, 0, um == UV_CFL_PRED, alpha_u, alpha_v, &jsign);
-        const long long j = SH->cj[ci][0] + SH->cj[ci][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
-        if (j < best_uv) { best_uv = j; b_um = um; b_sign = jsign; b_au = alpha_u; b_av = alpha_v; b_tr = tr; ccur ^= 1; }
+        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um2, false, 0, is_cfl, alpha_u, alpha_v, &jsign);
+        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        if (j < r_best) { r_best = j; r_ci = cc; r_sign = jsign; }
       }
-      WG_SYNC();
+      if (r_best < best_uv || (r_best == best_uv && r_ci < b_ci)) { best_uv = r_best; b_ci = r_ci; b_sign = r_sign; b_round = rd; }
+      if (nrounds == 2 && rd == 0 && r_ci < nc && (r_ci - base) % ns == half) {       // this wave holds the first round's best candidate of its plane: park it
+        const int gg = (r_ci - base) / ns;
+        if (LANE < NN) { park_rec[LANE] = S->grp[gg].rec[LANE]; park_qc[LANE] = S->grp[gg].qc[LANE]; }
+        const int e_ = __builtin_amdgcn_readlane(gr.eob, gg * 16), c_ = __builtin_amdgcn_readlane(gr.cul, gg * 16), d_ = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        if (LANE == 0) { park_meta[0] = e_; park_meta[1] = c_; park_meta[2] = d_; }
+      }
+      // (no barrier here: the next round writes other cj entries, and the parked data is read after that round's barrier)
     }
-    if (mine) {
-      const int b = ccur ^ 1;
-      commit_rect<WL, HL>(f, p, r, c, S->rec[b], S->qc[b], b_tr.eob, b_tr.cul, b_tr.dcc);
-      if (LANE == 0) SH->ceob[p - 1] = b_tr.eob;
+    const int b_um = lut4(cand_pack, b_ci), chose_cfl = b_um == UV_CFL_PRED;
+    const int from_park = nrounds == 2 && b_round == 0;
+    if (from_park ? half == 0 : b_ci % ns == half) {                        // the wave that commits plane p
+      int beob, bcul, bdcc;
+      if (from_park) {
+        beob = park_meta[0]; bcul = park_meta[1]; bdcc = park_meta[2];
+        commit_rect<WL, HL>(f, p, r, c, (const LDS uint16_t *)park_rec, (const LDS int32_t *)park_qc, beob, bcul, bdcc);
+      } else {
+        const int gg = b_ci / ns;
+        beob = __builtin_amdgcn_readlane(gr.eob, gg * 16); bcul = __builtin_amdgcn_readlane(gr.cul, gg * 16); bdcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        commit_rect<WL, HL>(f, p, r, c, S->grp[gg].rec, S->grp[gg].qc, beob, bcul, bdcc);
+      }
+      if (LANE == 0) SH->ceob[p - 1] = beob;
       if (p == 1) {
         fill_rect<WL, HL>(f->m_uvmode, ms, r, c, b_um);
         fill_rect<WL, HL>((uint8_t *)f->m_angle_uv, ms, r, c, 0);
-        fill_rect<WL, HL>(f->m_cfl_sign, ms, r, c, b_sign);
-        fill_rect<WL, HL>(f->m_cfl_au, ms, r, c, b_au ? iabs_(b_au) - 1 : 0);
-        fill_rect<WL, HL>(f->m_cfl_av, ms, r, c, b_av ? iabs_(b_av) - 1 : 0);
+        fill_rect<WL, HL>(f->m_cfl_sign, ms, r, c, chose_cfl ? b_sign : 0);
+        fill_rect<WL, HL>(f->m_cfl_au, ms, r, c, (chose_cfl && alpha_u) ? iabs_(alpha_u) - 1 : 0);
+        fill_rect<WL, HL>(f->m_cfl_av, ms, r, c, (chose_cfl && alpha_v) ? iabs_(alpha_v) - 1 : 0);
       }
     }
     WG_SYNC();

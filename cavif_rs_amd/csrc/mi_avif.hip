@@ -216,14 +216,14 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 
 // ---- K1 launch: the tile search as a work queue of superblocks (tile_search.h) ----
 // Persistent workgroups: as many as the device holds at once for this instantiation (asked from the runtime, not assumed), capped by the number of items.
-template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+template <int MAXBS, int NW, bool BU, bool CX> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   const size_t lds = k1_lds_bytes<MAXBS, NW>();
   static int resident[MI_MAX_DEVICES];                    // per instantiation and device; 0 = not asked yet
   if (resident[device] == 0) {
-    hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU, CX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0, cus = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_search_kernel<MAXBS, NW, BU>, 64 * NW, lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_search_kernel<MAXBS, NW, BU, CX>, 64 * NW, lds);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) return e;
@@ -234,20 +234,19 @@ template <int MAXBS, int NW, bool BU> static hipError_t launch_search_t(const Fr
   }
   const int grid = std::min(nitems, resident[device]);
   if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU, CX>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
   return hipGetLastError();
 }
 static size_t k1_snap_bytes(int maxbs) { return MI_K1_POOL_BYTES(maxbs); }
 // every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch; the
 // jobs must all belong to frames of the same block-size class (one instantiation per class).  grid_out != nullptr: only report the grid.
-static hipError_t launch_search(int maxbs, bool bottomup, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+// `complex`: the full candidate set of speed <= 1 (complex_pred_modes) has its own instantiations (Ctx::FULL, tile_search.h): its chroma stage must not be part of the speed-4 kernels' code
+static hipError_t launch_search(int maxbs, bool bottomup, bool complex, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   if (nitems <= 0) { if (grid_out) *grid_out = 0; return hipSuccess; }
-  if (bottomup) {
-    if (maxbs <= 2) return launch_search_t<2, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-    return launch_search_t<4, 4, true>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-  }
-  if (maxbs <= 2) return launch_search_t<2, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
-  return launch_search_t<4, 4, false>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s);
+#define MI_LAUNCH_(MB, BU_, CX_) launch_search_t<MB, 4, BU_, CX_>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s)
+  if (maxbs <= 2) return bottomup ? (complex ? MI_LAUNCH_(2, true, true) : MI_LAUNCH_(2, true, false)) : (complex ? MI_LAUNCH_(2, false, true) : MI_LAUNCH_(2, false, false));
+  return bottomup ? (complex ? MI_LAUNCH_(4, true, true) : MI_LAUNCH_(4, true, false)) : (complex ? MI_LAUNCH_(4, false, true) : MI_LAUNCH_(4, false, false));
+#undef MI_LAUNCH_
 }
 // jobs must all belong to frames of the same block-size class
 // K4, one instantiation per block-size class like K1 (jobs + first_job .. first_job + njobs of the grouped job list)
@@ -300,15 +299,17 @@ namespace mi {
 // Builds the launch's work list -- per block-size class, the superblocks of the class's tiles in (2 * row + column, job) order; jobs are indexed inside
 // their class segment of d_jobs -- and enqueues one queue launch per class on `s`.
 // the launches over a work list that is already on the device (the second pass of a two-pass encode reuses the first one's)
-static int search_launch(SearchQueue &q, bool bottomup, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
+// every frame of a launch comes from one encoder configuration: which walker and which candidate set the kernels are instantiated for
+static int search_mode(const mi_av1_config &c) { return (c.encode_bottomup != 0 ? 1 : 0) | (c.complex_pred_modes != 0 ? 2 : 0); }
+static int search_launch(SearchQueue &q, int mode /* bit 0: bottom-up walker, bit 1: full candidate set */, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_search(cls, bottomup, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
+    HIP_OK(launch_search(cls, (mode & 1) != 0, (mode & 2) != 0, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
   return MI_OK;
 }
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   q.items.clear();
   size_t snap_need = 0;
-  const bool bottomup = !frames.empty() && frames[0].cfg.encode_bottomup != 0;
+  const int mode = frames.empty() ? 0 : search_mode(frames[0].cfg);
   for (int cls = 2; cls <= 4; cls++) {
     q.q_begin[cls] = (int)q.items.size();
     std::vector<std::vector<SbItem>> by_key;
@@ -322,7 +323,7 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
     for (auto &v : by_key) q.items.insert(q.items.end(), v.begin(), v.end());
     const int nitems = (int)q.items.size() - q.q_begin[cls];
     int grid = 0;
-    HIP_OK(launch_search(cls, bottomup, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
+    HIP_OK(launch_search(cls, (mode & 1) != 0, (mode & 2) != 0, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
     // How many superblocks can be at work at once under whole-superblock dependencies (a tile's wavefront is min(rows, cols / 2) wide): when that
     // leaves resident workgroups idle the launch synchronises per root block instead (tile_search.h root_wait); a full batch keeps the cheaper
     // one-acquire-one-release-per-superblock protocol.
@@ -346,7 +347,7 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
   if (snap_need > q.snap_bytes) { if (q.d_snap) (void)hipFree(q.d_snap); q.d_snap = nullptr; q.snap_bytes = snap_need; HIP_OK(hipMalloc(&q.d_snap, snap_need)); }
   memcpy(q.h_items, q.items.data(), q.items.size() * sizeof(SbItem));
   HIP_OK(hipMemcpyAsync(q.d_items, q.h_items, q.items.size() * sizeof(SbItem), hipMemcpyHostToDevice, s));
-  return search_launch(q, bottomup, class_begin, d_frames, d_jobs, device, s);
+  return search_launch(q, mode, class_begin, d_frames, d_jobs, device, s);
 }
 }  // namespace mi
 
@@ -436,7 +437,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipMalloc(&b->d_recbuf, (size_t)max_tiles * 3 * (size_t)b->rec_cap * 4));
   b->aux_bytes = (size_t)max_tiles * (size_t)max_cap * 2 + (size_t)max_tiles * 3 * (size_t)b->rec_cap * 4;
   HIP_OK(hipMalloc(&b->d_offsets, max_tiles * 4));
-  HIP_OK(hipMalloc(&b->d_prof, std::max<size_t>(max_tiles, 2048) * 128 * 8));   // profiling builds: per tile job (K4) / per persistent workgroup (K1)
+  HIP_OK(hipMalloc(&b->d_prof, std::max<size_t>(max_tiles, 2048) * 128 * 8)); HIP_OK(hipMemset(b->d_prof, 0, std::max<size_t>(max_tiles, 2048) * 128 * 8));   // profiling builds: per tile job (K4) / per persistent workgroup (K1)
   // Packed payloads: the worst case is the sum of the tile capacities (raw size, hundreds of MB of pinned memory per batch), the
   // usual case a few per cent of it: start at 1/16 and let mi_batch_wait grow the pair when a run needs more.
   b->packed_max = std::min<size_t>(packed, (size_t)1 << 31);
@@ -543,7 +544,7 @@ int mi_batch_tile_clocks(mi_batch *b, unsigned long long *out) {
 int mi_batch_phase_profile(mi_batch *b, unsigned long long *out) {
   if (!b || !out || !b->d_prof) return MI_INVALID_ARGUMENT;
   (void)hipSetDevice(b->device);
-  HIP_OK(hipMemcpy(out, b->d_prof, b->jobs.size() * 128 * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out, b->d_prof, std::max<size_t>(b->jobs.size(), 2048) * 128 * 8, hipMemcpyDeviceToHost));     // rows: tile jobs (K4) or persistent workgroups (K1: up to the resident grid); unused rows are zero
   return MI_OK;
 }
 int mi_batch_num_tiles(const mi_batch *b) { return b ? (int)b->jobs.size() : 0; }
@@ -641,7 +642,7 @@ int mi_batch_encode_async(mi_batch *b) {
     hipLaunchKernelGGL(segment_kernel, dim3(nframes), dim3(256), 0, s, b->d_frames);
     HIP_OK(hipEventRecord(b->ev[1], s));
     if (pass == 0) { if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st; }
-    else if (int st = search_launch(b->queue, bottomup, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
+    else if (int st = search_launch(b->queue, search_mode(b->frames[0].cfg), class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
     HIP_OK(hipEventRecord(b->ev[2], s));
     HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
     HIP_OK(hipEventRecord(b->ev[4], s));
@@ -1043,7 +1044,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
       hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
       hipLaunchKernelGGL(segment_kernel, dim3(1), dim3(256), 0, s, d_frame);
       if (pass == 0) { if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st; }
-      else if (int st = search_launch(g.queue, p.cfg.encode_bottomup != 0, class_begin, d_frame, d_jobs, cfg->device, s)) return st;
+      else if (int st = search_launch(g.queue, search_mode(p.cfg), class_begin, d_frame, d_jobs, cfg->device, s)) return st;
       HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
       HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, g.d_rec, rec_cap, s));
     }

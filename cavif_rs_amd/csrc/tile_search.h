@@ -27,7 +27,9 @@
 #ifndef MI_PROFILE
 #define MI_PROFILE 0
 #endif
-#define MI_PROF_MAXN 16                             /* profiling builds time the 16x16-class launch */
+#ifndef MI_PROF_MAXN
+#define MI_PROF_MAXN 16                             /* profiling builds time the 16x16-class launch (-DMI_PROF_MAXN=32: the 64x64 class, tools/k1_phases.py 5) */
+#endif
 // bisect hooks (MI_DEBUG_LEVEL): probe builds only (-DMI_DEBUG_HOOKS=1); release builds carry no debug branches in K1
 #ifndef MI_DEBUG_HOOKS
 #define MI_DEBUG_HOOKS 0
@@ -121,7 +123,9 @@ template <int N> __device__ __forceinline__ LDS unsigned long long &mi_prof_slot
 // context is two 32-bit LDS pointers passed BY VALUE (registers): the accessors fold into ds_read offsets.  (It used to be a
 // struct on the kernel's stack passed by reference: every use inside the non-inlined block search was a flat load from scratch,
 // ~40 per call, each holding both wait counters.)
-template <int MAXN, int NW> struct Ctx {
+// FULL: the kernel was instantiated for the full candidate set of speed <= 1 (complex_pred_modes); the host launches the matching instantiation, so FULL == f->complex_modes and the kernels read the template parameter
+template <int MAXN, int NW, bool FULL_ = false> struct Ctx {
+  static constexpr bool FULL = FULL_;
   static constexpr int MAXBS = MAXN == 16 ? 2 : 4;     // the largest transform whose rate slices the class needs: the 32x32 class evaluates 64x64 blocks too (dev_blk64.h)
   static constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
   static constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
@@ -263,8 +267,8 @@ __device__ __forceinline__ uint32_t uv_mode_rate(const uint16_t *cost, const uin
 }
 
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
-template <int MAXN, int BS, int NW>
-__device__ inline long long eval_tx(const Ctx<MAXN, NW> k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+template <int MAXN, int BS, int NW, bool FULL>
+__device__ inline long long eval_tx(const Ctx<MAXN, NW, FULL> k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr,
                                     const LDS int *psv = nullptr, const LDS int *pact = nullptr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
@@ -314,11 +318,11 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
 // `budget`: the caller only needs to know whether the block's cost stays below it (split trials: cost of the
 // undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
 // reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
-template <int MAXN, int BS, int NW>
+template <int MAXN, int BS, int NW, bool FULL>
 // not_tail_called: with every argument in registers the calls would be marked `tail`, and LLVM's interprocedural register
 // allocation then refuses its no-callee-saved-registers treatment for this function (TargetFrameLowering::isSafeForNoCSROpt):
 // the prologue / epilogue would spill and reload 46 VGPRs + 34 SGPRs per call.
-__device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+__device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -433,7 +437,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int 
   }
   WAVE_SYNC();
   PH(4);
-  const int ncand = f->complex_modes ? 7 : 3;
+  const int ncand = FULL ? 7 : 3;
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
   auto dl_of = [](int q) { const int a = (q >> 1) + 1; return (q & 1) ? a : -a; };        // -1, 1, -2, 2, -3, 3
   const int refine = BS >= BS_8 && f->fine_directional;
@@ -917,7 +921,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int 
   // ---- chroma, 4x4 / 8x8 blocks with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four
   // waves (plane x half of the range), then every candidate of a plane in one grouped evaluation (dev_group.h) ----
   bool cgrouped = false;
-  if constexpr (SMALL_GROUPED) cgrouped = f->np > 1 && !f->complex_modes;
+  if constexpr (SMALL_GROUPED) cgrouped = f->np > 1 && !FULL;
   if constexpr (SMALL_GROUPED) if (cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, f->reduced_tx_set);
@@ -1039,8 +1043,161 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int 
     any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
     total_j += best_uv;
   }
+  // ---- chroma, 4x4 / 8x8 blocks with the FULL candidate set of speed <= 1 (oracle order: DC, the luma mode, the other eleven modes, CfL), in the kernels instantiated
+  // for that set (Ctx::FULL: inside the speed-4 kernels this code cost 2 % of K1 by its presence alone, as a called function 9 %): the CfL alpha scan on all four
+  // waves (plane x half of the alpha range), then the candidates four per wavefront (dev_group.h, one candidate per 16-lane row): wave W takes plane W / 2 + 1 and the
+  // candidates of parity W % 2, eight candidates of a plane per round, two rounds for the 13 or 14 candidates -- the later candidates first, so the likely winners
+  // are still in the wave's buffers at the end; the first round's best waits in LDS (dev_rect.h has the same scheme for the 2:1 blocks).  Until round 4 this set ran
+  // one candidate per wave pair and round (seven rounds of predict + evaluate + two barriers); measured on config 5: tile search 5.54 -> 3.94 s with both. ----
+  bool cfull = false;
+  if constexpr (SMALL_GROUPED && FULL) cfull = f->np > 1 && FULL;
+  if constexpr (SMALL_GROUPED && FULL) if (cfull) {
+    const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
+    unsigned long long cand_pack = 0; int nc = 0;
+    auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
+    push(DC_PRED);
+    if (best_mode != DC_PRED) push(best_mode);
+    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    push(UV_CFL_PRED);
+    const int uvset = tx_set_of(BS, f->reduced_tx_set);
+    const int mx = (1 << f->bd) - 1;
+    const int p = (W >> 1) + 1, half = W & 1;
+    const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
+    int lavg;
+    {
+      // rdo_cfl_alpha (oracle cfl_best_alpha: alpha 0, then +1, -1, ... +16, -16; the first strictly smaller SSE wins): this wave scans one half of the range
+      const LDS uint16_t *luma = SH->luma_rec;
+      int lsum = 0;
+      for (int idx = LANE; idx < nn; idx += 64) lsum += luma[idx] << 3;
+      lsum = wave_sum_i32(lsum);
+      lavg = round2_(lsum, 2 * log2w);
+      predict_block(f, x, y, log2w, availL, availU, DC_PRED, 0, ftype_uv, pra, prl, wa, wl, S->etmp, S->dcp);
+      long long best_sse = J_INF; int best_idx = 1 << 20;
+      if (half == 0) {
+        int e0 = 0;
+        for (int idx = LANE; idx < nn; idx += 64) { const int d = (int)SH->srcb[p][idx] - (int)S->dcp[idx]; e0 += __mul24(d, d); }
+        best_sse = (long long)wave_sum_i32(e0); best_idx = -1;
+      }
+      int e[16];
+#pragma unroll
+      for (int a2 = 0; a2 < 16; a2++) e[a2] = 0;
+      for (int idx = LANE; idx < nn; idx += 64) {
+        const int l = ((int)luma[idx] << 3) - lavg, dcv = S->dcp[idx], sv = SH->srcb[p][idx];
+        const int la = iabs_(l), neg = l < 0;
+#pragma unroll
+        for (int kq = 0; kq < 8; kq++) {
+          const int mag = half * 8 + kq + 1;
+          const int rr = round2_(__mul24(mag, la), 6), sc = neg ? -rr : rr;
+          const int dp = sv - iclamp_(dcv + sc, 0, mx), dm = sv - iclamp_(dcv - sc, 0, mx);
+          e[2 * kq] += __mul24(dp, dp); e[2 * kq + 1] += __mul24(dm, dm);
+        }
+      }
+#pragma unroll
+      for (int a2 = 0; a2 < 16; a2++) {
+        const long long ea = (long long)wave_sum_i32(e[a2]);
+        if (ea < best_sse) { best_sse = ea; best_idx = half * 16 + a2; }
+      }
+      if (LANE == 0) { SH->ca_sse[p - 1][half] = best_sse; SH->ca_idx[p - 1][half] = best_idx; }
+    }
+    PH(8);
+    WG_SYNC();
+    PH(2);
+    int alpha_u = 0, alpha_v = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) {
+      const int idx = SH->ca_sse[pp][1] < SH->ca_sse[pp][0] ? SH->ca_idx[pp][1] : SH->ca_idx[pp][0];
+      const int al = idx < 0 ? 0 : ((idx & 1) ? -((idx >> 1) + 1) : ((idx >> 1) + 1));
+      if (pp == 0) alpha_u = al; else alpha_v = al;
+    }
+    const int cfl_ok = alpha_u != 0 || alpha_v != 0;
+    // what waits in LDS across the rounds: the first round's best candidate of each plane (reconstruction, levels, eob / cul / dcc); lpred is dead after the luma search
+    LDS uint16_t *park_rec = (LDS uint16_t *)SH->lpred + (p - 1) * 3 * nn; LDS int32_t *park_qc = (LDS int32_t *)(park_rec + nn); LDS int *park_meta = (LDS int *)SH->order + (p - 1) * 3;
+    static_assert(2 * 3 * nn <= 768, "the parked candidates fit lpred");
+    long long best_uv = J_INF; int b_ci = 1 << 30, b_sign = 0, b_round = 0, b_delta = 0;
+    const int ns = nc <= 4 ? 1 : 2, nrounds = nc > 4 * ns ? 2 : 1, dealt = half < ns;
+    GroupRes gr = { 0, 0, 0, 0, 0 };
+    const int g = GROUP_ID;
+    auto delta_of = [&](int um) { return (um == best_mode && um >= V_PRED && um <= D67_PRED && BS >= BS_8) ? best_delta : 0; };
+#pragma unroll 1
+    for (int rd = 0; rd < nrounds; rd++) {
+      const int base = nrounds == 2 && rd == 0 ? 4 * ns : 0;                  // candidates base .. base + 4 ns - 1 of the list
+      // this wave's (at most four) predictions of the round, side by side in S->pred (the DC candidate reads S->dcp)
+#pragma unroll 1
+      for (int g2 = 0; g2 < 4; g2++) {
+        const int ci = base + half + ns * g2;
+        if (dealt && ci < nc) {
+          const int um = lut4(cand_pack, ci);
+          LDS uint16_t *cp = S->pred + g2 * nn;
+          if (um == UV_CFL_PRED) {
+            const int al = p == 1 ? alpha_u : alpha_v;
+            for (int idx = LANE; idx < nn; idx += 64) {
+              const int l = ((int)SH->luma_rec[idx] << 3) - lavg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6);
+              cp[idx] = (uint16_t)iclamp_((int)S->dcp[idx] + sc, 0, mx);
+            }
+            WAVE_SYNC();
+          } else if (um != DC_PRED) predict_block(f, x, y, log2w, availL, availU, um, delta_of(um), ftype_uv, pra, prl, wa, wl, S->etmp, cp);
+        }
+      }
+      const int ci = base + half + ns * g, live = dealt && ci < nc;
+      const int um = lut4(cand_pack, live ? ci : 0);
+      int txtype = mode_to_txtype(um);
+      if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
+      if (dealt) eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], um == DC_PRED ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + g * nn), p, BS, txtype,
+                    SH->sctx[p], SH->dctx[p], -1, 0, -1, SH->cact, &gr);
+      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      if (GROUP_LANE == 0 && live) SH->cj[ci][p - 1] = jp;
+      PH(9);
+      WG_SYNC();
+      PH(2);
+      // every wave: the best of the round's candidates, in list order (strictly smaller wins: the oracle's loop)
+      long long r_best = J_INF; int r_ci = 1 << 30, r_sign = 0, r_delta = 0;
+      for (int cc = base; cc < imin_(nc, base + 4 * ns); cc++) {
+        const int um2 = lut4(cand_pack, cc), is_cfl = um2 == UV_CFL_PRED;
+        if (is_cfl && !cfl_ok) continue;
+        int jsign = 0;
+        const int d2 = delta_of(um2);
+        const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um2, um2 >= V_PRED && um2 <= D67_PRED && BS >= BS_8, d2, is_cfl, alpha_u, alpha_v, &jsign);
+        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        if (j < r_best) { r_best = j; r_ci = cc; r_sign = jsign; r_delta = d2; }
+      }
+      if (r_best < best_uv || (r_best == best_uv && r_ci < b_ci)) { best_uv = r_best; b_ci = r_ci; b_sign = r_sign; b_round = rd; b_delta = r_delta; }
+      if (nrounds == 2 && rd == 0 && r_ci < nc && (r_ci - base) % ns == half) {       // this wave holds the first round's best candidate of its plane: park it
+        const int gg = (r_ci - base) / ns;
+        for (int i = LANE; i < nn; i += 64) { park_rec[i] = S->grp[gg].rec[i]; park_qc[i] = S->grp[gg].qc[i]; }
+        const int e_ = __builtin_amdgcn_readlane(gr.eob, gg * 16), c_ = __builtin_amdgcn_readlane(gr.cul, gg * 16), d_ = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        if (LANE == 0) { park_meta[0] = e_; park_meta[1] = c_; park_meta[2] = d_; }
+      }
+      // (no barrier here: the next round writes other cj entries, and the parked data is read after that round's barrier)
+    }
+    const int b_um = lut4(cand_pack, b_ci), chose_cfl = b_um == UV_CFL_PRED;
+    const int from_park = nrounds == 2 && b_round == 0;
+    if (from_park ? half == 0 : b_ci % ns == half) {                        // the wave that commits plane p
+      int beob, bcul, bdcc;
+      if (from_park) {
+        beob = park_meta[0]; bcul = park_meta[1]; bdcc = park_meta[2];
+        commit_plane<BS>(f, p, r, c, (const LDS uint16_t *)park_rec, (const LDS int32_t *)park_qc, beob, bcul, bdcc);
+      } else {
+        const int gg = b_ci / ns;
+        beob = __builtin_amdgcn_readlane(gr.eob, gg * 16); bcul = __builtin_amdgcn_readlane(gr.cul, gg * 16); bdcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+        commit_plane<BS>(f, p, r, c, S->grp[gg].rec, S->grp[gg].qc, beob, bcul, bdcc);
+      }
+      if (LANE == 0) SH->ceob[p - 1] = beob;
+      if (p == 1) {
+        fill_map_dev(f->m_uvmode, ms, r, c, n4, b_um);
+        fill_map_dev((uint8_t *)f->m_angle_uv, ms, r, c, n4, (uint8_t)(int8_t)b_delta);
+        fill_map_dev(f->m_cfl_sign, ms, r, c, n4, chose_cfl ? b_sign : 0);
+        fill_map_dev(f->m_cfl_au, ms, r, c, n4, (chose_cfl && alpha_u) ? iabs_(alpha_u) - 1 : 0);
+        fill_map_dev(f->m_cfl_av, ms, r, c, n4, (chose_cfl && alpha_v) ? iabs_(alpha_v) - 1 : 0);
+      }
+    }
+    PH(10);
+    WG_SYNC();
+    PH(2);
+    any_coef |= (SH->ceob[0] > 0) | (SH->ceob[1] > 0);
+    total_j += best_uv;
+  }
   // ---- chroma: candidate ci2 by wave pair (ci2 & 1), plane (W & 1) + 1 within the pair ----
-  if constexpr (NW >= 2) if (f->np > 1 && !cgrouped) {
+  if constexpr (NW >= 2) if (f->np > 1 && !cgrouped && !cfull) {
     const int cfl_allowed = BS <= BS_32;
     const uint16_t *uvcost = cfl_allowed ? k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE : k.cost() + CDF_UV_NOCFL + best_mode * CDF_UV_NOCFL_STRIDE;
     // candidate list: up to 14 modes of 4 bits packed into one 64-bit value (a private array indexed at run time lives in scratch)
@@ -1048,7 +1205,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int 
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (f->complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     if (cfl_allowed) push(UV_CFL_PRED);
     const int uvset = tx_set_of(BS, f->reduced_tx_set);
     constexpr int NPAIR = 2;
@@ -1216,7 +1373,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW> k, int r, int 
 
 #include "dev_blk64.h"
 // the evaluation of one block: the generic search, or -- for the 64x64 level of the 32x32 class -- its cooperative form
-template <int MAXN, int BS, int NW> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW> k, int r, int c, long long budget = J_INF) {
+template <int MAXN, int BS, int NW, bool FULL> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
   if constexpr (MAXN == 32 && BS == 4) return try_block64<NW>(k, r, c, budget); else return try_block<MAXN, BS, NW>(k, r, c, budget);
 }
 
@@ -1315,7 +1472,7 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
 // superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
 __device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) | (bj & 1) | ((bi & 2) << 2) | ((bj & 2) << 1); }   // Morton index in the superblock
-template <int MAXBS, int MAXN, int NW> __device__ inline void root_wait(const Ctx<MAXN, NW> k, int r, int c) {
+template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_wait(const Ctx<MAXN, NW, FULL> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t();
   if (threadIdx.x == 0) {
@@ -1339,7 +1496,7 @@ template <int MAXBS, int MAXN, int NW> __device__ inline void root_wait(const Ct
   WG_SYNC();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-template <int MAXBS, int MAXN, int NW> __device__ inline void root_publish(const Ctx<MAXN, NW> k, int r, int c) {
+template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_publish(const Ctx<MAXN, NW, FULL> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f();
   WG_SYNC();                                                               // every wave's stores of this root are issued
@@ -1350,7 +1507,7 @@ template <int MAXBS, int MAXN, int NW> __device__ inline void root_publish(const
 }
 
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
-  static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+  template <bool FULL> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, FULL> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
@@ -1423,7 +1580,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW> k, int r, int c, long long known_j) {
+  template <bool FULL> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, FULL> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     if (known_j >= 0) return 0;
@@ -1441,7 +1598,7 @@ template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(i
   return o;
 }
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
-  static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+  template <bool FULL> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, FULL> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
@@ -1492,7 +1649,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
-  static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW> k, int r, int c) {
+  template <bool FULL> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, FULL> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     return uni64(blk_eval<MAXN, 0, NW>(k, r, c));
@@ -1525,12 +1682,12 @@ static_assert(sizeof(Blk64Wave) <= offsetof(WaveScratch<32>, lev) - offsetof(Wav
 // (no resident slot idles while its tile's neighbours are still at work); it also replaces the row workers single images used to get.
 struct SbItem { uint32_t job; uint16_t sbr, sbc; };
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
-template <int MAXBS, int NW, bool BU>
+template <int MAXBS, int NW, bool BU, bool CX>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
                                                                                                           const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
   constexpr int MAXN = k1_maxn(MAXBS);
   extern __shared__ __align__(16) uint8_t smem[];
-  using K = Ctx<MAXN, NW>;
+  using K = Ctx<MAXN, NW, CX>;
   K k;
   k.base = (LDS uint8_t *)smem;
   k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);

@@ -390,7 +390,7 @@ class BatchEncoder:
         return a
 
     def phase_profile(self):
-        a = np.zeros((self.num_tiles(), 4, 32), dtype=np.uint64)
+        a = np.zeros((max(self.num_tiles(), 2048), 4, 32), dtype=np.uint64)      # rows: tile jobs (K4 profile) or persistent workgroups (K1 profile); unused rows stay zero
         st = self._L.mi_batch_phase_profile(self._h, a.ctypes.data)
         if st:
             raise AvifError(st)

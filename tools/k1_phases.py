@@ -3,11 +3,19 @@ import sys, numpy as np
 sys.path.insert(0, '.')
 import cavif_rs_amd as m
 from cavif_rs_amd.synth import synth_image
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-e = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10)
-b = m.BatchEncoder(e, B, 1920, 1080, 3)
-for i in range(B): b.upload(i, synth_image(1920, 1080, index=i))
-b.encode(); b.encode()
+# default: the 32 x 1080p batch at speed 4 (the 16x16 class).  `tools/k1_phases.py 5`: BASELINE config 5 -- one 8K image at speed 1 -- on a library built with
+# -DMI_PROFILE=1 -DMI_PROF_MAXN=32 (the 64x64 class; the 64x64 level's own phases land in the same slots, 2:1 blocks in WALKER_other)
+if len(sys.argv) > 1 and sys.argv[1] == '5':
+    e = m.Encoder().with_quality(80).with_speed(1).with_bit_depth(10)
+    b = m.BatchEncoder(e, 1, 7680, 4320, 3)
+    b.upload(0, synth_image(7680, 4320, index=5))
+    b.encode()
+else:
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    e = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10)
+    b = m.BatchEncoder(e, B, 1920, 1080, 3)
+    for i in range(B): b.upload(i, synth_image(1920, 1080, index=i))
+    b.encode(); b.encode()
 p = b.phase_profile().astype(np.float64)          # [persistent workgroup][wave][phase] cycles
 p = p[p[:, 0, 15] > 0]
 names = ['queue_claim_wait', 'stage_src_edges', 'WAIT_barrier', 'satd13', 'sort', 'delta_satd', 'luma_rd', 'luma_commit', 'cfl_alpha', 'chroma_eval', 'chroma_commit', 'final', 'luma_final_pred', 'tx_size_trial', 'walker_area_copies', 'WALKER_other']
