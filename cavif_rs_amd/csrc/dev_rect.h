@@ -556,6 +556,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   const int ftype_y = IS_SMOOTH_(amode) || IS_SMOOTH_(lmode);
   const int ftype_uv = f->np > 1 && ((availU && IS_SMOOTH_(uvU)) || (availL && IS_SMOOTH_(uvL)));
   LDS uint16_t *wa = S->wa + EDGE_OFF, *wl = S->wl + EDGE_OFF;
+  PH_BEGIN();
 
   // ---- stage the source block, the raw edges and the transform contexts of every plane (plane p by wave p % NW), the psychovisual references
   for (int p = 0; p < f->np; p++) if (p % NW == W) {
@@ -572,7 +573,9 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     if (LANE == 0) { SH->pact[0] = a; SH->cact = a; SH->seg_nb = seg_nb; }
     seg_select(f, SH, a);
   }
+  PH(1);
   WG_SYNC();
+  PH(2);
   const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
   const int psv_a = f->tune_psnr ? 0 : SH->psv4[0], psv_b = f->tune_psnr ? 0 : SH->psv4[1], act = SH->pact[0];
@@ -583,6 +586,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     const long long sd = satd_wh(SH->srcb[0], S->pred, W_, H_);
     if (LANE == 0) SH->satd[m] = sd;
   }
+  PH(3);
   WG_SYNC();
   if (LANE < 13) {
     const long long mine = SH->satd[LANE];
@@ -599,6 +603,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   // the surviving modes are predicted once (candidate ci by wave ci % NW) into the prediction cache and shared by their tx-type trials
   LDS uint16_t *pcache = MAXN <= 16 ? (LDS uint16_t *)SH->lpred : (LDS uint16_t *)SH->split_rec;      // [7][NN]; both are free until the tx-size trial
   for (int ci = W; ci < ncand; ci += NW) predict_block_wh(f, x, y, WL, HL, availL, availU, SH->order[ci], 0, ftype_y, ra, rl, wa, wl, S->etmp, pcache + ci * NN);
+  PH(12);
   WG_SYNC();
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_tx = DCT_DCT, cur = 0; TxRes my_tr = { 0, 0, 0, 0, 0 }; uint32_t my_mrate = 0;
   // up to sixteen (mode x tx type) trials in ONE round, four per wave (one per 16-lane row, eval_group_wh): the 3 x 5 trials of speed 4
@@ -660,6 +665,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     if (j < my_j) { my_j = j; my_e = e; my_mode = m; my_tx = txtype; my_tr = tr; my_mrate = mode_rate; cur ^= 1; }
   }
   if (LANE == 0) { SH->wbest_j[W] = my_j; SH->wbest_e[W] = my_e; }
+  PH(6);
   WG_SYNC();
   int win = 0;
   for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[win] || (SH->wbest_j[w2] == SH->wbest_j[win] && SH->wbest_e[w2] < SH->wbest_e[win])) win = w2;
@@ -811,6 +817,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   }
   if (luma_j >= budget) return luma_j;
   long long total_j = luma_j;
+  PH(13);
   // ---- chroma with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four waves (plane x half of the range), then every
   // candidate of a plane in one grouped evaluation (waves 0 and 2, one candidate per 16-lane row) -- the square path's scheme (tile_search.h) ----
   bool cgrouped = false;
@@ -1030,6 +1037,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     total_j += best_uv;
   }
   // ---- skip flag ----
+  PH(9);
   const int skip = !any_coef;
   int seg_ctx = 0;                                                       // intra_segment_id, as in try_block
   const int seg_nb2 = SH->seg_nb, seg_ul = (seg_nb2 & 15) - 1, seg_u = ((seg_nb2 >> 4) & 15) - 1, seg_l = (seg_nb2 >> 8) - 1;
