@@ -74,8 +74,8 @@ __device__ inline void inv_txfm64_add_dev(const LDS int32_t *dq, LDS int32_t *tb
   WAVE_SYNC();
 }
 
-template <int NW, bool FULL>
-__device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r, int c, long long budget = J_INF) {
+template <int NW, int TS>
+__device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, TS> k, int r, int c, long long budget = J_INF) {
   static_assert(NW == 4, "the 64x64 level deals its candidates to four wavefronts");
   constexpr int MAXN = 32, BS = 4, n = 64, n4 = 16, log2w = 6, nn = n * n;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
@@ -162,9 +162,9 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
     SH->order[rank] = LANE;
   }
   WAVE_SYNC();
-  const int ncand = FULL ? 7 : 3;
+  const int ncand = Tools<TS>::FULL ? 7 : 3;
   auto dl_of = [](int q) { const int a = (q >> 1) + 1; return (q & 1) ? a : -a; };
-  const int refine = f->fine_directional;
+  const int refine = Tools<TS>::fine_directional(f);
   if (refine) {
 #pragma unroll 1
     for (int u = W; u < ncand * 6; u += NW) {
@@ -180,7 +180,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
     PH(2);
   }
   // ---- full RD over the surviving (mode, delta): candidate e by wave e % NW; a 64x64 transform is always DCT_DCT and its type is not coded ----
-  const bool tx_trial = f->tx_mode_select && f->rdo_tx;
+  const bool tx_trial = Tools<TS>::tx_mode_select(f) && Tools<TS>::rdo_tx(f);
   long long my_j = J_INF; int my_e = 1 << 30, my_mode = DC_PRED, my_delta = 0; TxRes my_tr = { 0, 0, 0, 0, 0 };
   uint32_t my_mrate = 0;
 #pragma unroll 1
@@ -200,7 +200,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
                                        f->bd, sctx_y, dctx_y, -1, 0, &tr.rate, &tr.cul, &tr.dcc);
     if (eob > 0) inv_txfm64_add_dev(B->cbuf, B->tbuf, B->pred, f->bd);
     tr.eob = eob;
-    if (!f->tune_psnr) tr.sse = psy_dist_wave<64>(SH->x64.src64, B->pred, (const LDS int *)SH->psv, (const LDS int *)SH->pact, f->bd);
+    if (!Tools<TS>::tune_psnr(f)) tr.sse = psy_dist_wave<64>(SH->x64.src64, B->pred, (const LDS int *)SH->psv, (const LDS int *)SH->pact, f->bd);
     else tr.sse = sse_dev(SH->x64.src64, B->pred, nn);
     long long j = ((tr.sse * f->wq[0]) >> 5) + (((long long)tr.rate * f->rdmult + 256) >> 9);
     j += ((long long)mode_rate * f->rdmult + 256) >> 9;
@@ -245,7 +245,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
   long long luma_j = best_j; int any_coef = SH->lm_eob > 0;
 
   // ---- luma transform size: depth 1 = four 32x32, depth 2 = sixteen 16x16 transform blocks, raster order, each predicted from the ones before it ----
-  if (f->tx_mode_select) {
+  if (Tools<TS>::tx_mode_select(f)) {
     const int actx = nb_txU >= 0 && (1 << dim_wl(nb_txU)) >= n, lctx = nb_txL >= 0 && (1 << dim_hl(nb_txL)) >= n;
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
@@ -257,7 +257,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
         LDS uint16_t *brow = SH->x64.bnd, *rcol = SH->x64.bnd + G * G * hn;       // bottom row / right column of sub-block q at + q * hn
         long long j_split = SH->lm_mode_j + (((long long)dcost[D] * f->rdmult + 256) >> 9);
         int stx_ns = 0, stx_set = 0;
-        const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
+        const int stx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), SBS, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
         int sub_any = 0;
 #pragma unroll 1
@@ -383,7 +383,7 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, FULL> k, int r
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (Tools<TS>::FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     const int pair = ((W >> 1) & 1) ^ 1, p = (W & 1) + 1;
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_buf = 0, pb_any = 0, pb_eob = 0, pb_cul = 0, pb_dcc = 0;   // per transform block: eob 16 bits (two words), cul 8 bits, dcc 2 bits
     int pb_eob_hi = 0, cbuf_i = 0;

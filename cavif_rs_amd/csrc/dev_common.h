@@ -254,11 +254,13 @@ __device__ __forceinline__ int scan_pos(const LDS uint16_t *ls, int n, int cls, 
   if (cls == TXC_VERT) return i;                       // mrow scan
   const int c = i / n, r = i - c * n; return r * n + c; // mcol scan
 }
-// intra tx-type CDF row for luma; returns -1 when the type is not signalled
-template <typename FP> __device__ __forceinline__ int intra_tx_cdf(FP f, int txs, int ymode, int *nsyms, int *set_out) {
-  const int set = tx_set_of(txs, f->reduced_tx_set);
+// intra tx-type CDF row for luma; returns -1 when the type is not signalled.  `reduced`: the frame's reduced_tx_set switch (a constant in the tile-search kernels
+// instantiated for a fixed tool set, tile_search.h Tools)
+template <typename FP> __device__ __forceinline__ int intra_tx_cdf_r(FP f, bool reduced, int txs, int ymode, int *nsyms, int *set_out) {
+  const int set = tx_set_of(txs, reduced);
   *set_out = set;
   if (set == 0 || f->base_q_idx == 0) { *nsyms = 0; return -1; }
   if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + (txs * 13 + ymode) * CDF_INTRA_TX1_STRIDE; }
   *nsyms = 5; return CDF_INTRA_TX2 + (txs * 13 + ymode) * CDF_INTRA_TX2_STRIDE;
 }
+template <typename FP> __device__ __forceinline__ int intra_tx_cdf(FP f, int txs, int ymode, int *nsyms, int *set_out) { return intra_tx_cdf_r(f, f->reduced_tx_set != 0, txs, ymode, nsyms, set_out); }

@@ -183,8 +183,8 @@ template <int W, int H> __device__ inline void inv_txfm_rect_add(const LDS int32
 }
 
 // tx set / CDF row of a 2:1 transform (oracle av1o_tx_set / av1o_intra_tx_cdf): the larger dimension (8) bounds the set, the smaller (4) indexes the CDFs
-template <typename FP> __device__ __forceinline__ int rect_tx_cdf(FP f, int ymode, int *nsyms, int *set_out) {
-  const int set = f->reduced_tx_set ? 2 : 1;
+template <int TS, typename FP> __device__ __forceinline__ int rect_tx_cdf(FP f, int ymode, int *nsyms, int *set_out) {
+  const int set = Tools<TS>::reduced_tx_set(f) ? 2 : 1;
   *set_out = set;
   if (f->base_q_idx == 0) { *nsyms = 0; return -1; }
   if (set == 1) { *nsyms = 7; return CDF_INTRA_TX1 + ymode * CDF_INTRA_TX1_STRIDE; }
@@ -286,8 +286,8 @@ __device__ inline int rect_quant_rate(CostPtr cost, LDS int32_t *cbuf, LDS int32
 
 // One 2:1 transform block by one wave (eval_tx for the rectangular sizes).  psv2 / act: the two 4x4 cells' source variances and the activity of the
 // 8x8 cell the block lies in (luma, Tune::Psychovisual); cact: the same activity for chroma.
-template <int MAXN, int WL, int HL, int NW, bool FULL>
-__device__ inline long long eval_rect(const Ctx<MAXN, NW, FULL> k, int plane, int sctx, int dctx, const LDS uint16_t *src, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+template <int MAXN, int WL, int HL, int NW, int TS>
+__device__ inline long long eval_rect(const Ctx<MAXN, NW, TS> k, int plane, int sctx, int dctx, const LDS uint16_t *src, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                       LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, int psv_a, int psv_b, int act) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W + 1, NN = W * H;
   const LDS FrameDev *f = k.f(); LDS WaveScratch<MAXN> *S = k.s();
@@ -306,7 +306,7 @@ __device__ inline long long eval_rect(const Ctx<MAXN, NW, FULL> k, int plane, in
     sd[cell] = d; qd[cell] = d * d; se[cell] = e * e;
   }
   long long dist;
-  if (plane == 0 && !f->tune_psnr) {
+  if (plane == 0 && !Tools<TS>::tune_psnr(f)) {
     dist = 0;
 #pragma unroll
     for (int cell = 0; cell < 2; cell++) {
@@ -535,8 +535,8 @@ template <typename FP, typename TP> __device__ inline void txb_ctx_wh(FP f, TP t
   } else *skip_ctx = 7 + (any_a != 0) + (any_l != 0) + (whole ? 0 : 3);
 }
 
-template <int MAXN, int BSR, int NW, bool FULL>
-__device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
+template <int MAXN, int BSR, int NW, int TS>
+__device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, int r, int c, long long budget = J_INF) {
   constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL, NN = W_ * H_, w4 = W_ >> 2, h4 = H_ >> 2;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -578,7 +578,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   PH(2);
   const int sctx_y = SH->sctx[0], dctx_y = SH->dctx[0];
   const LDS uint16_t *ra = SH->ra[0] + EDGE_OFF, *rl = SH->rl[0] + EDGE_OFF;
-  const int psv_a = f->tune_psnr ? 0 : SH->psv4[0], psv_b = f->tune_psnr ? 0 : SH->psv4[1], act = SH->pact[0];
+  const int psv_a = Tools<TS>::tune_psnr(f) ? 0 : SH->psv4[0], psv_b = Tools<TS>::tune_psnr(f) ? 0 : SH->psv4[1], act = SH->pact[0];
 
   // ---- luma: SATD over the 13 modes (mode m by wave m % NW), stable sort ----
   for (int m = W; m < 13; m += NW) {
@@ -596,10 +596,10 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   }
   WG_SYNC();
   // ---- full RD over the surviving modes x tx types (no angle deltas below 8x8): evaluation e = ci * ntx + ti by wave e % NW ----
-  const int ncand = FULL ? 7 : 3;
+  const int ncand = Tools<TS>::FULL ? 7 : 3;
   int tx_ns = 0, tx_set = 0;
-  const int tx_off0 = rect_tx_cdf(f, 0, &tx_ns, &tx_set);
-  const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
+  const int tx_off0 = rect_tx_cdf<TS>(f, 0, &tx_ns, &tx_set);
+  const int ntx = (Tools<TS>::rdo_tx(f) && tx_off0 >= 0) ? tx_ns : 1;
   // the surviving modes are predicted once (candidate ci by wave ci % NW) into the prediction cache and shared by their tx-type trials
   LDS uint16_t *pcache = MAXN <= 16 ? (LDS uint16_t *)SH->lpred : (LDS uint16_t *)SH->split_rec;      // [7][NN]; both are free until the tx-size trial
   for (int ci = W; ci < ncand; ci += NW) predict_block_wh(f, x, y, WL, HL, availL, availU, SH->order[ci], 0, ftype_y, ra, rl, wa, wl, S->etmp, pcache + ci * NN);
@@ -621,13 +621,13 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
       const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
       const uint32_t mode_rate = ycost[m];
       int ns2, set2;
-      const int tx_off = rect_tx_cdf(f, m, &ns2, &set2);
+      const int tx_off = rect_tx_cdf<TS>(f, m, &ns2, &set2);
       int txtype;
       if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
       else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
       GroupRes gr;
       eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[0], pcache + ci * NN, 0, txtype, sctx_y, dctx_y, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0,
-                            f->tune_psnr ? -1 : psv_a, psv_b, act, &gr);
+                            Tools<TS>::tune_psnr(f) ? -1 : psv_a, psv_b, act, &gr);
       long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
       if (!live) j = J_INF;
       bool improved = false;
@@ -655,7 +655,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     const LDS uint16_t *cpred = pcache + ci * NN;
     const uint32_t mode_rate = ycost[m];
     int ns2, set2;
-    const int tx_off = rect_tx_cdf(f, m, &ns2, &set2);
+    const int tx_off = rect_tx_cdf<TS>(f, m, &ns2, &set2);
     int txtype;
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
@@ -690,14 +690,14 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   const int best_mode = SH->lm_mode;
   long long luma_j = best_j; int any_coef = SH->lm_eob > 0;
   // ---- luma transform size: the 2:1 transform against its two 4x4 halves (Split_Tx_Size), tx_depth priced with the 8x8 category ----
-  if (f->tx_mode_select) {
+  if (Tools<TS>::tx_mode_select(f)) {
     const int actx = nb_txU >= 0 && dim_wl(nb_txU) >= WL, lctx = nb_txL >= 0 && dim_hl(nb_txL) >= HL;
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + (actx + lctx) * CDF_TX_SIZE_STRIDE;
     luma_j += ((long long)dcost[0] * f->rdmult + 256) >> 9;
-    if (f->rdo_tx) {
+    if (Tools<TS>::rdo_tx(f)) {
       long long j_split = SH->lm_mode_j + (((long long)dcost[1] * f->rdmult + 256) >> 9);
       int stx_ns = 0, stx_set = 0;
-      const int stx_off = intra_tx_cdf(f, 0, best_mode, &stx_ns, &stx_set);
+      const int stx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), 0, best_mode, &stx_ns, &stx_set);
       const int sntx = stx_off >= 0 ? stx_ns : 1;
       LDS uint16_t *split_rec = (LDS uint16_t *)SH->ssrc + 64;             // [NN] (ssrc[0..31] = the two sub-sources)
       LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;   // [2][16]
@@ -751,7 +751,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
           const int txtype = sym_to_txtype(stx_set, live ? e : 0);
           GroupRes gr;
           eval_group<4>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * 16, SH->spred, 0, 0, txtype, ssc, sdc, stx_off, txtype_to_sym(stx_set, txtype),
-                        f->tune_psnr ? -1 : SH->psv4[q], SH->pact[0], &gr);
+                        Tools<TS>::tune_psnr(f) ? -1 : SH->psv4[q], SH->pact[0], &gr);
           long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
           if (!live) j = J_INF;
 #pragma unroll
@@ -821,10 +821,10 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
   // ---- chroma with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four waves (plane x half of the range), then every
   // candidate of a plane in one grouped evaluation (waves 0 and 2, one candidate per 16-lane row) -- the square path's scheme (tile_search.h) ----
   bool cgrouped = false;
-  if constexpr (CAN_GROUP) cgrouped = f->np > 1 && !FULL;
+  if constexpr (CAN_GROUP) cgrouped = f->np > 1 && !Tools<TS>::FULL;
   if constexpr (CAN_GROUP) if (cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
-    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = f->reduced_tx_set ? 2 : 1;
+    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = Tools<TS>::reduced_tx_set(f) ? 2 : 1;
     const int mx = (1 << f->bd) - 1;
     {
       const int p = (W >> 1) + 1, half = W & 1;
@@ -912,19 +912,19 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, FULL> k, 
     total_j += best_uv;
   }
   // ---- chroma with the FULL candidate set of speed <= 1 (oracle order: DC, the luma mode, the other eleven modes, CfL), in the kernels instantiated for that set
-  // (Ctx::FULL): the CfL alpha scan on all four waves (plane x half of the range), then the candidates four per wavefront (eval_group_wh, one candidate per 16-lane
+  // (Tools<TS>::FULL): the CfL alpha scan on all four waves (plane x half of the range), then the candidates four per wavefront (eval_group_wh, one candidate per 16-lane
   // row): wave W takes plane W / 2 + 1 and the candidates of parity W % 2, eight candidates of a plane per round, two rounds -- the later candidates first, so that
   // the likely winners (DC, the luma mode) are still in the wave's buffers at the end; the first round's best waits in LDS (rec + levels: 192 B per plane).  Until
   // round 4 this set ran one candidate per ROUND on two waves (14 rounds of predict + evaluate + three barriers): half of config 5's critical path. ----
-  if constexpr (FULL) if (f->np > 1 && !cgrouped) {
+  if constexpr (Tools<TS>::FULL) if (f->np > 1 && !cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     unsigned long long cand_pack = 0; int nc = 0;
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (Tools<TS>::FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     push(UV_CFL_PRED);
-    const int uvset = f->reduced_tx_set ? 2 : 1;
+    const int uvset = Tools<TS>::reduced_tx_set(f) ? 2 : 1;
     const int mx = (1 << f->bd) - 1;
     const int p = (W >> 1) + 1, half = W & 1;
     const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;

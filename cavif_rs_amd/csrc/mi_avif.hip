@@ -216,14 +216,14 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 
 // ---- K1 launch: the tile search as a work queue of superblocks (tile_search.h) ----
 // Persistent workgroups: as many as the device holds at once for this instantiation (asked from the runtime, not assumed), capped by the number of items.
-template <int MAXBS, int NW, bool BU, bool CX> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+template <int MAXBS, int NW, bool BU, int TS> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   const size_t lds = k1_lds_bytes<MAXBS, NW>();
   static int resident[MI_MAX_DEVICES];                    // per instantiation and device; 0 = not asked yet
   if (resident[device] == 0) {
-    hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU, CX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)tile_search_kernel<MAXBS, NW, BU, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0, cus = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_search_kernel<MAXBS, NW, BU, CX>, 64 * NW, lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_search_kernel<MAXBS, NW, BU, TS>, 64 * NW, lds);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) return e;
@@ -234,18 +234,21 @@ template <int MAXBS, int NW, bool BU, bool CX> static hipError_t launch_search_t
   }
   const int grid = std::min(nitems, resident[device]);
   if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU, CX>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU, TS>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
   return hipGetLastError();
 }
 static size_t k1_snap_bytes(int maxbs) { return MI_K1_POOL_BYTES(maxbs); }
 // every frame of a launch comes from one encoder configuration, so the partition order (top-down / bottom-up) is per launch; the
 // jobs must all belong to frames of the same block-size class (one instantiation per class).  grid_out != nullptr: only report the grid.
-// `complex`: the full candidate set of speed <= 1 (complex_pred_modes) has its own instantiations (Ctx::FULL, tile_search.h): its chroma stage must not be part of the speed-4 kernels' code
-static hipError_t launch_search(int maxbs, bool bottomup, bool complex, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
+// `tools`: the tool set the kernels are instantiated for (tile_search.h Tools): bit 0 = the full candidate set of speed <= 1 (complex_pred_modes), bit 1 = the switches of
+// ravif's speed 4 as constants -- instantiated where speed 4 runs (blocks up to 16x16, top-down); any other combination of switches runs the general kernels
+static hipError_t launch_search(int maxbs, bool bottomup, int tools, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   if (nitems <= 0) { if (grid_out) *grid_out = 0; return hipSuccess; }
-#define MI_LAUNCH_(MB, BU_, CX_) launch_search_t<MB, 4, BU_, CX_>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s)
-  if (maxbs <= 2) return bottomup ? (complex ? MI_LAUNCH_(2, true, true) : MI_LAUNCH_(2, true, false)) : (complex ? MI_LAUNCH_(2, false, true) : MI_LAUNCH_(2, false, false));
-  return bottomup ? (complex ? MI_LAUNCH_(4, true, true) : MI_LAUNCH_(4, true, false)) : (complex ? MI_LAUNCH_(4, false, true) : MI_LAUNCH_(4, false, false));
+#define MI_LAUNCH_(MB, BU_, TS_) launch_search_t<MB, 4, BU_, TS_>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s)
+  const bool full = (tools & 1) != 0;
+  if (maxbs <= 2 && !bottomup && tools == 2) return MI_LAUNCH_(2, false, 2);
+  if (maxbs <= 2) return bottomup ? (full ? MI_LAUNCH_(2, true, 1) : MI_LAUNCH_(2, true, 0)) : (full ? MI_LAUNCH_(2, false, 1) : MI_LAUNCH_(2, false, 0));
+  return bottomup ? (full ? MI_LAUNCH_(4, true, 1) : MI_LAUNCH_(4, true, 0)) : (full ? MI_LAUNCH_(4, false, 1) : MI_LAUNCH_(4, false, 0));
 #undef MI_LAUNCH_
 }
 // jobs must all belong to frames of the same block-size class
@@ -300,10 +303,13 @@ namespace mi {
 // their class segment of d_jobs -- and enqueues one queue launch per class on `s`.
 // the launches over a work list that is already on the device (the second pass of a two-pass encode reuses the first one's)
 // every frame of a launch comes from one encoder configuration: which walker and which candidate set the kernels are instantiated for
-static int search_mode(const mi_av1_config &c) { return (c.encode_bottomup != 0 ? 1 : 0) | (c.complex_pred_modes != 0 ? 2 : 0); }
-static int search_launch(SearchQueue &q, int mode /* bit 0: bottom-up walker, bit 1: full candidate set */, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
+static int search_mode(const mi_av1_config &c) {            // bit 0: bottom-up walker; bits 1..: the kernels' tool set (tile_search.h Tools)
+  const bool speed4_switches = !c.complex_pred_modes && c.rdo_tx_decision && c.reduced_tx_set && c.fine_directional_intra && !c.tune_psnr;   // (tx_mode_select follows from rdo_tx_decision)
+  return (c.encode_bottomup != 0 ? 1 : 0) | (c.complex_pred_modes != 0 ? 2 : 0) | (speed4_switches ? 4 : 0);
+}
+static int search_launch(SearchQueue &q, int mode /* search_mode() */, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   for (int cls = 2; cls <= 4; cls++)
-    HIP_OK(launch_search(cls, (mode & 1) != 0, (mode & 2) != 0, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
+    HIP_OK(launch_search(cls, (mode & 1) != 0, mode >> 1, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
   return MI_OK;
 }
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
@@ -323,7 +329,7 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
     for (auto &v : by_key) q.items.insert(q.items.end(), v.begin(), v.end());
     const int nitems = (int)q.items.size() - q.q_begin[cls];
     int grid = 0;
-    HIP_OK(launch_search(cls, (mode & 1) != 0, (mode & 2) != 0, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
+    HIP_OK(launch_search(cls, (mode & 1) != 0, mode >> 1, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
     // How many superblocks can be at work at once under whole-superblock dependencies (a tile's wavefront is min(rows, cols / 2) wide): when that
     // leaves resident workgroups idle the launch synchronises per root block instead (tile_search.h root_wait); a full batch keeps the cheaper
     // one-acquire-one-release-per-superblock protocol.

@@ -492,7 +492,7 @@ template <int BSR> __device__ __forceinline__ void write_block_rect(TileWriter *
       int txtype, off = -1, sym = 0, ns = 0, set;
       if (p == 0) {
         txtype = v_txt;
-        off = split ? intra_tx_cdf(&w->txc, 0, ymode, &ns, &set) : rect_tx_cdf(&w->txc, ymode, &ns, &set);
+        off = split ? intra_tx_cdf(&w->txc, 0, ymode, &ns, &set) : rect_tx_cdf<0>(&w->txc, ymode, &ns, &set);
         if (off >= 0) sym = txtype_to_sym(set, txtype);
       } else {
         set = w->txc.reduced_tx_set ? 2 : 1;

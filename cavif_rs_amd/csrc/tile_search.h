@@ -123,9 +123,21 @@ template <int N> __device__ __forceinline__ LDS unsigned long long &mi_prof_slot
 // context is two 32-bit LDS pointers passed BY VALUE (registers): the accessors fold into ds_read offsets.  (It used to be a
 // struct on the kernel's stack passed by reference: every use inside the non-inlined block search was a flat load from scratch,
 // ~40 per call, each holding both wait counters.)
-// FULL: the kernel was instantiated for the full candidate set of speed <= 1 (complex_pred_modes); the host launches the matching instantiation, so FULL == f->complex_modes and the kernels read the template parameter
-template <int MAXN, int NW, bool FULL_ = false> struct Ctx {
-  static constexpr bool FULL = FULL_;
+// TS, the tool set a kernel is instantiated for (the host launches the matching instantiation, mi_avif.hip search_mode):
+//   bit 0 (FULL)  the full candidate set of speed <= 1 (complex_pred_modes): FULL == f->complex_modes, the kernels read the template parameter
+//   bit 1 (FIXED) the switches of ravif's speed 4 below the high-quality threshold (av1encoder.rs:576-586: rdo_tx_decision, reduced_tx_set, fine_directional_intra,
+//                 hence tx_mode_select; Tune::Psychovisual) are constants of the kernel instead of loads from the frame descriptor: the headline configuration's
+//                 block searches lose the code of the other settings (-3 % K1).  Every other combination of switches runs the instantiations without the bit.
+template <int TS> struct Tools {
+  static constexpr bool FULL = (TS & 1) != 0, FIXED = (TS & 2) != 0;
+  template <typename F> static __device__ __forceinline__ bool rdo_tx(F f) { return FIXED ? true : f->rdo_tx != 0; }
+  template <typename F> static __device__ __forceinline__ bool reduced_tx_set(F f) { return FIXED ? true : f->reduced_tx_set != 0; }
+  template <typename F> static __device__ __forceinline__ bool fine_directional(F f) { return FIXED ? true : f->fine_directional != 0; }
+  template <typename F> static __device__ __forceinline__ bool tx_mode_select(F f) { return FIXED ? true : f->tx_mode_select != 0; }
+  template <typename F> static __device__ __forceinline__ bool tune_psnr(F f) { return FIXED ? false : f->tune_psnr != 0; }
+};
+template <int MAXN, int NW, int TS_ = 0> struct Ctx {
+  static constexpr int TS = TS_;
   static constexpr int MAXBS = MAXN == 16 ? 2 : 4;     // the largest transform whose rate slices the class needs: the 32x32 class evaluates 64x64 blocks too (dev_blk64.h)
   static constexpr size_t SH_BYTES = (sizeof(SharedScratch<MAXN>) + 15) & ~(size_t)15, WS_BYTES = (sizeof(WaveScratch<MAXN>) + 15) & ~(size_t)15;
   static constexpr size_t SC_BYTES = SCAN_LDS_ENTRIES(MAXN) * 2, CC_BYTES = (COEF_COST_MAX_ENTRIES(MAXBS) * 2 + 15) & ~(size_t)15;
@@ -267,8 +279,8 @@ __device__ __forceinline__ uint32_t uv_mode_rate(const uint16_t *cost, const uin
 }
 
 // One transform block by one wave: residual -> fwd -> quant -> rate, dequant -> inverse -> recon; returns weighted J.
-template <int MAXN, int BS, int NW, bool FULL>
-__device__ inline long long eval_tx(const Ctx<MAXN, NW, FULL> k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
+template <int MAXN, int BS, int NW, int TS>
+__device__ inline long long eval_tx(const Ctx<MAXN, NW, TS> k, int plane, int sctx, int dctx, const LDS uint16_t *pred, int txtype, int tx_off, int tx_sym,
                                     LDS uint16_t *rec_out, LDS int32_t *qc_out, TxRes *tr, const LDS uint16_t *src_override = nullptr,
                                     const LDS int *psv = nullptr, const LDS int *pact = nullptr) {
   constexpr int n = 4 << BS, P = n + 1, CS = n < 32 ? n : 32;
@@ -294,7 +306,7 @@ __device__ inline long long eval_tx(const Ctx<MAXN, NW, FULL> k, int plane, int 
   tr->eob = eob;
   PH(20);
   // distortion: luma = psychovisual cdef-dist per 8x8 cell x activity; chroma = SSE x the block's mean activity
-  if (plane == 0 && !f->tune_psnr) tr->sse = psy_dist_wave<n>(src, rec_out, psv ? psv : (const LDS int *)k.sh()->psv, pact ? pact : (const LDS int *)k.sh()->pact, f->bd);
+  if (plane == 0 && !Tools<TS>::tune_psnr(f)) tr->sse = psy_dist_wave<n>(src, rec_out, psv ? psv : (const LDS int *)k.sh()->psv, pact ? pact : (const LDS int *)k.sh()->pact, f->bd);
   else { const long long e = sse_dev(src, rec_out, n * n); tr->sse = plane == 0 ? e : (e * k.sh()->cact + 8192) >> 14; }
   PH(21);
   return ((tr->sse * f->wq[plane]) >> 5) + (((long long)tr->rate * f->rdmult + 256) >> 9);
@@ -318,11 +330,11 @@ __device__ inline void commit_plane(const LDS FrameDev *f, int plane, int r, int
 // `budget`: the caller only needs to know whether the block's cost stays below it (split trials: cost of the
 // undivided block minus what the earlier sub-blocks already cost).  Costs only grow, so once the luma part alone
 // reaches the budget the rest of the evaluation cannot change the caller's decision and is skipped.
-template <int MAXN, int BS, int NW, bool FULL>
+template <int MAXN, int BS, int NW, int TS>
 // not_tail_called: with every argument in registers the calls would be marked `tail`, and LLVM's interprocedural register
 // allocation then refuses its no-callee-saved-registers treatment for this function (TargetFrameLowering::isSafeForNoCSROpt):
 // the prologue / epilogue would spill and reload 46 VGPRs + 34 SGPRs per call.
-__device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
+__device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, int c, long long budget = J_INF) {
   constexpr int n = 4 << BS, n4 = 1 << BS, log2w = 2 + BS, nn = n * n, CS = n < 32 ? n : 32, qn = CS * CS;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;
@@ -437,10 +449,10 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
   }
   WAVE_SYNC();
   PH(4);
-  const int ncand = FULL ? 7 : 3;
+  const int ncand = Tools<TS>::FULL ? 7 : 3;
   // angle-delta refinement by SATD: unit (ci, q) by wave (ci*6+q) % NW
   auto dl_of = [](int q) { const int a = (q >> 1) + 1; return (q & 1) ? a : -a; };        // -1, 1, -2, 2, -3, 3
-  const int refine = BS >= BS_8 && f->fine_directional;
+  const int refine = BS >= BS_8 && Tools<TS>::fine_directional(f);
   bool refine_grouped = false;
   if constexpr (SMALL_GROUPED) refine_grouped = refine && ncand == 3;
   if constexpr (SMALL_GROUPED) if (refine_grouped) {
@@ -479,9 +491,9 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
   }
   // ---- full RD over surviving (mode, delta) x tx type: eval e = ci*ntx + ti by wave e % NW ----
   int tx_ns = 0, tx_set = 0;
-  const int tx_off0 = intra_tx_cdf(f, BS, 0, &tx_ns, &tx_set);
-  const int ntx = (f->rdo_tx && tx_off0 >= 0) ? tx_ns : 1;
-  const bool tx_trial = BS > 0 && f->tx_mode_select && f->rdo_tx;        // one-level-smaller luma transforms are tried after the mode decision
+  const int tx_off0 = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), BS, 0, &tx_ns, &tx_set);
+  const int ntx = (Tools<TS>::rdo_tx(f) && tx_off0 >= 0) ? tx_ns : 1;
+  const bool tx_trial = BS > 0 && Tools<TS>::tx_mode_select(f) && Tools<TS>::rdo_tx(f);        // one-level-smaller luma transforms are tried after the mode decision
   LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;
   LDS uint16_t *split_rec = MAXN <= 16 ? SH->lpred + 512 : (LDS uint16_t *)SH->split_rec;
   LDS uint16_t *spred = SH->spred;
@@ -522,13 +534,13 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
         const int delta = SH->ldelta[ci];
         const uint32_t mode_rate = y_mode_rate(k.cost(), ycost, m, m >= V_PRED && m <= D67_PRED && BS >= BS_8, delta);
         int ns2, set2;
-        const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
+        const int tx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), BS, m, &ns2, &set2);
         int txtype;
         if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
         else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
         GroupRes gr;
         eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_y, dctx_y, tx_off,
-                      tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, f->tune_psnr ? -1 : SH->psv[0], SH->pact[0], &gr);
+                      tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, Tools<TS>::tune_psnr(f) ? -1 : SH->psv[0], SH->pact[0], &gr);
         long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
         if (!live) j = J_INF;
         bool improved = false;
@@ -567,7 +579,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
     }
     const uint32_t mode_rate = y_mode_rate(k.cost(), ycost, m, directional && BS >= BS_8, delta);
     int ns2, set2;
-    const int tx_off = intra_tx_cdf(f, BS, m, &ns2, &set2);
+    const int tx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), BS, m, &ns2, &set2);
     int txtype;
     if (ntx > 1) txtype = sym_to_txtype(tx_set, ti);
     else { txtype = mode_to_txtype(m); if (tx_off < 0 || txtype_to_sym(tx_set, txtype) < 0) txtype = DCT_DCT; }
@@ -615,7 +627,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
   // transform against four transforms one level smaller with the winning mode.  Each sub-block is predicted from the
   // reconstruction of the ones before it (spec transform_block), so the four steps are serial; inside a step the tx types
   // of the sub-block are dealt to the waves (16-lane rows for 4x4 / 8x8 transforms) like the candidates of a block.
-  if constexpr (BS > 0) if (f->tx_mode_select) {
+  if constexpr (BS > 0) if (Tools<TS>::tx_mode_select(f)) {
     const int maxw = 4 << BS;
     const int actx = nb_txU >= 0 && (1 << dim_wl(nb_txU)) >= maxw, lctx = nb_txL >= 0 && (1 << dim_hl(nb_txL)) >= maxw;   // neighbours may carry 2:1 transform codes
     const uint16_t *dcost = k.cost() + CDF_TX_SIZE + ((BS - 1) * 3 + actx + lctx) * CDF_TX_SIZE_STRIDE;
@@ -632,7 +644,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
         constexpr int SBS = BS - D, G = 1 << D, hn = n >> D, half = n4 >> D, hnn = hn * hn, SCS = hn < 32 ? hn : 32, sqn = SCS * SCS;
         long long j_split = SH->lm_mode_j + (((long long)dcost[D] * f->rdmult + 256) >> 9);
         int stx_ns = 0, stx_set = 0;
-        const int stx_off = intra_tx_cdf(f, SBS, best_mode, &stx_ns, &stx_set);
+        const int stx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), SBS, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
         int sub_any = 0;
 #if MI_PROFILE
@@ -750,7 +762,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
               else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
               GroupRes gr;
               eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
-                             f->tune_psnr ? -1 : psv_q, pact_q, &gr);
+                             Tools<TS>::tune_psnr(f) ? -1 : psv_q, pact_q, &gr);
               long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
               if (!live) j = J_INF;
 #pragma unroll
@@ -921,10 +933,10 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
   // ---- chroma, 4x4 / 8x8 blocks with the simple candidate set (DC, luma's mode, CfL): the CfL alpha scan on all four
   // waves (plane x half of the range), then every candidate of a plane in one grouped evaluation (dev_group.h) ----
   bool cgrouped = false;
-  if constexpr (SMALL_GROUPED) cgrouped = f->np > 1 && !FULL;
+  if constexpr (SMALL_GROUPED) cgrouped = f->np > 1 && !Tools<TS>::FULL;
   if constexpr (SMALL_GROUPED) if (cgrouped) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
-    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, f->reduced_tx_set);
+    const int nplain = best_mode != DC_PRED ? 2 : 1, nc = nplain + 1, uvset = tx_set_of(BS, Tools<TS>::reduced_tx_set(f));
     const int bdelta = (best_mode >= V_PRED && best_mode <= D67_PRED && BS >= BS_8) ? best_delta : 0;
     const int mx = (1 << f->bd) - 1;
     {
@@ -1050,16 +1062,16 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
   // are still in the wave's buffers at the end; the first round's best waits in LDS (dev_rect.h has the same scheme for the 2:1 blocks).  Until round 4 this set ran
   // one candidate per wave pair and round (seven rounds of predict + evaluate + two barriers); measured on config 5: tile search 5.54 -> 3.94 s with both. ----
   bool cfull = false;
-  if constexpr (SMALL_GROUPED && FULL) cfull = f->np > 1 && FULL;
-  if constexpr (SMALL_GROUPED && FULL) if (cfull) {
+  if constexpr (SMALL_GROUPED && Tools<TS>::FULL) cfull = f->np > 1 && Tools<TS>::FULL;
+  if constexpr (SMALL_GROUPED && Tools<TS>::FULL) if (cfull) {
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     unsigned long long cand_pack = 0; int nc = 0;
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (Tools<TS>::FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     push(UV_CFL_PRED);
-    const int uvset = tx_set_of(BS, f->reduced_tx_set);
+    const int uvset = tx_set_of(BS, Tools<TS>::reduced_tx_set(f));
     const int mx = (1 << f->bd) - 1;
     const int p = (W >> 1) + 1, half = W & 1;
     const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
@@ -1205,9 +1217,9 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
     push(DC_PRED);
     if (best_mode != DC_PRED) push(best_mode);
-    if (FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
+    if (Tools<TS>::FULL) for (int m = 1; m < 13; m++) if (m != best_mode) push(m);
     if (cfl_allowed) push(UV_CFL_PRED);
-    const int uvset = tx_set_of(BS, f->reduced_tx_set);
+    const int uvset = tx_set_of(BS, Tools<TS>::reduced_tx_set(f));
     constexpr int NPAIR = 2;
     const int pair = ((W >> 1) & 1) ^ 1, active = W < 4;      // pair 0 (two plain candidates) = waves 2, 3: they have the lighter luma share
     long long pb_j = J_INF; int pb_c = 1 << 30, pb_delta = 0, pb_sign = 0, pb_au = 0, pb_av = 0, ccur = 0; TxRes pb_tr = { 0, 0, 0, 0, 0 };
@@ -1373,7 +1385,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, FULL> k, int r
 
 #include "dev_blk64.h"
 // the evaluation of one block: the generic search, or -- for the 64x64 level of the 32x32 class -- its cooperative form
-template <int MAXN, int BS, int NW, bool FULL> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW, FULL> k, int r, int c, long long budget = J_INF) {
+template <int MAXN, int BS, int NW, int TS> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW, TS> k, int r, int c, long long budget = J_INF) {
   if constexpr (MAXN == 32 && BS == 4) return try_block64<NW>(k, r, c, budget); else return try_block<MAXN, BS, NW>(k, r, c, budget);
 }
 
@@ -1472,7 +1484,7 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
 // superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
 __device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) | (bj & 1) | ((bi & 2) << 2) | ((bj & 2) << 1); }   // Morton index in the superblock
-template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_wait(const Ctx<MAXN, NW, FULL> k, int r, int c) {
+template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t();
   if (threadIdx.x == 0) {
@@ -1496,7 +1508,7 @@ template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_wa
   WG_SYNC();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_publish(const Ctx<MAXN, NW, FULL> k, int r, int c) {
+template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_publish(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f();
   WG_SYNC();                                                               // every wave's stores of this root are issued
@@ -1507,7 +1519,7 @@ template <int MAXBS, int MAXN, int NW, bool FULL> __device__ inline void root_pu
 }
 
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
-  template <bool FULL> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, FULL> k, int r, int c, long long known_j) {
+  template <int TS> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, TS> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
@@ -1580,7 +1592,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPart<MAXN, MAXBS, 0, NW> {
-  template <bool FULL> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, FULL> k, int r, int c, long long known_j) {
+  template <int TS> static __device__ MI_K1_WALK_INLINE int run(const Ctx<MAXN, NW, TS> k, int r, int c, long long known_j) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     if (known_j >= 0) return 0;
@@ -1598,7 +1610,7 @@ template <int MAXN> __device__ __forceinline__ constexpr size_t snap_level_off(i
   return o;
 }
 template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
-  template <bool FULL> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, FULL> k, int r, int c) {
+  template <int TS> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, TS> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     constexpr int half = (1 << BS) >> 1, px = 4 << BS, n4 = 1 << BS;
@@ -1649,7 +1661,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
   }
 };
 template <int MAXN, int MAXBS, int NW> struct RdPartBU<MAXN, MAXBS, 0, NW> {
-  template <bool FULL> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, FULL> k, int r, int c) {
+  template <int TS> static __device__ MI_K1_WALK_INLINE long long run(const Ctx<MAXN, NW, TS> k, int r, int c) {
     const LDS FrameDev *f = k.f();
     if (r >= f->mi_rows || c >= f->mi_cols) return 0;
     return uni64(blk_eval<MAXN, 0, NW>(k, r, c));
@@ -1682,12 +1694,12 @@ static_assert(sizeof(Blk64Wave) <= offsetof(WaveScratch<32>, lev) - offsetof(Wav
 // (no resident slot idles while its tile's neighbours are still at work); it also replaces the row workers single images used to get.
 struct SbItem { uint32_t job; uint16_t sbr, sbc; };
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
-template <int MAXBS, int NW, bool BU, bool CX>
+template <int MAXBS, int NW, bool BU, int TS>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
                                                                                                           const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
   constexpr int MAXN = k1_maxn(MAXBS);
   extern __shared__ __align__(16) uint8_t smem[];
-  using K = Ctx<MAXN, NW, CX>;
+  using K = Ctx<MAXN, NW, TS>;
   K k;
   k.base = (LDS uint8_t *)smem;
   k.ws = (LDS WaveScratch<MAXN> *)(smem + K::SH_BYTES + (size_t)(NW > 1 ? WAVE_ID : 0) * K::WS_BYTES);
