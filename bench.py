@@ -247,8 +247,8 @@ def end_to_end(n_files, w, h, speed, quality, depth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE config 4: 256 images / 8 GPUs)')
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
@@ -261,7 +261,7 @@ def main():
     ap.add_argument('--no-pcie-loop', action='store_true', help='skip the second timed loop (H2D inside the region)')
     ap.add_argument('--secondary', action='store_true', help='also time BASELINE configs 2, 3 and 5 (single images; config 5 takes a while)')
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
-    ap.add_argument('--pipeline', type=int, default=3, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 3 measured best on MI355X)')
+    ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 4 measured best on MI355X: profiles/r04y_slots_probe.txt)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -304,7 +304,7 @@ def main():
     device = local_rank % ndev
     enc = m.Encoder().with_quality(args.quality).with_speed(args.speed).with_bit_depth(args.depth).with_device(device)
     w, h, B = args.width, args.height, args.batch
-    depth_q = max(1, args.pipeline)
+    depth_q = max(1, min(args.pipeline, args.steps))         # a slot that no timed step would use is not created (its outputs could not be checked either)
     batches = [m.BatchEncoder(enc, B, w, h, channels=3) for _ in range(depth_q)]
     batch = batches[0]
     first = None

@@ -303,9 +303,18 @@ namespace mi {
 // their class segment of d_jobs -- and enqueues one queue launch per class on `s`.
 // the launches over a work list that is already on the device (the second pass of a two-pass encode reuses the first one's)
 // every frame of a launch comes from one encoder configuration: which walker and which candidate set the kernels are instantiated for
-static int search_mode(const mi_av1_config &c) {            // bit 0: bottom-up walker; bits 1..: the kernels' tool set (tile_search.h Tools)
-  const bool speed4_switches = !c.complex_pred_modes && c.rdo_tx_decision && c.reduced_tx_set && c.fine_directional_intra && !c.tune_psnr;   // (tx_mode_select follows from rdo_tx_decision)
-  return (c.encode_bottomup != 0 ? 1 : 0) | (c.complex_pred_modes != 0 ? 2 : 0) | (speed4_switches ? 4 : 0);
+// bit 0: bottom-up walker; bits 1..: the kernels' tool set (tile_search.h Tools).  The walker and the candidate set follow from the speed alone, the same for every frame of a
+// launch; rdo_tx_decision also depends on the frame's quantiser (av1encoder.rs:576: `speed <= 4 && !high_quality`), and a launch holds the colour and the alpha frames of
+// its pictures, each with its own quality: the kernels with the speed-4 switches as constants run only when EVERY frame of the launch has them.
+static int search_mode(const std::vector<FramePlan> &frames) {
+  if (frames.empty()) return 0;
+  const mi_av1_config &c0 = frames[0].cfg;
+  bool speed4_switches = true;
+  for (const FramePlan &p : frames) {
+    const mi_av1_config &c = p.cfg;
+    speed4_switches = speed4_switches && !c.complex_pred_modes && c.rdo_tx_decision && c.reduced_tx_set && c.fine_directional_intra && !c.tune_psnr;   // (tx_mode_select follows from rdo_tx_decision)
+  }
+  return (c0.encode_bottomup != 0 ? 1 : 0) | (c0.complex_pred_modes != 0 ? 2 : 0) | (speed4_switches ? 4 : 0);
 }
 static int search_launch(SearchQueue &q, int mode /* search_mode() */, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   for (int cls = 2; cls <= 4; cls++)
@@ -315,7 +324,7 @@ static int search_launch(SearchQueue &q, int mode /* search_mode() */, const int
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   q.items.clear();
   size_t snap_need = 0;
-  const int mode = frames.empty() ? 0 : search_mode(frames[0].cfg);
+  const int mode = search_mode(frames);
   for (int cls = 2; cls <= 4; cls++) {
     q.q_begin[cls] = (int)q.items.size();
     std::vector<std::vector<SbItem>> by_key;
@@ -648,7 +657,7 @@ int mi_batch_encode_async(mi_batch *b) {
     hipLaunchKernelGGL(segment_kernel, dim3(nframes), dim3(256), 0, s, b->d_frames);
     HIP_OK(hipEventRecord(b->ev[1], s));
     if (pass == 0) { if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st; }
-    else if (int st = search_launch(b->queue, search_mode(b->frames[0].cfg), class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
+    else if (int st = search_launch(b->queue, search_mode(b->frames), class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
     HIP_OK(hipEventRecord(b->ev[2], s));
     HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
     HIP_OK(hipEventRecord(b->ev[4], s));
@@ -1050,7 +1059,7 @@ int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], 
       hipLaunchKernelGGL(activity_kernel, dim3(((p.pw / 8) * (p.ph / 8) + 255) / 256, 1), dim3(256), 0, s, d_frame);
       hipLaunchKernelGGL(segment_kernel, dim3(1), dim3(256), 0, s, d_frame);
       if (pass == 0) { if (int st = search_enqueue(g.queue, one, jobs, class_begin, d_frame, d_jobs, cfg->device, s)) return st; }
-      else if (int st = search_launch(g.queue, search_mode(p.cfg), class_begin, d_frame, d_jobs, cfg->device, s)) return st;
+      else if (int st = search_launch(g.queue, search_mode(one), class_begin, d_frame, d_jobs, cfg->device, s)) return st;
       HIP_OK(launch_loop_filters(d_frame, 1, p.mi_cols * p.mi_rows * 4, p.sb_cols * p.sb_rows, p.cfg.lrf ? lr_units_host(p.cfg.width) * lr_units_host(p.cfg.height) : 0, p.cfg.sgr_full ? 16 : 4, s, nullptr));
       HIP_OK(launch_entropy(p.maxbs, d_frame, d_jobs, njobs, d_pre, cap, g.d_rec, rec_cap, s));
     }

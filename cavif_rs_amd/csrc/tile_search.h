@@ -42,8 +42,11 @@
 // phase timers (profiling builds only): per wave, accumulated in LDS, flushed to the tile's clock record
 #if MI_PROFILE
 #define PH_BEGIN() unsigned long long ph_t_ = clock64()
-#define PH(i) do { const unsigned long long n_ = clock64(); if (LANE == 0) SH->prof[W][i] += n_ - ph_t_; ph_t_ = n_; } while (0)
+#define PH(i) do { const unsigned long long n_ = clock64(); if (LANE == 0 && !(MI_PROFILE == 3 && (i) >= 16 && (i) <= 21)) SH->prof[W][i] += n_ - ph_t_; ph_t_ = n_; } while (0)
+// -DMI_PROFILE=3: slots 16..21 hold the time per block size (4x4, 8x8, 16x16, 32x32 / 64x64, 8x4, 4x8) instead of the evaluation's sub-phases
+#define PH_SIZE(slot, call) [&]() { const unsigned long long t0_ = clock64(); const long long r_ = (call); if (MI_PROFILE == 3 && LANE == 0) k.sh()->prof[WAVE_ID][16 + (slot)] += clock64() - t0_; return r_; }()
 #else
+#define PH_SIZE(slot, call) (call)
 #define PH_BEGIN() do {} while (0)
 #define PH(i) do {} while (0)
 #endif
@@ -1386,7 +1389,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
 #include "dev_blk64.h"
 // the evaluation of one block: the generic search, or -- for the 64x64 level of the 32x32 class -- its cooperative form
 template <int MAXN, int BS, int NW, int TS> __device__ __forceinline__ long long blk_eval(const Ctx<MAXN, NW, TS> k, int r, int c, long long budget = J_INF) {
-  if constexpr (MAXN == 32 && BS == 4) return try_block64<NW>(k, r, c, budget); else return try_block<MAXN, BS, NW>(k, r, c, budget);
+  if constexpr (MAXN == 32 && BS == 4) return PH_SIZE(3, try_block64<NW>(k, r, c, budget)); else return PH_SIZE(BS < 3 ? BS : 3, (try_block<MAXN, BS, NW>(k, r, c, budget)));
 }
 
 // ---- area snapshot (NONE-vs-SPLIT comparison), kept in the workgroup's HBM scratch; whole workgroup ----
@@ -1560,12 +1563,12 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
           if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
           {
             long long j = uni64(part_j(k.sh(), f, BS, pctx, 1));
-            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
+            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(PH_SIZE(4, (try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j))));
             if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
           }
           {
             long long j = uni64(part_j(k.sh(), f, BS, pctx, 2));
-            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
+            for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(PH_SIZE(5, (try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j))));
             if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
           }
           if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); return 1; }   // 1: the later siblings' trial results are stale
@@ -1644,12 +1647,12 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPartBU {
       if (j_split < j_none) { j_best = j_split; area_copy_dev<BS, NW>(f, split_snap, r, c, 1); have_split = 1; }
       {
         long long j = uni64(part_j(k.sh(), f, BS, pctx, 1));
-        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j));
+        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(PH_SIZE(4, (try_block_rect<MAXN, BS_8X4, NW>(k, r + k2, c, j_best - j))));
         if (j < j_best) { j_best = j; rect_won = 1; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
       }
       {
         long long j = uni64(part_j(k.sh(), f, BS, pctx, 2));
-        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j));
+        for (int k2 = 0; k2 < 2 && j < j_best; k2++) j += uni64(PH_SIZE(5, (try_block_rect<MAXN, BS_4X8, NW>(k, r, c + k2, j_best - j))));
         if (j < j_best) { j_best = j; rect_won = 2; area_copy_dev<BS, NW>(f, best_snap, r, c, 1); }
       }
       if (rect_won) { area_copy_dev<BS, NW>(f, best_snap, r, c, 0); return j_best; }

@@ -57,9 +57,9 @@ def test_emulated_kernels_64x64_level(emu_env):
 
 def test_emulated_batch_api_equals_oracle(emu_env):
     """The batch entry points under the emulator's thread pool: work lists that span several frames (colour and colour + alpha images, two block-size
-    classes in one encode, top-down and bottom-up order) equal the oracle byte for byte."""
+    classes in one encode, top-down and bottom-up order, colour and alpha frames on different sides of the high-quality threshold) equal the oracle byte for byte."""
     p, rows = _run(emu_env, 'batch', 1200)
-    assert len(rows) == 4 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
+    assert len(rows) == 6 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
 def test_product_library_is_not_the_emulator():

@@ -245,3 +245,21 @@ def test_near_lossless_noise_grows_the_packed_buffers(oracle):
     ref, _, _ = oracle.ravif_encode(im, quality=100, speed=8, depth=10)
     assert got.avif_file == ref
     assert e.encode_rgb(im).avif_file == ref                     # the grown pair is kept (pooled object)
+
+
+@pytest.mark.parametrize('q,aq', [(95, 40), (40, 95), (81, 80), (80, 81)])
+def test_colour_and_alpha_frames_with_different_switches(oracle, q, aq):
+    """A picture's colour and alpha frames are searched in one launch, each with its own quality: rdo_tx_decision is `speed <= 4 && !high_quality`
+    (ravif/src/av1encoder.rs:556,576), so the two frames of one launch can differ in it.  The launch must then run the general kernels, not the ones that hold the
+    speed-4 switches as constants (tile_search.h Tools; found by tools/gpu_random_sweep.py in round 4: 3 of 150 cases)."""
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(200, 136, index=q + aq, alpha=True)
+    e = m.Encoder().with_quality(q).with_alpha_quality(aq).with_speed(4).with_bit_depth(10)
+    ref, col, al = oracle.ravif_encode(img, quality=q, alpha_quality=aq, speed=4, depth=10, alpha_mode=1)
+    assert e.encode_rgba(img).avif_file == ref
+    b = m.BatchEncoder(e, 2, 200, 136, 4)
+    for i in range(2): b.upload(i, img)
+    b.encode()
+    assert b.get(0).avif_file == ref and b.get(1).avif_file == ref
+    b.close()

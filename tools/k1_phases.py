@@ -29,6 +29,9 @@ print('stage_ms', b.stage_ms())
 print('mean cycles per wave per tile: %.3g' % tot.mean())
 for i, n in enumerate(names):
     print('%-18s %6.2f%%   (wave0 %.2f%%, wave3 %.2f%%)' % (n, 100 * p[:, :, i].sum() / tot.sum(), 100 * p[:, 0, i].sum() / tot[:, 0].sum(), 100 * p[:, 3, i].sum() / tot[:, 3].sum()))
+if len(sys.argv) > 2 and sys.argv[2] == 'sizes':      # a -DMI_PROFILE=3 library: slots 16..21 = time per block size
+    print('by block size, share of the kernel: ' + '  '.join('%s %.2f%%' % (n, 100 * sub[:, :, i].sum() / tot.sum()) for i, n in enumerate(['4x4', '8x8', '16x16', '32x32+', '8x4', '4x8'])))
+    sys.exit(0)
 print('eval_tx split (share of the time spent inside evaluations):')
 for i, n in enumerate(['residual', 'fwd_txfm', 'quantize', 'coef_rate', 'dequant_inverse', 'sse']):
     print('  %-16s %6.2f%%  (%.2f%% of the kernel)' % (n, 100 * sub[:, :, i].sum() / sub.sum(), 100 * sub[:, :, i].sum() / tot.sum()))
