@@ -409,7 +409,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBS, 8),
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
                                                                              "quality": args.quality, "bit_depth": args.depth}),
-                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, area snapshots and partial-line coefficient writes (not spill scratch: profiles/r04_kernel_resources.txt), served by L2 / Infinity Cache at ~0.6 TB/s -- not what limits the kernel (waves parked 64 % of their cycles inside the evaluations, profiles/r04_pmc_summary.json)",
+                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, area snapshots and partial-line coefficient writes (not spill scratch: profiles/r04_kernel_resources.txt), served by L2 / Infinity Cache at ~0.6 TB/s -- not what limits the kernel: the step costs 2.76 ms per 1e9 VALU-active cycles of its kernels however they are overlapped (K1 at 2, 3 or 4 workgroups per CU under 3-4 batch slots: 147-148 ms per step each time, profiles/r04x_k1_grid_per_cu_vs_slots.txt; counters: profiles/r04_final_pmc_summary.json)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
                          "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
                          "overlapped_launch_ms": round(k1_overlapped, 3)},
