@@ -321,6 +321,29 @@ static int search_launch(SearchQueue &q, int mode /* search_mode() */, const int
     HIP_OK(launch_search(cls, (mode & 1) != 0, mode >> 1, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
   return MI_OK;
 }
+// the queue's device objects hold `nitems` work items and `snap_need` bytes of area snapshots (grown, never shrunk).  hipFree / hipMalloc wait for the device:
+// a batch object reserves its worst case when it is made (search_reserve), so that an encode whose image count grows does not stall behind the other slots' kernels
+static int queue_fit(SearchQueue &q, size_t nitems, size_t snap_need, hipStream_t s) {
+  if (nitems > q.items_cap) {
+    if (q.d_items) (void)hipFree(q.d_items); if (q.h_items) (void)hipHostFree(q.h_items);
+    q.d_items = nullptr; q.h_items = nullptr; q.items_cap = nitems + nitems / 8;
+    HIP_OK(hipMalloc(&q.d_items, q.items_cap * sizeof(SbItem))); HIP_OK(hipHostMalloc(&q.h_items, q.items_cap * sizeof(SbItem)));
+  }
+  if (!q.d_next) { HIP_OK(hipMalloc(&q.d_next, 16 * sizeof(int))); HIP_OK(hipMemsetAsync(q.d_next, 0, 16 * sizeof(int), s)); }   // once: every launch leaves its pair zeroed
+  if (snap_need > q.snap_bytes) { if (q.d_snap) (void)hipFree(q.d_snap); q.d_snap = nullptr; q.snap_bytes = snap_need; HIP_OK(hipMalloc(&q.d_snap, snap_need)); }
+  return MI_OK;
+}
+static int search_reserve(SearchQueue &q, const std::vector<FramePlan> &frames, int device, hipStream_t s) {
+  size_t per_class[5] = { 0, 0, 0, 0, 0 }, items = 0, snap_need = 0;
+  for (const FramePlan &p : frames) { per_class[std::max(p.maxbs, 2)] += (size_t)p.sb_rows * p.sb_cols; items += (size_t)p.sb_rows * p.sb_cols; }
+  const int mode = search_mode(frames);
+  for (int cls = 2; cls <= 4; cls++) for (int tools : { mode >> 1, (mode >> 1) & ~2 }) {        // a run with fewer frames may run the other instantiation (search_mode)
+    int grid = 0;
+    HIP_OK(launch_search(cls, (mode & 1) != 0, tools, nullptr, nullptr, nullptr, (int)per_class[cls], nullptr, nullptr, &grid, device, s));
+    snap_need = std::max(snap_need, (size_t)grid * k1_snap_bytes(cls));
+  }
+  return queue_fit(q, items, snap_need, s);
+}
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   q.items.clear();
   size_t snap_need = 0;
@@ -353,13 +376,7 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
     snap_need = std::max(snap_need, (size_t)grid * k1_snap_bytes(cls));
   }
   q.q_begin[5] = (int)q.items.size();
-  if (q.items.size() > q.items_cap) {
-    if (q.d_items) (void)hipFree(q.d_items); if (q.h_items) (void)hipHostFree(q.h_items);
-    q.d_items = nullptr; q.h_items = nullptr; q.items_cap = q.items.size() + q.items.size() / 8;
-    HIP_OK(hipMalloc(&q.d_items, q.items_cap * sizeof(SbItem))); HIP_OK(hipHostMalloc(&q.h_items, q.items_cap * sizeof(SbItem)));
-  }
-  if (!q.d_next) { HIP_OK(hipMalloc(&q.d_next, 16 * sizeof(int))); HIP_OK(hipMemsetAsync(q.d_next, 0, 16 * sizeof(int), s)); }   // once: every launch leaves its pair zeroed
-  if (snap_need > q.snap_bytes) { if (q.d_snap) (void)hipFree(q.d_snap); q.d_snap = nullptr; q.snap_bytes = snap_need; HIP_OK(hipMalloc(&q.d_snap, snap_need)); }
+  if (int st = queue_fit(q, q.items.size(), snap_need, s)) return st;
   memcpy(q.h_items, q.items.data(), q.items.size() * sizeof(SbItem));
   HIP_OK(hipMemcpyAsync(q.d_items, q.h_items, q.items.size() * sizeof(SbItem), hipMemcpyHostToDevice, s));
   return search_launch(q, mode, class_begin, d_frames, d_jobs, device, s);
@@ -464,7 +481,7 @@ static int batch_alloc(mi_batch *b) {
   HIP_OK(hipHostMalloc(&b->h_alpha, sizeof(int) * b->cap));
   HIP_OK(hipHostMalloc(&b->h_frames, sizeof(FrameDev) * worst.size()));
   HIP_OK(hipHostMalloc(&b->h_jobs, sizeof(TileJob) * max_tiles));
-  return MI_OK;
+  return search_reserve(b->queue, worst, b->device, b->stream);   // the tile search's work list and snapshot pool for a full batch: no (device-synchronising) reallocation inside an encode
 }
 
 extern "C" {
@@ -945,7 +962,9 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
           if (sp == x.width) memcpy(dst, x.pixels, row * d0.height);
           else for (uint32_t y = 0; y < d0.height; y++) memcpy(dst + y * row, x.pixels + (size_t)y * sp * d0.channels, row);
         }
+        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d staged\n", since(), dev, j);
         rc = mi_batch_upload_async(sl.b, 0, (int)run.size());
+        if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: slot %d upload enqueued\n", since(), dev, j);
       }
       if (release) for (size_t k : run) release(user, i0 + k);   // staged (or failed): the caller's pixels are no longer read
       if (rc == MI_OK) rc = mi_batch_encode_async(sl.b);
