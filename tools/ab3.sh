@@ -1,4 +1,4 @@
-for rep in 1 2 3; do for lib in tools/variants/fixed_tools.so tools/variants/o2.so; do
+for rep in 1 2 3; do for lib in tools/variants/o3_cur.so tools/variants/o2_cur.so; do
   MI_AVIF_LIB=$lib python bench.py --steps 4 --warmup 1 --pipeline 1 --no-cpu-baseline --no-pcie-loop --end-to-end 0 2>&1 | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); st=d['stage_ms_per_step']
