@@ -70,8 +70,12 @@ static void re_encode_q15(RangeEnc *e, uint32_t fl, uint32_t fh, int s, int nsym
 void re_symbol_noadapt(RangeEnc *e, int s, const uint16_t *icdf, int nsyms) {
   re_encode_q15(e, s > 0 ? icdf[s - 1] : 32768, icdf[s], s, nsyms);
 }
+/* tools/k4_row_balance.py only (how the entropy kernel's adapter waves should share the CDF rows): with AV1O_SYM_HIST=<file> in the environment av1o_code_tile
+ * points av1o_hist_base at the tile's CDF array and every adaptive symbol is counted under its row's offset; the tile's 65536 counters are appended to the file */
+const uint16_t *av1o_hist_base = NULL; unsigned *av1o_hist = NULL;
 void re_symbol(RangeEnc *e, int s, uint16_t *icdf, int nsyms) {
   re_symbol_noadapt(e, s, icdf, nsyms);
+  if (av1o_hist_base && icdf >= av1o_hist_base && icdf - av1o_hist_base < 65536) av1o_hist[icdf - av1o_hist_base]++;
   /* spec 8.3.2 symbol adaptation, on inverse CDFs */
   int cnt = icdf[nsyms];
   int rate = 3 + (cnt > 15) + (cnt > 31) + imin(ilog_nz((uint32_t)nsyms) - 1, 2);

@@ -2,6 +2,7 @@
  * rate estimator and the tile bitstream writer, and phase 2: the tile writer itself (spec 5.11.1-5.11.36:
  * decode_partition / intra_frame_mode_info / residual), driven by the mode-info maps phase 1 left behind.
  * TEST INFRASTRUCTURE (see av1o.h).  rav1e equivalents: src/context/*.rs, src/ec.rs (absent). */
+#include <stdio.h>
 #include "av1o_int.h"
 #include "av1o_syms.h"
 
@@ -155,6 +156,7 @@ uint32_t av1o_coef_rate_full(const Av1oFrame *f, const int32_t *qc, int eob, int
 }
 
 /* ---------------- phase 2: tile writer ---------------- */
+extern const uint16_t *av1o_hist_base; extern unsigned *av1o_hist;
 typedef struct { RangeEnc ec; uint16_t cdf[CDF_TOTAL]; Av1oFrame *f; TileB t; uint8_t *cdef_done; uint16_t lr_cdf[4]; int lr_ref[3][2]; } TileW;
 static void lr_sym(void *u, int s, int n) { TileW *w = (TileW *)u; re_symbol(&w->ec, s, w->lr_cdf, n); }
 static void ec_sym(void *u, int off, int s, int n) { TileW *w = (TileW *)u; re_symbol(&w->ec, s, w->cdf + off, n); }
@@ -293,6 +295,8 @@ size_t av1o_code_tile(Av1oFrame *f, int tile_row, int tile_col, uint8_t **out) {
   memcpy(w->cdf, f->cdf0, sizeof(w->cdf));
   w->cdef_done = (uint8_t *)calloc((size_t)f->sb_rows * f->sb_cols, 1);
   re_init(&w->ec);
+  const char *hist_path = getenv("AV1O_SYM_HIST");              /* tools only, single-threaded runs (av1o_common.c) */
+  if (hist_path) { av1o_hist = (unsigned *)calloc(65536, sizeof(unsigned)); av1o_hist_base = w->cdf; }
   /* tile start: switchable restoration_type CDF (libaom AOM_CDF3(9413, 22581)), RefSgrXqd = Sgrproj_Xqd_Mid */
   w->lr_cdf[0] = 32768 - 9413; w->lr_cdf[1] = 32768 - 22581; w->lr_cdf[2] = 0; w->lr_cdf[3] = 0;
   for (int p = 0; p < 3; p++) { w->lr_ref[p][0] = -32; w->lr_ref[p][1] = 31; }
@@ -302,6 +306,7 @@ size_t av1o_code_tile(Av1oFrame *f, int tile_row, int tile_col, uint8_t **out) {
       write_partition(w, r, c, BS_64);
     }
   if (f->tile_cdf) memcpy(f->tile_cdf + (size_t)(tile_row * f->tile_cols + tile_col) * CDF_TOTAL, w->cdf, sizeof(w->cdf));   /* what a second pass prices this tile against */
+  if (hist_path) { FILE *fh = fopen(hist_path, "ab"); if (fh) { fwrite(av1o_hist, sizeof(unsigned), 65536, fh); fclose(fh); } av1o_hist_base = NULL; free(av1o_hist); av1o_hist = NULL; }
   size_t n = re_finish(&w->ec, out);
   re_free(&w->ec);
   free(w->cdef_done);
