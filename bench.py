@@ -47,6 +47,36 @@ def hbm_traffic_bytes(kernel, cfg):
         return None
 
 
+VALU_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz max clock; a SIMD issues at most one VALU instruction per cycle to one of its waves
+
+
+def valu_roofline(kernel, cfg, launch_ms, pixels):
+    """What actually bounds the tile search: VALU issue.  From the committed SQ_* counter pass (profiles/valu_counters.json, tools/final_profile.sh; taken on this
+    workload) and THIS run's launch duration: the fraction of the chip's VALU issue cycles the kernel kept busy, the share of lanes its VALU instructions had
+    active, and the VALU work per pixel.  None when the counters are for another workload."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'valu_counters.json')) as fh:
+            d = json.load(fh)
+        if any(d['config'].get(k_) != v_ for k_, v_ in cfg.items()):
+            return None
+        c = d['kernels'][kernel]
+        act, thr = c['SQ_ACTIVE_INST_VALU'], c['SQ_THREAD_CYCLES_VALU']
+        peak_cycles = 256 * 4 * VALU_CLOCK_GHZ * 1e9 * launch_ms / 1e3              # SIMD-cycles available during one launch at the peak clock
+        out = {"bound": "valu", "kernel": kernel, "achieved": round(act * 4.0 / (launch_ms / 1e3) / 1e12, 4), "peak": round(256 * 4 * VALU_CLOCK_GHZ / 1e3, 4), "unit": "T VALU-busy SIMD-cycles/s",
+               "frac": round(act * 4.0 / peak_cycles, 4), "lane_utilisation": round(thr / (64.0 * act), 4),
+               "valu_busy_quad_cycles_per_launch": act, "valu_busy_quad_cycles_per_pixel": round(act / pixels, 2),
+               "counters_launch_ms": c.get('avg_launch_ms'), "launch_ms": round(launch_ms, 3),
+               "note": "frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles the SIMDs spent issuing VALU work, summed over the chip) / (1024 SIMDs x launch time x 2.4 GHz); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); counters from profiles/valu_counters.json (own rocprofv3 --pmc pass), launch time from this run"}
+        if 'SQ_INSTS_VALU' in c:
+            out["valu_wave_instructions_per_pixel"] = round(c['SQ_INSTS_VALU'] / pixels, 2)
+            out["quad_cycles_per_valu_instruction"] = round(act / c['SQ_INSTS_VALU'], 3)
+        if 'SQ_WAIT_ANY' in c and 'SQ_WAVE_CYCLES' in c:
+            out["wave_time_waiting"] = round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)
+        return out
+    except Exception:
+        return None
+
+
 def _synth_cache_dir():
     """Per-user cache of the synthetic inputs, keyed by the generator's source: a changed cavif_rs_amd/synth.py (or somebody else's files
     under a shared /tmp) can never stand in for the images the sha256 manifest was made from."""
@@ -223,6 +253,41 @@ def single_image_line(m, name, w, h, alpha, index, speed, quality, alpha_quality
     return out
 
 
+def threads_line(m, T, imgs, B, w, h, speed, quality, depth, device, steps=3):
+    """The same batch with the tile target bounded by T threads (ravif `with_num_threads(T)` = `cavif -jT`; with T = this box's host cores: what
+    the reference's `threads = None` resolves to through rayon::current_num_threads(), ravif/src/av1encoder.rs:665-668).  One batch slot, `steps` timed steps;
+    the first eight files are checked against the oracle's sha256 in scripts/parity_manifest.json when it holds that T (keys cfg4s/...@jT)."""
+    import hashlib
+    enc = m.Encoder().with_quality(quality).with_speed(speed).with_bit_depth(depth).with_device(device).with_num_threads(T)
+    bt = m.BatchEncoder(enc, B, w, h, channels=3)
+    for i in range(B):
+        bt.pinned_input(i)[...] = imgs[i]
+    bt.upload_async(0, B); bt.encode_async(); bt.wait()           # warm-up
+    t = time.perf_counter()
+    k1 = []
+    for _ in range(steps):
+        bt.encode_async(); bt.wait(); k1.append(bt.stage_ms()['tile_search'])
+    dt = (time.perf_counter() - t) / steps
+    out = {"threads": T, "tiles_per_image": bt.num_tiles() // B, "ms_per_step": round(dt * 1e3, 3), "MPix_per_s": round(B * w * h / 1e6 / dt, 3),
+           "tile_search_ms": round(sum(k1) / len(k1), 3), "slots": 1,
+           "what": "the default batch with with_num_threads(%d) (cavif -j%d): tile target min(T, w*h/min_tile_size^2); one batch slot, so compare with a --pipeline 1 run of the default line" % (T, T)}
+    try:
+        with open(os.path.join(ROOT, 'scripts', 'parity_manifest.json')) as fh:
+            man = json.load(fh)['files']
+        checked = equal = 0
+        for i in range(min(B, 8)):
+            e = man.get('cfg4s/synth_%04d.avif@j%d' % (i, T))
+            if e is None:
+                continue
+            checked += 1
+            equal += hashlib.sha256(bt.get(i).avif_file).hexdigest() == e['sha256']
+        out["output_identity"] = {"checked": checked, "equal": equal, "status": "vs the CPU oracle's sha256 for -j%d (scripts/parity_manifest.json)" % T if checked else "unchecked: no oracle entries for T=%d in scripts/parity_manifest.json" % T}
+    except Exception as e:
+        out["output_identity"] = {"status": "unchecked: %s" % e}
+    bt.close()
+    return out
+
+
 def end_to_end(n_files, w, h, speed, quality, depth):
     """PNG files -> .avif files through the command line (cavif_mi), the clock comparable with `cavif` itself."""
     from scripts.gen_synth_png import write_png
@@ -261,6 +326,8 @@ def main():
     ap.add_argument('--no-pcie-loop', action='store_true', help='skip the second timed loop (H2D inside the region)')
     ap.add_argument('--secondary', action='store_true', help='also time BASELINE configs 2, 3 and 5 (single images; config 5 takes a while)')
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
+    ap.add_argument('--threads', type=int, default=0, help='ravif with_num_threads / cavif -j: T bounds the tile target (av1encoder.rs:665-668); 0 = unspecified (None): uncapped on a GPU')
+    ap.add_argument('--no-threads-line', action='store_true', help='skip the secondary line at T = host cores (what `cavif -j0` would ask for on this box)')
     ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 4 measured best on MI355X: profiles/r04y_slots_probe.txt)')
     args = ap.parse_args()
 
@@ -303,6 +370,8 @@ def main():
         raise SystemExit('bench.py: %d ranks but %d HIP device(s) visible: one rank per GPU' % (world, ndev))
     device = local_rank % ndev
     enc = m.Encoder().with_quality(args.quality).with_speed(args.speed).with_bit_depth(args.depth).with_device(device)
+    if args.threads > 0:
+        enc = enc.with_num_threads(args.threads)
     w, h, B = args.width, args.height, args.batch
     depth_q = max(1, min(args.pipeline, args.steps))         # a slot that no timed step would use is not created (its outputs could not be checked either)
     batches = [m.BatchEncoder(enc, B, w, h, channels=3) for _ in range(depth_q)]
@@ -400,9 +469,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / i32 transform / i64 RD cost", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic %dx%d RGB8 images per GPU, speed=%d quality=%g depth=%d, 4:4:4 BT.601, %d tiles per step per GPU"
-                                   % (B, w, h, args.speed, args.quality, args.depth, batch.num_tiles()),
+                                   % (B, w, h, args.speed, args.quality, args.depth, batch.num_tiles()) + (", T=%d" % args.threads if args.threads > 0 else ", T unspecified"),
                        "images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth,
-                       "tile_target": "T = threads unspecified (ravif None): target w*h/min_tile_size^2 uncapped -> %d tiles per image" % (batch.num_tiles() // B),
+                       "threads": args.threads,
+                       "tile_target": ("T = %d threads (with_num_threads / cavif -j%d): target min(T, w*h/min_tile_size^2) -> %d tiles per image" % (args.threads, args.threads, batch.num_tiles() // B)) if args.threads > 0
+                                      else "T = threads unspecified (ravif None): target w*h/min_tile_size^2 uncapped -> %d tiles per image" % (batch.num_tiles() // B),
                        "tools": "partition 4..16, 13 modes + angle deltas, tx-type + tx-size RDO (TX_MODE_SELECT), CfL, Tune::Psychovisual, deblock level search, CDEF search, sgrproj loop restoration (reduced sets)",
                        "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU, each holding different images, driven in rotation" % (world, depth_q)},
             "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -413,6 +484,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
                          "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
                          "overlapped_launch_ms": round(k1_overlapped, 3)},
+            "roofline_valu": valu_roofline("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed, "quality": args.quality, "bit_depth": args.depth}, isolated_k1_ms, B * w * h),
             "ms_per_step_per_rank": {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3), "ranks": len(per_rank),
                                      "note": "each rank's own clock from the opening barrier to its last wait; ms_per_step is the MAX over ranks around both barriers"},
             "stage_ms_per_step": {k_: round(v_ / args.steps, 3) for k_, v_ in stage_acc.items()},
@@ -428,6 +500,9 @@ def main():
     for bt in batches:
         bt.close()
     if rank == 0:
+        if world == 1 and not args.no_threads_line and B <= MANIFEST_IMAGES:
+            T = max(1, os.cpu_count() or 1)
+            out["threads_host_cores"] = threads_line(m, T, synth_images(w, h, list(range(B))), B, w, h, args.speed, args.quality, args.depth, device)
         if args.secondary:
             aq = min((args.quality + 100.0) / 2.0, args.quality + args.quality / 4.0 + 2.0)
             out["secondary"] = [

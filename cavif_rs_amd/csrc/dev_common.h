@@ -189,17 +189,21 @@ __device__ __forceinline__ int seg_symbol(int seg, int pred, int max) {     // t
 
 // ---- Tune::Psychovisual helpers (oracle/av1o_common.c av1o_psy_boost_q14 / av1o_cell_var; rav1e dist.rs cdef_dist_kernel,
 // activity.rs, recalled): integer, bit-identical to the CPU restatement.
-__device__ __forceinline__ uint32_t psy_isqrt46(unsigned long long n) {       // floor(sqrt(n)), n < 2^46: float guess + exact integer correction
-  uint32_t x = (uint32_t)sqrtf((float)n);
+// Both roots and quotients are float GUESSES made exact by integer correction, so the guesses may be cheap: the operands go to float directly (an fma instead of a 64-bit
+// integer -> float conversion), the square root and the reciprocal are the raw hardware approximations (1 ulp; an IEEE-correct sqrtf / division is a ten-instruction
+// sequence each) -- whatever they return, the while loops leave floor(sqrt(n)) and floor(t / den).
+__device__ __forceinline__ uint32_t psy_isqrt46(unsigned long long n, float nf) {       // floor(sqrt(n)), n < 2^46; nf ~ n
+  uint32_t x = (uint32_t)__builtin_amdgcn_sqrtf(nf);
   while ((unsigned long long)x * x > n) x--;
   while ((unsigned long long)(x + 1) * (x + 1) <= n) x++;
   return x;
 }
 __device__ inline uint32_t psy_boost_q14(uint32_t sv, uint32_t dv) {
   const unsigned long long num = 4033ull * ((unsigned long long)sv + dv + 16384);
-  const uint32_t den = psy_isqrt46(16265089ull + (unsigned long long)sv * dv);
+  const uint32_t den = psy_isqrt46(16265089ull + (unsigned long long)sv * dv, __builtin_fmaf((float)sv, (float)dv, 16265089.0f));
   const unsigned long long t = num + den / 2;
-  uint32_t q = (uint32_t)((float)t / (float)den);              // guess, then exact
+  const float tf = __builtin_fmaf(4033.0f, (float)sv + (float)dv + 16384.0f, (float)(den >> 1));
+  uint32_t q = (uint32_t)(tf * __builtin_amdgcn_rcpf((float)den));                    // guess, then exact
   while ((unsigned long long)q * den > t) q--;
   while ((unsigned long long)(q + 1) * den <= t) q++;
   return q;
@@ -218,6 +222,10 @@ __device__ __forceinline__ int psy_cell_dist(uint32_t sse, uint32_t sd, uint32_t
   return (int)d;
 }
 
+// RD cost terms of a candidate whose distortion fits 32 bits (grouped evaluations: blocks up to 8x8): u32 x 64-bit products (v_mad_u64_u32 + one 32-bit multiply)
+// where `(long long)int * long long` is a full 64 x 64 multiply behind a sign extension.  Same values: both factors are non-negative and the products stay below 2^63.
+template <typename FP> __device__ __forceinline__ long long rd_dist32(FP f, int plane, int sse) { return (long long)(((unsigned long long)(uint32_t)sse * (unsigned long long)f->wq[plane]) >> 5); }
+template <typename FP> __device__ __forceinline__ long long rd_rate32(FP f, uint32_t rate) { return (long long)(((unsigned long long)rate * (unsigned long long)f->rdmult + 256) >> 9); }
 __device__ __forceinline__ int tx_set_of(int txs, int reduced) { return txs >= 3 ? 0 : (reduced ? 2 : (txs == 2 ? 2 : 1)); }
 __device__ __forceinline__ int tx_set_count(int set) { return set == 0 ? 1 : (set == 1 ? 7 : 5); }
 __device__ __forceinline__ int sym_to_txtype(int set, int s) {

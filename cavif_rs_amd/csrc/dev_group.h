@@ -164,9 +164,10 @@ __device__ __forceinline__ void eval_group4_tail(const CoefCost &cc, FP f, LDS G
     }
   }
   bits = row_sum_i32(bits);
-  cul = row_sum_i32(imin_(cul, 1 << 20));
-  dcc = row_max_i32(dcc);
-  res->eob = eob; res->cul = imin_(cul, 63); res->dcc = dcc; res->rate = head + (uint32_t)bits;
+  // the level sum (the context keeps min(sum, 63): clamping each lane's share to 63 first gives the same value) and the dc sign class (set by the one lane that
+  // holds scan position 0) share one row reduction
+  const int cd = row_sum_i32(imin_(cul, 63) | (dcc << 16));
+  res->eob = eob; res->cul = imin_(cd & 0xFFFF, 63); res->dcc = cd >> 16; res->rate = head + (uint32_t)bits;
   // inverse transform + reconstruction (this lane's sample sits at the transposed index, see tx4_tab)
   if (eob > 0) {
     const int cbits = imax_(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));
@@ -323,9 +324,8 @@ __device__ inline void eval_group(const CoefCost &cc, CostPtr cost, const LDS ui
     }
   }
   bits = row_sum_i32(bits);
-  cul = row_sum_i32(imin_(cul, 1 << 20));
-  dcc = row_max_i32(dcc);                        // only the group's lane 0 (scan position 0) sets it
-  res->eob = eob; res->cul = imin_(cul, 63); res->dcc = dcc; res->rate = head + (uint32_t)bits;
+  const int cd = row_sum_i32(imin_(cul, 63) | (dcc << 16));   // one reduction for both (see eval_group4_tail); only the group's lane 0 (scan position 0) sets dcc
+  res->eob = eob; res->cul = imin_(cd & 0xFFFF, 63); res->dcc = cd >> 16; res->rate = head + (uint32_t)bits;
   // ---- inverse 2-D transform + reconstruction (inv_txfm2d_add_dev), only where the candidate has coefficients
   {
     constexpr int ROWSH = N == 4 ? 0 : 1;

@@ -628,7 +628,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
       GroupRes gr;
       eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[0], pcache + ci * NN, 0, txtype, sctx_y, dctx_y, tx_off, tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0,
                             Tools<TS>::tune_psnr(f) ? -1 : psv_a, psv_b, act, &gr);
-      long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
+      long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate) + rd_rate32(f, mode_rate);
       if (!live) j = J_INF;
       bool improved = false;
 #pragma unroll
@@ -752,7 +752,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
           GroupRes gr;
           eval_group<4>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * 16, SH->spred, 0, 0, txtype, ssc, sdc, stx_off, txtype_to_sym(stx_set, txtype),
                         Tools<TS>::tune_psnr(f) ? -1 : SH->psv4[q], SH->pact[0], &gr);
-          long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+          long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
           if (!live) j = J_INF;
 #pragma unroll
           for (int gg = 0; gg < 4; gg++) {
@@ -877,7 +877,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * NN), p, txtype,
                             SH->sctx[p], SH->dctx[p], -1, 0, -1, 0, SH->cact, &gr);
-      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      const long long jp = rd_dist32(f, p, gr.sse) + rd_rate32(f, gr.rate);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }
     WG_SYNC();
@@ -889,7 +889,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
         int jsign = 0;
         const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, false, 0, is_cfl && cfl_ok, alpha_u, alpha_v, &jsign);
         if (!is_cfl || cfl_ok) {
-          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + rd_rate32(f, mode_rate);
           if (j < best_uv) { best_uv = j; bc = cnd; b_sign = jsign; }
         }
       }
@@ -989,7 +989,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       if (dealt) eval_group_wh<WL, HL>(k.cc(), k.cost(), f, &S->grp[g], SH->srcb[p], um == DC_PRED ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + g * NN), p, txtype,
                             SH->sctx[p], SH->dctx[p], -1, 0, -1, 0, SH->cact, &gr);
-      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      const long long jp = rd_dist32(f, p, gr.sse) + rd_rate32(f, gr.rate);
       if (GROUP_LANE == 0 && live) SH->cj[ci][p - 1] = jp;
       WG_SYNC();
       // every wave: the best of the round's candidates, in list order (strictly smaller wins: the oracle's loop)
@@ -999,7 +999,7 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
         if (is_cfl && !cfl_ok) continue;
         int jsign = 0;
         const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um2, false, 0, is_cfl, alpha_u, alpha_v, &jsign);
-        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + rd_rate32(f, mode_rate);
         if (j < r_best) { r_best = j; r_ci = cc; r_sign = jsign; }
       }
       if (r_best < best_uv || (r_best == best_uv && r_ci < b_ci)) { best_uv = r_best; b_ci = r_ci; b_sign = r_sign; b_round = rd; }

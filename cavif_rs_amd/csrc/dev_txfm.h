@@ -34,7 +34,9 @@ __device__ __forceinline__ void tx_kinds(int t, int *col, int *row) {
 __device__ __forceinline__ int32_t rshift_round_(int32_t v, int s) { return s <= 0 ? (int32_t)((uint32_t)v << -s) : (v + (1 << (s - 1))) >> s; }
 
 // tbuf: int32 [N][N+1] holding the residual on entry; coef out: [CS][CS], CS = min(N,32)
-template <int N> __device__ inline void fwd_txfm2d_dev(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) {
+// (the code shape is pinned like the block searches', tile_search.h MI_K1_TRY_ATTR: the 2-D transforms of 16 points and more are functions of their own -- several
+// call sites share them and the instruction cache holds one copy --, the small ones are inlined)
+template <int N> __device__ __forceinline__ void fwd_txfm2d_body(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) {
   constexpr int P = N + 1, CS = N < 32 ? N : 32;
   constexpr int TXS = N == 4 ? 0 : N == 8 ? 1 : N == 16 ? 2 : N == 32 ? 3 : 4;
   const int8_t sh[5][3] = { { 2, 0, 0 }, { 2, -1, 0 }, { 2, -2, 0 }, { 2, -4, 0 }, { 0, -2, -2 } };
@@ -59,8 +61,13 @@ template <int N> __device__ inline void fwd_txfm2d_dev(LDS int32_t *tbuf, LDS in
   WAVE_SYNC();
 }
 
+template <int N> __device__ __attribute__((noinline)) void fwd_txfm2d_big(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) { fwd_txfm2d_body<N>(tbuf, coef, txtype); }
+template <int N> __device__ __forceinline__ void fwd_txfm2d_dev(LDS int32_t *tbuf, LDS int32_t *coef, int txtype) {
+  if constexpr (N >= 16) fwd_txfm2d_big<N>(tbuf, coef, txtype); else fwd_txfm2d_body<N>(tbuf, coef, txtype);
+}
+
 // dq in: [CS][CS] dequantised; adds the residual to rec[N*N] (u16, pitch N) in place.
-template <int N> __device__ inline void inv_txfm2d_add_dev(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) {
+template <int N> __device__ __forceinline__ void inv_txfm2d_add_body(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) {
   constexpr int P = N + 1, CS = N < 32 ? N : 32;
   constexpr int ROWSH = N == 4 ? 0 : N == 8 ? 1 : 2;
   int ck, rk; tx_kinds(txtype, &ck, &rk);
@@ -90,6 +97,11 @@ template <int N> __device__ inline void inv_txfm2d_add_dev(const LDS int32_t *dq
     for (int i = 0; i < N; i++) rec[i * N + j] = (uint16_t)iclamp_((int)rec[i * N + j] + round2_(x[i], 4), 0, mx);
   }
   WAVE_SYNC();
+}
+
+template <int N> __device__ __attribute__((noinline)) void inv_txfm2d_add_big(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) { inv_txfm2d_add_body<N>(dq, tbuf, rec, txtype, bd); }
+template <int N> __device__ __forceinline__ void inv_txfm2d_add_dev(const LDS int32_t *dq, LDS int32_t *tbuf, LDS uint16_t *rec, int txtype, int bd) {
+  if constexpr (N >= 16) inv_txfm2d_add_big<N>(dq, tbuf, rec, txtype, bd); else inv_txfm2d_add_body<N>(dq, tbuf, rec, txtype, bd);
 }
 
 // returns eob (wave-uniform); qc [CS*CS].  All magnitudes fit 32 bits (|coef| < 2^22, q < 2^13).

@@ -60,12 +60,12 @@ __device__ inline void filter_edge_sample_dev(uint16_t *px, int step, int filter
 }
 
 // Edge geometry shared by the level search and the filter: thread id -> (r, c, line i); returns the filter size or 0.
-__device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pass, long long tid, int *r_, int *c_, int *i_) {
-  int r, c, i;
+__device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pass, uint32_t tid, int *r_, int *c_, int *i_) {
+  int r, c, i;                   // (tid < 4 x the frame's 4x4 cells: 32-bit divisions)
   if (pass == 0) {       // consecutive threads walk mi columns of one pixel row
-    const int line = (int)(tid / f->mi_cols); c = (int)(tid % f->mi_cols); r = line >> 2; i = line & 3;
+    const uint32_t mc = (uint32_t)f->mi_cols; const int line = (int)(tid / mc); c = (int)(tid - (uint32_t)line * mc); r = line >> 2; i = line & 3;
   } else {               // consecutive threads walk pixel columns of one mi row
-    const int col_px = (int)(tid % (f->mi_cols * 4)); r = (int)(tid / (f->mi_cols * 4)); c = col_px >> 2; i = col_px & 3;
+    const uint32_t mc4 = (uint32_t)f->mi_cols * 4u; r = (int)(tid / mc4); const int col_px = (int)(tid - (uint32_t)r * mc4); c = col_px >> 2; i = col_px & 3;
   }
   *r_ = r; *c_ = c; *i_ = i;
   if (r >= f->mi_rows || c >= f->mi_cols) return 0;
@@ -89,17 +89,34 @@ __device__ __forceinline__ int deblock_edge(const FrameDev *f, int plane, int pa
 // line is off below the smallest level Lmin that passes the masks and can only change where L >> 4 changes, so a line adds at
 // most two (level range, SSE delta) pairs to the (plane, pass) difference array -- LDS first, then one global atomic per
 // non-zero entry and workgroup.  grid = (line chunks, plane * 2 + pass, frame).
+// Edge lines are sparse among the candidate positions (one 4x4 column in two .. four carries a transform edge: a quarter of the lanes had work, SQ_THREAD_CYCLES_VALU
+// at 23 % in round 4), so a workgroup first walks MI_DBK_CHUNK candidate positions with the cheap geometry test and queues the edge lines it finds in LDS (packed
+// column | line | size), then judges the queued lines with every lane busy.  The tallies are exact 64-bit sums: the order of the lines does not matter.
+#define MI_DBK_CHUNK 2048
+__device__ __forceinline__ int deblock_queue_lines(const FrameDev *f, int plane, int pass, uint32_t base, LDS uint32_t *list, LDS int *cnt) {
+  if (threadIdx.x == 0) *cnt = 0;
+  __syncthreads();
+  for (uint32_t it = 0; it < MI_DBK_CHUNK; it += 256) {
+    int r, c, i;
+    const int fsz = deblock_edge(f, plane, pass, base + it + threadIdx.x, &r, &c, &i);
+    if (fsz) list[__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint32_t)c | ((uint32_t)(r * 4 + i) << 12) | ((uint32_t)(fsz >> 3) << 28);   // fsz 4 / 8 / 16 -> 0 / 1 / 2
+  }
+  __syncthreads();
+  return *cnt;
+}
 __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__restrict__ frames, int nframes) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y >> 1, pass = blockIdx.y & 1;
   if (plane >= f->np || f->fast_deblock || frame_idle(f)) return;
+  if ((uint32_t)blockIdx.x * MI_DBK_CHUNK >= (uint32_t)f->mi_cols * (uint32_t)f->mi_rows * 4u) return;
   __shared__ long long ldiff[65];
+  __shared__ uint32_t list_s[MI_DBK_CHUNK];
+  __shared__ int cnt_s;
   if (threadIdx.x < 65) ldiff[threadIdx.x] = 0;
-  __syncthreads();
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int r, c, i;
-  const int fsz = deblock_edge(f, plane, pass, tid, &r, &c, &i);
-  if (fsz) {
+  const int nlines = deblock_queue_lines(f, plane, pass, (uint32_t)blockIdx.x * MI_DBK_CHUNK, (LDS uint32_t *)list_s, (LDS int *)&cnt_s);
+  for (int j = threadIdx.x; j < nlines; j += 256) {
+    const uint32_t e = list_s[j];
+    const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3, fsz = 4 << (e >> 28);
     const int s8 = f->bd - 8, half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8), one = 1 << s8;
     const int step = pass == 0 ? 1 : f->stride;
     const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
@@ -165,20 +182,25 @@ __global__ void deblock_pick_kernel(FrameDev *frames, int nframes) {
   for (int i = 0; i < 4; i++) f->lf_out[i] = f->lf_level[i];
 }
 
-// pass 0: vertical edges (filter along x), pass 1: horizontal edges.  One thread per (plane, line, mi col).
+// pass 0: vertical edges (filter along x), pass 1: horizontal edges.  A workgroup queues the edge lines among MI_DBK_CHUNK candidate positions (deblock_queue_lines),
+// then filters them one per lane: the lines of a pass are independent (a filter never reaches past half of the smaller adjoining transform).
 __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *__restrict__ frames, int nframes, int pass) {
   const FrameDev *f = frames + blockIdx.z;
   const int plane = blockIdx.y;
   if (plane >= f->np || frame_idle(f)) return;
   const int L = plane == 0 ? f->lf_level[pass] : f->lf_level[plane + 1];
   if (!L) return;
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int r, c, i;
-  const int fsz = deblock_edge(f, plane, pass, tid, &r, &c, &i);
-  if (!fsz) return;
-  const int x = c * 4, y = r * 4;
-  uint16_t *px = pass == 0 ? f->rec[plane] + (size_t)(y + i) * f->stride + x : f->rec[plane] + (size_t)y * f->stride + x + i;
-  filter_edge_sample_dev(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);
+  if ((uint32_t)blockIdx.x * MI_DBK_CHUNK >= (uint32_t)f->mi_cols * (uint32_t)f->mi_rows * 4u) return;
+  __shared__ uint32_t list_s[MI_DBK_CHUNK];
+  __shared__ int cnt_s;
+  const int nlines = deblock_queue_lines(f, plane, pass, (uint32_t)blockIdx.x * MI_DBK_CHUNK, (LDS uint32_t *)list_s, (LDS int *)&cnt_s);
+  for (int j = threadIdx.x; j < nlines; j += 256) {
+    const uint32_t e = list_s[j];
+    const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3, fsz = 4 << (e >> 28);
+    const int x = c * 4, y = r * 4;
+    uint16_t *px = pass == 0 ? f->rec[plane] + (size_t)(y + i) * f->stride + x : f->rec[plane] + (size_t)y * f->stride + x + i;
+    filter_edge_sample_dev(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);
+  }
 }
 
 // ---------------------------------------------------------------- CDEF
@@ -194,10 +216,12 @@ __device__ __forceinline__ int constrain_dev(int diff, int thr, int damping) {
   return diff < 0 ? -v : v;
 }
 // The 12 tap samples of one pixel for direction `dir` (spec 7.15.3 / cdef_get_at): order k=0,1 x sign -,+ x
-// { primary(dir), secondary(dir-2), secondary(dir+2) }.  Samples outside the frame are flagged invalid.
-__device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t *in, int py, int px_, int dir, int *tap, unsigned *valid) {
+// { primary(dir), secondary(dir-2), secondary(dir+2) }.  A sample outside the frame (CdefAvailable = 0) is skipped by the spec; here it takes the centre pixel's
+// value `x`, which is the same thing -- its difference is 0, so constrain() adds nothing, and it cannot move the clamp bounds that start at x -- and spares the
+// filter arithmetic a validity test per tap and use (a quarter of the strength search's instructions in round 4).
+__device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t *in, int py, int px_, int dir, int x, int *tap) {
   const int st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
-  unsigned v = 0; int n = 0;
+  int n = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
 #pragma unroll
@@ -206,49 +230,46 @@ __device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t
       for (int q = 0; q < 3; q++) {
         const int d2 = q == 0 ? dir : ((dir + (q == 1 ? -2 : 2)) & 7);
         const int yy = py + sg * cdef_dir_off(d2, k, 0), xx = px_ + sg * cdef_dir_off(d2, k, 1);
-        int val = 0;
-        if (yy >= 0 && yy < fh && xx >= 0 && xx < fw) { val = in[(size_t)yy * st + xx]; v |= 1u << n; }
-        tap[n++] = val;
+        const bool in_frame = yy >= 0 && yy < fh && xx >= 0 && xx < fw;
+        const int val = in[in_frame ? yy * st + xx : py * st + px_];          // one unconditional load per tap (the centre's address where the tap is outside)
+        tap[n++] = in_frame ? val : x;
       }
     }
   }
-  *valid = v;
 }
 // filter value of one pixel from its preloaded taps
-__device__ __forceinline__ int cdef_apply_taps(int x, const int *tap, unsigned valid, int pri, int sec, int damping, int cs) {
+__device__ __forceinline__ int cdef_apply_taps(int x, const int *tap, int pri, int sec, int damping, int cs) {
   int sum = 0, mx = x, mn = x;
   const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
 #pragma unroll
   for (int n = 0; n < 12; n++) {
-    if (valid & (1u << n)) {
-      const int k = n / 6, q = n % 3, t = tap[n];
-      const int wgt = q == 0 ? (k == 0 ? pt0 : pt1) : (k == 0 ? 2 : 1);
-      sum += wgt * constrain_dev(t - x, q == 0 ? pri : sec, damping);
-      mx = imax_(mx, t); mn = imin_(mn, t);
-    }
+    const int k = n / 6, q = n % 3, t = tap[n];
+    const int wgt = q == 0 ? (k == 0 ? pt0 : pt1) : (k == 0 ? 2 : 1);
+    sum += wgt * constrain_dev(t - x, q == 0 ? pri : sec, damping);
+    mx = imax_(mx, t); mn = imin_(mn, t);
   }
   return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx);
 }
 // The same filter in pieces, for the strength search: the clamp bounds and the secondary taps' sum do not depend on the primary strength, and the
 // fixed strength list repeats its secondary strengths (0, 0, 1, 1, 2, 3, 3, 3), so the search computes bounds once per sample and a secondary sum
 // once per distinct strength.  cdef_apply_taps(x, ...) == cdef_finish(x, cdef_pri_sum(...) + cdef_sec_sum(...), mn, mx).
-__device__ __forceinline__ void cdef_bounds(int x, const int *tap, unsigned valid, int *mn_, int *mx_) {
+__device__ __forceinline__ void cdef_bounds(int x, const int *tap, int *mn_, int *mx_) {
   int mx = x, mn = x;
 #pragma unroll
-  for (int n = 0; n < 12; n++) if (valid & (1u << n)) { mx = imax_(mx, tap[n]); mn = imin_(mn, tap[n]); }
+  for (int n = 0; n < 12; n++) { mx = imax_(mx, tap[n]); mn = imin_(mn, tap[n]); }
   *mn_ = mn; *mx_ = mx;
 }
-__device__ __forceinline__ int cdef_pri_sum(int x, const int *tap, unsigned valid, int pri, int damping, int cs) {
+__device__ __forceinline__ int cdef_pri_sum(int x, const int *tap, int pri, int damping, int cs) {
   const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
   int sum = 0;
 #pragma unroll
-  for (int n = 0; n < 12; n += 3) if (valid & (1u << n)) sum += (n < 6 ? pt0 : pt1) * constrain_dev(tap[n] - x, pri, damping);
+  for (int n = 0; n < 12; n += 3) sum += (n < 6 ? pt0 : pt1) * constrain_dev(tap[n] - x, pri, damping);
   return sum;
 }
-__device__ __forceinline__ int cdef_sec_sum(int x, const int *tap, unsigned valid, int sec, int damping) {
+__device__ __forceinline__ int cdef_sec_sum(int x, const int *tap, int sec, int damping) {
   int sum = 0;
 #pragma unroll
-  for (int n = 0; n < 12; n++) if (n % 3 != 0 && (valid & (1u << n))) sum += (n < 6 ? 2 : 1) * constrain_dev(tap[n] - x, sec, damping);
+  for (int n = 0; n < 12; n++) if (n % 3 != 0) sum += (n < 6 ? 2 : 1) * constrain_dev(tap[n] - x, sec, damping);
   return sum;
 }
 __device__ __forceinline__ int cdef_finish(int x, int sum, int mn, int mx) { return iclamp_(x + ((8 + sum - (sum < 0)) >> 4), mn, mx); }
@@ -332,17 +353,17 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
       for (int p = 0; p < f->np; p++) {
         const int y = r * 4 + py_l, x = c * 4 + px_l;
         const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
-        int tap[12]; unsigned valid;
-        cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid);
+        int tap[12];
+        cdef_load_taps(f, f->rec[p], y, x, ydir, un, tap);
         int mn, mx, ssum = 0, ssec = 0;
-        cdef_bounds(un, tap, valid, &mn, &mx);
+        cdef_bounds(un, tap, &mn, &mx);
         const bool psy = p == 0 && !f->tune_psnr;
         uint32_t my_sse = 0, my_s = 0, my_q = 0;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
           int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
-          if (sec != ssec) { ssec = sec; ssum = cdef_sec_sum(un, tap, valid, sec, damping); }     // wave-uniform: the list repeats its secondary strengths
-          const int v = (pri == 0 && sec == 0) ? un : cdef_finish(un, cdef_pri_sum(un, tap, valid, pri, damping, cs) + ssum, mn, mx);
+          if (sec != ssec) { ssec = sec; ssum = cdef_sec_sum(un, tap, sec, damping); }     // wave-uniform: the list repeats its secondary strengths
+          const int v = (pri == 0 && sec == 0) ? un : cdef_finish(un, cdef_pri_sum(un, tap, pri, damping, cs) + ssum, mn, mx);
           const int d = v - sv;
           const uint32_t sse = (uint32_t)wave_sum_i32(__mul24(d, d));             // 64 samples * 1023^2 < 2^26
           if (lane == idx) my_sse = sse;
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
       int v = f->rec[p][(size_t)y * f->stride + x];
       if (filt) {
         int pri, sec, damping; cdef_strengths(f, p, best, var, &pri, &sec, &damping);
-        if (pri || sec) { int tap[12]; unsigned valid; cdef_load_taps(f, f->rec[p], y, x, ydir, tap, &valid); v = cdef_apply_taps(v, tap, valid, pri, sec, damping, cs); }
+        if (pri || sec) { int tap[12]; cdef_load_taps(f, f->rec[p], y, x, ydir, v, tap); v = cdef_apply_taps(v, tap, pri, sec, damping, cs); }
       }
       f->fin[p][(size_t)y * f->stride + x] = (uint16_t)v;
     }

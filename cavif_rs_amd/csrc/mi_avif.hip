@@ -245,10 +245,14 @@ static size_t k1_snap_bytes(int maxbs) { return MI_K1_POOL_BYTES(maxbs); }
 static hipError_t launch_search(int maxbs, bool bottomup, int tools, const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   if (nitems <= 0) { if (grid_out) *grid_out = 0; return hipSuccess; }
 #define MI_LAUNCH_(MB, BU_, TS_) launch_search_t<MB, 4, BU_, TS_>(d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, grid_out, device, s)
+#ifdef MI_FAST_BUILD                                     // experiment builds only (tools/build_variant.sh): the headline configuration's instantiation and nothing else
+  return MI_LAUNCH_(2, false, 2);
+#else
   const bool full = (tools & 1) != 0;
   if (maxbs <= 2 && !bottomup && tools == 2) return MI_LAUNCH_(2, false, 2);
   if (maxbs <= 2) return bottomup ? (full ? MI_LAUNCH_(2, true, 1) : MI_LAUNCH_(2, true, 0)) : (full ? MI_LAUNCH_(2, false, 1) : MI_LAUNCH_(2, false, 0));
   return bottomup ? (full ? MI_LAUNCH_(4, true, 1) : MI_LAUNCH_(4, true, 0)) : (full ? MI_LAUNCH_(4, false, 1) : MI_LAUNCH_(4, false, 0));
+#endif
 #undef MI_LAUNCH_
 }
 // jobs must all belong to frames of the same block-size class
@@ -257,6 +261,10 @@ static hipError_t launch_entropy(int maxbs, const FrameDev *d_frames, const Tile
   if (njobs <= 0) return hipSuccess;
   // a launch that leaves wave slots free (fewer than 512 tiles: 6 waves each still fit the device in one round) runs four adapter waves per tile
   const bool sparse = njobs < 512;
+#ifdef MI_FAST_BUILD
+  hipLaunchKernelGGL((tile_entropy_kernel<2, MI_K4_ADAPTERS>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS)), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
+  return hipGetLastError();
+#endif
   if (maxbs <= 2) {
     if (sparse) hipLaunchKernelGGL((tile_entropy_kernel<2, MI_K4_ADAPTERS_SPARSE>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS_SPARSE)), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
     else hipLaunchKernelGGL((tile_entropy_kernel<2, MI_K4_ADAPTERS>), dim3(njobs), dim3(MI_K4_THREADS_OF(MI_K4_ADAPTERS)), sizeof(EntropyLds<16>), s, d_frames, d_jobs, njobs, d_precarry, pre_cap, d_recbuf, rec_cap);
@@ -283,10 +291,10 @@ namespace mi {
 // The frame-level stages between the tile search and the entropy coder, shared by the batch and the single-frame entry
 // points: K2a deblock level search -> level pick -> K2 deblock (vertical, horizontal edges) -> K3 CDEF.
 static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_mi_cells, int max_sb, int max_lr_units, int max_lr_sets, hipStream_t s, hipEvent_t ev_cdef) {
-  hipLaunchKernelGGL(deblock_tally_kernel, dim3((max_mi_cells + 255) / 256, 6, nframes), dim3(256), 0, s, d_frames, nframes);
+  hipLaunchKernelGGL(deblock_tally_kernel, dim3((max_mi_cells + MI_DBK_CHUNK - 1) / MI_DBK_CHUNK, 6, nframes), dim3(256), 0, s, d_frames, nframes);
   hipLaunchKernelGGL(deblock_pick_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
   for (int pass = 0; pass < 2; pass++)
-    hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + 255) / 256, 3, nframes), dim3(256), 0, s, d_frames, nframes, pass);
+    hipLaunchKernelGGL(deblock_kernel, dim3((max_mi_cells + MI_DBK_CHUNK - 1) / MI_DBK_CHUNK, 3, nframes), dim3(256), 0, s, d_frames, nframes, pass);
   if (ev_cdef) { hipError_t e = hipEventRecord(ev_cdef, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, d_frames, 1);
   if (max_lr_units > 0) {

@@ -530,7 +530,10 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
       LDS uint16_t *park_rec = (LDS uint16_t *)S->dcp; LDS int32_t *park_qc = (LDS int32_t *)(S->dcp + 64);
       for (int rd = 0; rd < rounds; rd++) {
         int e;
-        if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W : (W < 3 ? W * 5 + 4 : -1);   // a wave's rows 0..2 share the tx type (no divergence in the 1-D networks)
+        // 3 x 5 trials: a wave's rows 0..2 hold one of the four DCT / ADST combinations for the three modes, so each 1-D pass of the wave walks ONE butterfly network;
+        // the three identity trials (a scaling, no network) ride in row 3 of waves 0..2.  (Until round 5 wave 0 held the identity trials and row 3 the fifth combination:
+        // three of the four waves then walked both networks in one of their passes -- 10 + 10 network walks per block instead of 8 + 8.)
+        if (ncand == 3 && ntx == 5) e = g < 3 ? g * 5 + W + 1 : (W < 3 ? W * 5 : -1);
         else e = rd * 16 + W * 4 + g;
         const bool live = e >= 0 && e < total;
         const int ee = live ? e : 0, ci = ee / ntx, ti = ee - ci * ntx, m = SH->order[ci];
@@ -544,7 +547,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         GroupRes gr;
         eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[0], SH->lpred + ci * nn, 0, BS, txtype, sctx_y, dctx_y, tx_off,
                       tx_off >= 0 ? txtype_to_sym(tx_set, txtype) : 0, Tools<TS>::tune_psnr(f) ? -1 : SH->psv[0], SH->pact[0], &gr);
-        long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9) + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate) + rd_rate32(f, mode_rate);
         if (!live) j = J_INF;
         bool improved = false;
 #pragma unroll
@@ -766,7 +769,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
               GroupRes gr;
               eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
                              Tools<TS>::tune_psnr(f) ? -1 : psv_q, pact_q, &gr);
-              long long j = (((long long)gr.sse * f->wq[0]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+              long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
               if (!live) j = J_INF;
 #pragma unroll
               for (int gg = 0; gg < 4; gg++) {
@@ -1015,7 +1018,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
       int txtype = mode_to_txtype(um);
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], cand == 0 ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + cand * nn), p, BS, txtype, SH->sctx[p], SH->dctx[p], -1, 0, -1, SH->cact, &gr);
-      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      const long long jp = rd_dist32(f, p, gr.sse) + rd_rate32(f, gr.rate);
       if (GROUP_LANE == 0 && g < nc) SH->cj[g][p - 1] = jp;
     }
     PH(9);
@@ -1030,7 +1033,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um, !is_cfl && cnd == 1 && um >= V_PRED && um <= D67_PRED && BS >= BS_8, bdelta,
                                                 is_cfl && cfl_ok, alpha_u, alpha_v, &jsign);
         if (!is_cfl || cfl_ok) {
-          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+          const long long j = SH->cj[cnd][0] + SH->cj[cnd][1] + rd_rate32(f, mode_rate);
           if (j < best_uv) { best_uv = j; bc = cnd; b_sign = jsign; }
         }
       }
@@ -1159,7 +1162,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
       if (txtype_to_sym(uvset, txtype) < 0) txtype = DCT_DCT;
       if (dealt) eval_group<n>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->srcb[p], um == DC_PRED ? (const LDS uint16_t *)S->dcp : (const LDS uint16_t *)(S->pred + g * nn), p, BS, txtype,
                     SH->sctx[p], SH->dctx[p], -1, 0, -1, SH->cact, &gr);
-      const long long jp = (((long long)gr.sse * f->wq[p]) >> 5) + (((long long)gr.rate * f->rdmult + 256) >> 9);
+      const long long jp = rd_dist32(f, p, gr.sse) + rd_rate32(f, gr.rate);
       if (GROUP_LANE == 0 && live) SH->cj[ci][p - 1] = jp;
       PH(9);
       WG_SYNC();
@@ -1172,7 +1175,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         int jsign = 0;
         const int d2 = delta_of(um2);
         const uint32_t mode_rate = uv_mode_rate(k.cost(), uvcost, um2, um2 >= V_PRED && um2 <= D67_PRED && BS >= BS_8, d2, is_cfl, alpha_u, alpha_v, &jsign);
-        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        const long long j = SH->cj[cc][0] + SH->cj[cc][1] + rd_rate32(f, mode_rate);
         if (j < r_best) { r_best = j; r_ci = cc; r_sign = jsign; r_delta = d2; }
       }
       if (r_best < best_uv || (r_best == best_uv && r_ci < b_ci)) { best_uv = r_best; b_ci = r_ci; b_sign = r_sign; b_round = rd; b_delta = r_delta; }
@@ -1333,7 +1336,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
       WG_SYNC();                                            // (B) both planes' costs visible
       PH(2);
       if (valid && ok) {
-        const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + (((long long)mode_rate * f->rdmult + 256) >> 9);
+        const long long j = SH->cj[ci2][0] + SH->cj[ci2][1] + rd_rate32(f, mode_rate);
         if (j < pb_j) {
           pb_j = j; pb_c = ci2; pb_delta = delta; pb_sign = jsign; pb_au = alpha_u; pb_av = alpha_v; pb_tr = trp;
           ccur ^= 1;
@@ -1765,9 +1768,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
     if (!fine && (sbc > 0 || sbr > 0)) {
       // Polling with relaxed loads (they bypass the non-coherent cache levels by themselves) and ONE acquire once both conditions hold: an acquire
       // per poll invalidates this XCD's L2 every few hundred cycles for as long as any workgroup waits, under the feet of the ones at work.
+      // Bounded like root_wait (2^25 polls are tens of seconds): a wait that gives up marks the frame through its sticky error word, the entropy stage then fails
+      // every tile of it and the host returns MI_ENCODING_ERROR -- a protocol error or a preempted device must not hang the GPU in the default (coarse) mode either.
       if (threadIdx.x == 0) {
-        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc) __builtin_amdgcn_s_sleep(16);
-        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16); }
+        unsigned spin = 0;
+        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; }
+        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; } }
+        if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(gf), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       WG_SYNC();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

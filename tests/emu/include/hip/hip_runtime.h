@@ -62,6 +62,8 @@ inline void __syncthreads() { emu::wg_barrier(); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline int __clz(unsigned v) { return v == 0 ? 32 : __builtin_clz(v); }
 inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
+inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }             /* dev_common.h: raw v_sqrt_f32 / v_rcp_f32 guesses */
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline unsigned long long clock64() { return emu::ticks(); }
 inline unsigned long long wall_clock64() { return emu::ticks(); }
@@ -82,6 +84,7 @@ inline unsigned long long emu_ballot64(bool p) {
 }
 #define MI_BALLOT64(p) emu_ballot64(p)
 #define MI_SMUL32(r, a, b) ((r) = (a) * (b))
+#define MI_MAD24(r, x, c, acc) ((r) = __mul24((x), (c)) + (acc))     /* txfm_gen.hip.h: v_mad_i32_i24 */
 struct uchar4 { unsigned char x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };

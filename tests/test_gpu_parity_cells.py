@@ -263,3 +263,34 @@ def test_colour_and_alpha_frames_with_different_switches(oracle, q, aq):
     b.encode()
     assert b.get(0).avif_file == ref and b.get(1).avif_file == ref
     b.close()
+
+
+@pytest.mark.parametrize('depth', [10, 8])
+def test_saturated_primaries_through_the_front_end_kernel(oracle, avifdec, depth):
+    """a-4 on the device: ravif's rgb_to_ycbcr rounds half away from zero and saturates only at the integer type (ravif/src/av1encoder.rs:504-523), so pure red
+    gives Cr = 1024 at depth 10 -- one above the sample range -- and Cb / Cr = 255 (saturated) at depth 8.  Flat 64x64 patches of the
+    primaries, white, black, mid grey and (1,2,3) go through mi_ravif_encode_rgb at quality 100 (quantizer 0: the finest steps, so the flat patches survive):
+    bytes == oracle, and dav1d's picture carries the known answers clipped to the sample range in the middle of every patch."""
+    import cavif_rs_amd as m
+    cols = [(255, 255, 255), (0, 0, 0), (255, 0, 0), (0, 255, 0), (0, 0, 255), (128, 128, 128), (1, 2, 3), (255, 255, 0)]
+    want10 = [(1023, 512, 512), (0, 512, 512), (306, 339, 1024), (601, 173, 84), (117, 1023, 429), (514, 512, 512), (7, 515, 510)]
+    want8 = {2: (76, 85, 255), 4: (29, 255, 107)}
+    img = np.zeros((128, 256, 3), np.uint8)
+    for i, c in enumerate(cols):
+        img[(i // 4) * 64:(i // 4) * 64 + 64, (i % 4) * 64:(i % 4) * 64 + 64] = c
+    e = m.Encoder().with_quality(100).with_speed(4).with_bit_depth(depth)
+    got = e.encode_rgb(img)
+    ref, _, _ = oracle.ravif_encode(img, quality=100, speed=4, depth=depth)
+    assert got.avif_file == ref
+    mx = (1 << depth) - 1
+    d = avifdec.decode(got.avif_file)
+    assert d['depth'] == depth
+    for i, c in enumerate(cols):
+        cy, cx = (i // 4) * 64 + 32, (i % 4) * 64 + 32
+        dec = tuple(int(d['planes'][p][cy, cx]) for p in range(3))
+        exp = None
+        if depth == 10 and i < len(want10): exp = want10[i]
+        if depth == 8 and i in want8: exp = want8[i]
+        if exp is not None:
+            # quantizer 0 is not lossless: allow the finest step's rounding around the clipped known answer
+            assert all(abs(a - min(b, mx)) <= 2 for a, b in zip(dec, exp)), (i, dec, exp)

@@ -205,7 +205,15 @@ def emit_fn(name, ops, N, qual):
             L.append('  ' + ' '.join(f'x[{i}] = -x[{i}];' for i in op[1]))
         elif op[0] == 'rot':
             _, p, q, (a, b, c, d) = op
-            L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = TX_R12({M}({a}, t0) + {M}({b}, t1)); x[{q}] = TX_R12({M}({c}, t0) + {M}({d}, t1));')
+            if N <= 16:
+                # one output = R12(a*t0 + b*t1): two chained 24-bit multiply-adds (TX_ROT), or -- equal magnitudes, the 2896 butterflies -- ONE on the sum / difference
+                # (TX_ROT1: a*t0 + b*t1 == a*(t0 +- t1) in wrapping 32-bit arithmetic; |t0 +- t1| < 2^21 here)
+                def one(u, v):
+                    if abs(u) == abs(v): return f'TX_ROT1({u}, t0 {"+" if u == v else "-"} t1)'
+                    return f'TX_ROT({u}, t0, {v}, t1)'
+                L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = {one(a, b)}; x[{q}] = {one(c, d)};')
+            else:
+                L.append(f'  t0 = x[{p}]; t1 = x[{q}]; x[{p}] = TX_R12({M}({a}, t0) + {M}({b}, t1)); x[{q}] = TX_R12({M}({c}, t0) + {M}({d}, t1));')
         elif op[0] == 'had':
             _, p, q, a, b, c, d = op
             def term(s, v): return ('-' if s < 0 else '+') + v
@@ -247,6 +255,14 @@ def emit(path, qual, guard, mul_defs):
 if __name__ == '__main__':
     selfcheck()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    emit(os.path.join(root, 'oracle', 'txfm_gen.h'), 'static inline', 'ORACLE_TXFM_GEN_H', '#define TX_MUL24(a, b) ((a) * (b))\n#define TX_MUL32(a, b) ((a) * (b))')
-    emit(os.path.join(root, 'cavif_rs_amd', 'csrc', 'txfm_gen.hip.h'), 'static __device__ __forceinline__', 'MI_TXFM_GEN_HIP_H', '#define TX_MUL24(a, b) __mul24((a), (b))\n#define TX_MUL32(a, b) ((a) * (b))')
+    rot_c = ('#define TX_ROT(a, p, b, q) TX_R12((a) * (p) + (b) * (q))\n#define TX_ROT1(a, s) TX_R12((a) * (s))')
+    # The device form pins the instruction selection: v_mad_i32_i24 chains with the rounding constant as the first addend.  Left to itself LLVM turns __mul24 into a
+    # plain multiply of sign-extended operands, re-associates the two outputs of a rotation around a shared partial sum and ends with 32-bit multiplies, explicit
+    # v_bfe_i32 sign extensions and three-operand adds: 11 .. 13 issue slots per rotation instead of 7 .. 9 (tools/probe/valu_rates.hip has the per-instruction rates).
+    rot_hip = ('#ifndef MI_MAD24                                     /* (the CPU test harness tests/emu/ predefines it, like MI_SMUL32 in tile_entropy.h) */\n'
+               '#define MI_MAD24(r, x, c, acc) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(acc))\n#endif\n'
+               'static __device__ __forceinline__ int32_t tx_mad24(int32_t x, int32_t c, int32_t acc) { int32_t r; MI_MAD24(r, x, c, acc); return r; }\n'
+               '#define TX_ROT(a, p, b, q) (tx_mad24((q), (b), tx_mad24((p), (a), 2048)) >> 12)\n#define TX_ROT1(a, s) (tx_mad24((s), (a), 2048) >> 12)')
+    emit(os.path.join(root, 'oracle', 'txfm_gen.h'), 'static inline', 'ORACLE_TXFM_GEN_H', '#define TX_MUL24(a, b) ((a) * (b))\n#define TX_MUL32(a, b) ((a) * (b))\n' + rot_c)
+    emit(os.path.join(root, 'cavif_rs_amd', 'csrc', 'txfm_gen.hip.h'), 'static __device__ __forceinline__', 'MI_TXFM_GEN_HIP_H', '#define TX_MUL24(a, b) __mul24((a), (b))\n#define TX_MUL32(a, b) ((a) * (b))\n' + rot_hip)
     print('wrote oracle/txfm_gen.h, cavif_rs_amd/csrc/txfm_gen.hip.h')
