@@ -464,6 +464,46 @@ __device__ inline void predict_dir_group(const LDS FrameDev *f, int x, int y, in
   WAVE_SYNC();
 }
 
+// The five non-directional predictions (DC, PAETH, SMOOTH, SMOOTH_V, SMOOTH_H) of a 4x4 / 8x8 block, one per 16-lane row like the directional ones above: the branches of
+// predict_block() for these modes with the same arithmetic, on the block's raw edges.  `mode` is row-uniform; a row with mode < 0 idles.  The smooth weights
+// (spec Sm_Weights_Tx_4x4 / 8x8) are packed immediates instead of a table in memory.  Until round 5 these five ran one after the other through the generic
+// one-block-per-wave predictor on the two waves that had no directional rows: the longest chain of the SATD stage.
+template <int N>
+__device__ inline void predict_nondir_group(int mode, int have_left, int have_above, int bd, const LDS uint16_t *ra, const LDS uint16_t *rl, LDS uint16_t *pred) {
+  constexpr int log2w = N == 4 ? 2 : 3, IT = N * N / 16;
+  constexpr unsigned long long wt = N == 4 ? 0x405595FFULL : 0x202532496992C5FFULL;     // { 255, 149, 85, 64 } / { 255, 197, 146, 105, 73, 50, 37, 32 }
+  const int gl = GROUP_LANE;
+  if (mode == DC_PRED) {
+    int v = 1 << (bd - 1);
+    if (have_left || have_above) {
+      int s = gl < N ? (have_above ? (int)ra[gl] : 0) + (have_left ? (int)rl[gl] : 0) : 0;
+      s = row_sum_i32(s);
+      v = (have_left && have_above) ? (s + N) >> (log2w + 1) : (s + (N >> 1)) >> log2w;
+    }
+#pragma unroll
+    for (int k = 0; k < IT; k++) pred[gl + 16 * k] = (uint16_t)v;
+  } else if (mode == PAETH_PRED) {
+    const int tl = ra[-1];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+      const int idx = gl + 16 * k, i = idx >> log2w, j = idx & (N - 1);
+      const int a = ra[j], l = rl[i], base = a + l - tl;
+      const int pl = iabs_(base - l), pt = iabs_(base - a), ptl = iabs_(base - tl);
+      pred[idx] = (uint16_t)((pl <= pt && pl <= ptl) ? l : (pt <= ptl ? a : tl));
+    }
+  } else if (mode >= 0) {
+    const int bl = rl[N - 1], tr = ra[N - 1];
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+      const int idx = gl + 16 * k, i = idx >> log2w, j = idx & (N - 1);
+      const int wi = lut8(wt, i), wj = lut8(wt, j);
+      const int vt = wi * (int)ra[j] + (256 - wi) * bl, ht = wj * (int)rl[i] + (256 - wj) * tr;
+      pred[idx] = (uint16_t)(mode == SMOOTH_PRED ? round2_(vt + ht, 9) : round2_(mode == SMOOTH_V_PRED ? vt : ht, 8));
+    }
+  }
+  WAVE_SYNC();
+}
+
 // 4x4-Hadamard SATD of one row's prediction (satd_dev with 16 lanes: one lane per column x group of four rows)
 template <int N> __device__ inline int satd_group(const LDS uint16_t *src, const LDS uint16_t *pred) {
   constexpr int units = N * (N / 4);              // 16 for 8x8, 4 for 4x4: whole quads

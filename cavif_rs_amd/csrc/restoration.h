@@ -236,14 +236,17 @@ __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__res
   const int ur = ui / ucols, uc = ui - ur * ucols;
   __shared__ LrLds L;
   L.a2tab[threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? 1 : ((threadIdx.x << 8) + threadIdx.x / 2) / (threadIdx.x + 1));
-  LrChunk ch[4];
-  const int nch = lr_chunks(f, ur, uc, ucols, urows, ch);
+  // the unit's chunks live in LDS: a per-thread array indexed at run time is a scratch (HBM-backed) array -- every lane wrote and re-read its own copy of these
+  // wave-uniform 96 bytes, which was most of the kernel's memory traffic in round 4 (13.9 GB per launch for 0.4 GB of planes)
+  __shared__ LrChunk ch[4]; __shared__ int nch_s;
+  if (threadIdx.x == 0) nch_s = lr_chunks(f, ur, uc, ucols, urows, ch);
   const int st = f->stride, bd = f->bd, mx = (1 << bd) - 1;
   const uint16_t *src = f->src[plane];
   const int reduced[4] = { 1, 3, 6, 11 };
   const int set = f->sgr_full ? si : reduced[si & 3];
   int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
   __syncthreads();
+  const int nch = nch_s;
   int flt[16];
   for (int k = 0; k < 16; k++) flt[k] = 0;
   long long acc[6];
@@ -316,12 +319,13 @@ __global__ __launch_bounds__(256) void lr_kernel(const FrameDev *__restrict__ fr
   const int ur = ui / ucols, uc = ui - ur * ucols;
   __shared__ LrLds L;
   L.a2tab[threadIdx.x] = (uint16_t)(threadIdx.x == 0 ? 1 : ((threadIdx.x << 8) + threadIdx.x / 2) / (threadIdx.x + 1));
-  LrChunk ch[4];
-  const int nch = lr_chunks(f, ur, uc, ucols, urows, ch);
+  __shared__ LrChunk ch[4]; __shared__ int nch_s;                    // (LDS, not a per-thread array: see lr_search_kernel)
+  if (threadIdx.x == 0) nch_s = lr_chunks(f, ur, uc, ucols, urows, ch);
   const int st = f->stride, bd = f->bd, mx = (1 << bd) - 1;
   const uint16_t *cdef = f->fin[plane], *src = f->src[plane];
   uint16_t *out = f->lrp[plane];
   __syncthreads();
+  const int nch = nch_s;
   // RESTORE_NONE
   long long acc[2];
   {

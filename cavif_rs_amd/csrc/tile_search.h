@@ -399,7 +399,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
   if constexpr (SMALL_GROUPED) {
     // 4x4 / 8x8: the eight directional modes run four per wave (one prediction angle per 16-lane row, dev_group.h) on
     // waves 0 and 1 -- rows sorted so that a wave's rows mostly share the interpolation branch --, the five others
-    // wave-wide on waves 2 and 3
+    // on rows of waves 2 and 3 (predict_nondir_group)
     if (W < 2) {
       const int g = GROUP_ID;
       const int m = W == 0 ? (g == 0 ? V_PRED : g == 1 ? H_PRED : g == 2 ? D45_PRED : D67_PRED) : D135_PRED + g;
@@ -408,16 +408,13 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
       const int sd = satd_group<n>(SH->srcb[0], gp->pred);
       if (GROUP_LANE == 0) SH->satd[m] = (long long)sd;
     } else {
-      const int deal = W == 2 ? 0xFC90 : 0xFFBA;          // DC, SMOOTH, PAETH | SMOOTH_V, SMOOTH_H
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int m = (deal >> (4 * i)) & 15;
-        if (m < 13) {
-          predict_block(f, x, y, log2w, availL, availU, m, 0, ftype_y, ra, rl, wa, wl, S->etmp, S->pred);
-          const long long sd = satd_dev(SH->srcb[0], S->pred, n);
-          if (LANE == 0) SH->satd[m] = sd;
-        }
-      }
+      // the five others the same way, one per row: DC, PAETH, SMOOTH on wave 2, SMOOTH_V, SMOOTH_H on wave 3
+      const int g = GROUP_ID;
+      const int m = W == 2 ? (g == 0 ? DC_PRED : g == 1 ? PAETH_PRED : g == 2 ? SMOOTH_PRED : -1) : (g == 0 ? SMOOTH_V_PRED : g == 1 ? SMOOTH_H_PRED : -1);
+      LDS GroupPredBuf *gp = &S->gpred[g];
+      predict_nondir_group<n>(m, availL, availU, f->bd, ra, rl, gp->pred);
+      const int sd = satd_group<n>(SH->srcb[0], gp->pred);
+      if (m >= 0 && GROUP_LANE == 0) SH->satd[m] = (long long)sd;
     }
   } else if constexpr (NW == 4) {
   // dealt by cost rather than round-robin: the six diagonal modes (edge filter + interpolation) weigh about three

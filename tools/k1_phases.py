@@ -28,7 +28,7 @@ tot = p.sum(axis=2)                                 # per tile per wave
 print('stage_ms', b.stage_ms())
 print('mean cycles per wave per tile: %.3g' % tot.mean())
 for i, n in enumerate(names):
-    print('%-18s %6.2f%%   (wave0 %.2f%%, wave3 %.2f%%)' % (n, 100 * p[:, :, i].sum() / tot.sum(), 100 * p[:, 0, i].sum() / tot[:, 0].sum(), 100 * p[:, 3, i].sum() / tot[:, 3].sum()))
+    print('%-18s %6.2f%%   (waves ' % (n, 100 * p[:, :, i].sum() / tot.sum()) + ' '.join('%.2f%%' % (100 * p[:, w_, i].sum() / tot[:, w_].sum()) for w_ in range(4)) + ')')
 if len(sys.argv) > 2 and sys.argv[2] == 'sizes':      # a -DMI_PROFILE=3 library: slots 16..21 = time per block size
     print('by block size, share of the kernel: ' + '  '.join('%s %.2f%%' % (n, 100 * sub[:, :, i].sum() / tot.sum()) for i, n in enumerate(['4x4', '8x8', '16x16', '32x32+', '8x4', '4x8'])))
     sys.exit(0)
