@@ -6,6 +6,7 @@
 // rav1e equivalents (absent): src/deblock.rs, src/cdef.rs, rdo.rs::rdo_loop_decision.
 #pragma once
 #include "dev_common.h"
+#include "dev_pk16.h"
 
 __device__ inline void filter_edge_sample_dev(uint16_t *px, int step, int filter_size, int plane, int lvl, int sharp, int bd) {
   const int sh = sharp > 4 ? 2 : (sharp > 0 ? 1 : 0);
@@ -204,6 +205,12 @@ __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *__restrict
 }
 
 // ---------------------------------------------------------------- CDEF
+// sums over lanes 0..31 and over lanes 32..63 on the DPP network: afterwards lanes 16..31 hold the first half's total, lanes 48..63 the second half's
+__device__ __forceinline__ int half_sum_i32(int v) {
+  v += DPP_(0, v, 0xB1, 0xF); v += DPP_(0, v, 0x4E, 0xF); v += DPP_(0, v, 0x141, 0xF); v += DPP_(0, v, 0x140, 0xF);
+  v += DPP_(0, v, 0x142, 0xA);
+  return v;
+}
 __device__ __forceinline__ int cdef_dir_off(int dir, int k, int comp) {
   const int8_t d[8][2][2] = { { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } }, { { 0, 1 }, { 1, 2 } },
                               { { 1, 1 }, { 2, 2 } }, { { 1, 0 }, { 2, 1 } }, { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
@@ -219,9 +226,25 @@ __device__ __forceinline__ int constrain_dev(int diff, int thr, int damping) {
 // { primary(dir), secondary(dir-2), secondary(dir+2) }.  A sample outside the frame (CdefAvailable = 0) is skipped by the spec; here it takes the centre pixel's
 // value `x`, which is the same thing -- its difference is 0, so constrain() adds nothing, and it cannot move the clamp bounds that start at x -- and spares the
 // filter arithmetic a validity test per tap and use (a quarter of the strength search's instructions in round 4).
-__device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t *in, int py, int px_, int dir, int x, int *tap) {
+// `interior` (wave-uniform): the whole 8x8 block lies at least two samples inside the frame on every side, so no tap needs a test -- all but the frame's border blocks.
+__device__ __forceinline__ void cdef_load_taps(const FrameDev *f, const uint16_t *in, int py, int px_, int dir, int x, int *tap, bool interior) {
   const int st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
   int n = 0;
+  if (interior) {
+    const uint16_t *c = in + py * st + px_;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int sg = -1; sg <= 1; sg += 2) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int d2 = q == 0 ? dir : ((dir + (q == 1 ? -2 : 2)) & 7);
+          tap[n++] = c[sg * (cdef_dir_off(d2, k, 0) * st + cdef_dir_off(d2, k, 1))];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 2; k++) {
 #pragma unroll
@@ -338,36 +361,106 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
   __syncthreads();
   const int py_l = lane >> 3, px_l = lane & 7;
   if (f->enable_cdef) {
-    for (int b = wave; b < 64; b += 4) {
-      const int r = sr * 16 + (b >> 3) * 2, c = sc * 16 + (b & 7) * 2;
-      if (r >= f->mi_rows || c >= f->mi_cols) continue;
-      const int sk = f->m_skip[r * ms + c] & f->m_skip[(r + 1) * ms + c] & f->m_skip[r * ms + c + 1] & f->m_skip[(r + 1) * ms + c + 1] & 1;      // bit 0 of the map (the rest is the segment id)
-      if (sk) continue;
-      int var; const int ydir = cdef_direction_dev(f->rec[0] + (size_t)(r * 4) * f->stride + c * 4, f->stride, f->bd, part, &var);
-      if (lane == 0) { dirvar[b][0] = ydir; dirvar[b][1] = var; }
-      // candidate idx's cost lives on lane idx: the wave sums of a candidate are wave-uniform, lane idx keeps them, and the psychovisual pricing
-      // (integer square root and quotient, dev_common.h) runs once for the eight candidates side by side instead of eight times on every lane
-      long long cst = 0;
+    // Strength search, two 8x8 blocks per wavefront pass: lanes 0..31 take block bA, lanes 32..63 block bB = bA + 4, every lane two horizontally adjacent samples
+    // in packed 16-bit arithmetic (dev_pk16.h) -- 10-bit samples, their differences, the constrained differences (|.| <= strength) and a pixel's weighted tap sums
+    // (< 1024 + 256) all fit 16 bits.  Same filter as cdef_apply_taps / cdef_pri_sum / cdef_sec_sum, sample for sample; a block's sums land on its own half's lanes.
+    const int hs = lane >> 5, l32 = lane & 31, py2 = l32 >> 2, px2 = (l32 & 3) * 2;
+    const int st = f->stride, fw = f->mi_cols * 4, fh = f->mi_rows * 4;
+    for (int it = 0; it < 8; it++) {
+      const int bA = wave + 8 * it, bB = bA + 4;
+      const int rA = sr * 16 + (bA >> 3) * 2, cA = sc * 16 + (bA & 7) * 2, rB = sr * 16 + (bB >> 3) * 2, cB = sc * 16 + (bB & 7) * 2;
+      bool actA = rA < f->mi_rows && cA < f->mi_cols, actB = rB < f->mi_rows && cB < f->mi_cols;
+      if (actA) actA = !(f->m_skip[rA * ms + cA] & f->m_skip[(rA + 1) * ms + cA] & f->m_skip[rA * ms + cA + 1] & f->m_skip[(rA + 1) * ms + cA + 1] & 1);   // bit 0 of the map (the rest is the segment id)
+      if (actB) actB = !(f->m_skip[rB * ms + cB] & f->m_skip[(rB + 1) * ms + cB] & f->m_skip[rB * ms + cB + 1] & f->m_skip[(rB + 1) * ms + cB + 1] & 1);
+      actA = uni32(actA) != 0; actB = uni32(actB) != 0;
+      if (!actA && !actB) continue;
+      int dirA = 0, varA = 0, dirB = 0, varB = 0;
+      if (actA) { dirA = cdef_direction_dev(f->rec[0] + (size_t)(rA * 4) * st + cA * 4, st, f->bd, part, &varA); if (lane == 0) { dirvar[bA][0] = dirA; dirvar[bA][1] = varA; } }
+      if (actB) { dirB = cdef_direction_dev(f->rec[0] + (size_t)(rB * 4) * st + cB * 4, st, f->bd, part, &varB); if (lane == 0) { dirvar[bB][0] = dirB; dirvar[bB][1] = varB; } }
+      // an idle half walks the other half's block (valid addresses, results unused)
+      const bool useB = actB && (hs || !actA);
+      const bool act = hs ? actB : actA;
+      const int r = useB ? rB : rA, c = useB ? cB : cA;
+      const int y = r * 4 + py2, x = c * 4 + px2;
+      const bool intA = rA * 4 >= 2 && cA * 4 >= 2 && rA * 4 + 10 <= fh && cA * 4 + 10 <= fw, intB = rB * 4 >= 2 && cB * 4 >= 2 && rB * 4 + 10 <= fh && cB * 4 + 10 <= fw;
+      const bool interior = (!actA || intA) && (!actB || intB);                       // wave-uniform: no tap of either block needs a frame test
       const int cell = (r >> 1) * (f->pw >> 3) + (c >> 1);
       const uint32_t cell_sv = f->svar8[cell], cell_act = f->act[cell];
+      long long cst = 0;                                                              // candidate idx of block A on lane idx, of block B on lane 32 + idx
       for (int p = 0; p < f->np; p++) {
-        const int y = r * 4 + py_l, x = c * 4 + px_l;
-        const int sv = f->src[p][(size_t)y * f->stride + x], un = f->rec[p][(size_t)y * f->stride + x];
-        int tap[12];
-        cdef_load_taps(f, f->rec[p], y, x, ydir, un, tap);
-        int mn, mx, ssum = 0, ssec = 0;
-        cdef_bounds(un, tap, &mn, &mx);
+        const uint16_t *in = f->rec[p];
+        const pk16 un = pk_load2(in + y * st + x), sv = pk_load2(f->src[p] + y * st + x);
+        pk16 tap[12]; int n = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+          for (int sg = -1; sg <= 1; sg += 2) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+              const int dA = q == 0 ? dirA : ((dirA + (q == 1 ? -2 : 2)) & 7), dB = q == 0 ? dirB : ((dirB + (q == 1 ? -2 : 2)) & 7);
+              const int dyA = sg * cdef_dir_off(dA, k, 0), dxA = sg * cdef_dir_off(dA, k, 1), dyB = sg * cdef_dir_off(dB, k, 0), dxB = sg * cdef_dir_off(dB, k, 1);
+              const int dy = useB ? dyB : dyA, dx = useB ? dxB : dxA;
+              if (interior) tap[n] = pk_load2(in + (y + dy) * st + x + dx);
+              else {
+                // a sample outside the frame takes its centre sample's value (cdef_load_taps); the pair is fetched where its row exists
+                const int yy = y + dy, xx = x + dx;
+                const bool rowok = yy >= 0 && yy < fh;
+                const pk16 t = pk_load2(in + (rowok ? yy : y) * st + (rowok ? xx : x));
+                const uint32_t tv = pk_to_u32(t), cv = pk_to_u32(un);
+                const bool ok0 = rowok && xx >= 0 && xx < fw, ok1 = rowok && xx + 1 >= 0 && xx + 1 < fw;
+                tap[n] = pk_from_u32(((ok0 ? tv : cv) & 0xFFFFu) | ((ok1 ? tv : cv) & 0xFFFF0000u));
+              }
+              n++;
+            }
+          }
+        }
+        pk16 mn = un, mx = un;
+#pragma unroll
+        for (int q = 0; q < 12; q++) { mx = pk_max(mx, tap[q]); mn = pk_min(mn, tap[q]); }
         const bool psy = p == 0 && !f->tune_psnr;
         uint32_t my_sse = 0, my_s = 0, my_q = 0;
+        int ssec = -1; pk16 ssum = pk_splat(0);
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
-          int pri, sec, damping; cdef_strengths(f, p, idx, var, &pri, &sec, &damping);
-          if (sec != ssec) { ssec = sec; ssum = cdef_sec_sum(un, tap, sec, damping); }     // wave-uniform: the list repeats its secondary strengths
-          const int v = (pri == 0 && sec == 0) ? un : cdef_finish(un, cdef_pri_sum(un, tap, pri, damping, cs) + ssum, mn, mx);
-          const int d = v - sv;
-          const uint32_t sse = (uint32_t)wave_sum_i32(__mul24(d, d));             // 64 samples * 1023^2 < 2^26
-          if (lane == idx) my_sse = sse;
-          if (psy) { const uint32_t s1 = (uint32_t)wave_sum_i32(v), s2 = (uint32_t)wave_sum_i32(__mul24(v, v)); if (lane == idx) { my_s = s1; my_q = s2; } }
+          int priA, priB, sec, damping, sec2, damping2;
+          cdef_strengths(f, p, idx, varA, &priA, &sec, &damping); cdef_strengths(f, p, idx, varB, &priB, &sec2, &damping2);     // the variance only moves the luma primary strength
+          const int pri = useB ? priB : priA;
+          if (sec != ssec) {                                                          // wave-uniform: the list repeats its secondary strengths
+            ssec = sec; ssum = pk_splat(0);
+            if (sec) {
+              const pk16 thr = pk_splat(sec), adj = pk_splat(imax_(0, damping - (31 - __clz(sec))));
+#pragma unroll
+              for (int q = 0; q < 12; q++) if (q % 3 != 0) {
+                const pk16 diff = tap[q] - un, mag = pk_abs(diff), sgn = diff >> pk_splat(15);
+                const pk16 v = pk_min(pk_max(thr - (mag >> adj), pk_splat(0)), mag);
+                ssum += ((v ^ sgn) - sgn) * pk_splat(q < 6 ? 2 : 1);
+              }
+            }
+          }
+          pk16 sum = ssum;
+          {
+            const int odd = (pri >> cs) & 1;
+            const pk16 thr = pk_splat(pri), adj = pk_splat(pri ? imax_(0, damping - (31 - __clz(pri))) : 0), w0 = pk_splat(odd ? 3 : 4), w1 = pk_splat(odd ? 3 : 2);
+#pragma unroll
+            for (int q = 0; q < 12; q += 3) {
+              const pk16 diff = tap[q] - un, mag = pk_abs(diff), sgn = diff >> pk_splat(15);
+              const pk16 v = pk_min(pk_max(thr - (mag >> adj), pk_splat(0)), mag);       // 0 when the strength is 0
+              sum += ((v ^ sgn) - sgn) * (q < 6 ? w0 : w1);
+            }
+          }
+          // cdef_finish: x + ((8 + sum - (sum < 0)) >> 4), clamped to the taps' range (no strength at all leaves x: sum = 0, mn <= x <= mx)
+          const pk16 v = pk_min(pk_max(un + ((pk_splat(8) + sum + (sum >> pk_splat(15))) >> pk_splat(4)), mn), mx);
+          const pk16 d = v - sv;
+          int e = pk_dot2(d, d, 0);                                                     // 32 lanes x 2 samples x 1023^2 < 2^26 per block
+          e = half_sum_i32(e);
+          const uint32_t eA = (uint32_t)__builtin_amdgcn_readlane(e, 31), eB = (uint32_t)__builtin_amdgcn_readlane(e, 63);
+          if (l32 == idx) my_sse = hs ? eB : eA;
+          if (psy) {
+            int s1 = half_sum_i32(pk_dot2(v, pk_splat(1), 0)), s2 = half_sum_i32(pk_dot2(v, v, 0));
+            const uint32_t s1A = (uint32_t)__builtin_amdgcn_readlane(s1, 31), s1B = (uint32_t)__builtin_amdgcn_readlane(s1, 63);
+            const uint32_t s2A = (uint32_t)__builtin_amdgcn_readlane(s2, 31), s2B = (uint32_t)__builtin_amdgcn_readlane(s2, 63);
+            if (l32 == idx) { my_s = hs ? s1B : s1A; my_q = hs ? s2B : s2A; }
+          }
         }
         // Tune::Psychovisual (rav1e rdo_loop_plane_error): luma through the cdef-dist kernel of the 8x8 block, chroma SSE x activity
         long long e;
@@ -375,7 +468,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
         else e = (long long)(((unsigned long long)my_sse * cell_act + 8192) >> 14);
         cst += (e * f->wq[p]) >> 5;
       }
-      if (lane < 8) atomicAdd(&costs[lane], (unsigned long long)cst);
+      if (act && l32 < 8) atomicAdd(&costs[l32], (unsigned long long)cst);
       if (lane == 0) any_blocks = 1;
     }
   }
@@ -400,7 +493,7 @@ __global__ __launch_bounds__(256, 4) void cdef_kernel(const FrameDev *__restrict
       int v = f->rec[p][(size_t)y * f->stride + x];
       if (filt) {
         int pri, sec, damping; cdef_strengths(f, p, best, var, &pri, &sec, &damping);
-        if (pri || sec) { int tap[12]; cdef_load_taps(f, f->rec[p], y, x, ydir, v, tap); v = cdef_apply_taps(v, tap, pri, sec, damping, cs); }
+        if (pri || sec) { int tap[12]; cdef_load_taps(f, f->rec[p], y, x, ydir, v, tap, r * 4 >= 2 && c * 4 >= 2 && r * 4 + 10 <= f->mi_rows * 4 && c * 4 + 10 <= f->mi_cols * 4); v = cdef_apply_taps(v, tap, pri, sec, damping, cs); }
       }
       f->fin[p][(size_t)y * f->stride + x] = (uint16_t)v;
     }

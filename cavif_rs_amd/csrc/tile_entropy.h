@@ -69,7 +69,12 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 #define K4_BIT(b) ((b) ? K4_BOUNDS(256u, 0u, 0u) : K4_BOUNDS(512u, 256u, 1u))
 // adapter waves per tile: two when the launch fills the device (1024 tiles x 4 waves = every SIMD's four wave slots at K4's register count; four
 // adapters were measured slower there: a second round of workgroups), four when it does not (single images: the adapters are the busiest stage)
+#ifndef MI_K4_ADAPTERS
 #define MI_K4_ADAPTERS 2
+#endif
+#ifndef MI_K4_LB_EXTRA
+#define MI_K4_LB_EXTRA                             /* probe builds: a second __launch_bounds__ argument (workgroups per CU) */
+#endif
 #define MI_K4_ADAPTERS_SPARSE 4
 #define MI_K4_THREADS_OF(NA) (64 * (2 + (NA)))
 // records of a typical worst superblock: per coefficient the base level, four base-range symbols, the sign and two more; per transform
@@ -611,7 +616,7 @@ template <int CS> struct EntropyLds {
 
 // recbuf: per tile job three record buffers of rec_cap entries (producer -> adapters -> coder, rotating per superblock)
 template <int MAXBS, int NA>
-__global__ __launch_bounds__(MI_K4_THREADS_OF(NA)) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap,
+__global__ __launch_bounds__(MI_K4_THREADS_OF(NA) MI_K4_LB_EXTRA) void tile_entropy_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs, int njobs, uint16_t *precarry, uint32_t pre_cap,
                                                                    uint32_t *recbuf, uint32_t rec_cap) {
   constexpr int CS = MAXBS <= 2 ? 16 : 32, MI_K4_THREADS = MI_K4_THREADS_OF(NA);
   extern __shared__ __align__(16) uint8_t k4_smem[];            // sizeof(EntropyLds<CS>), passed at launch

@@ -85,6 +85,22 @@ inline unsigned long long emu_ballot64(bool p) {
 #define MI_BALLOT64(p) emu_ballot64(p)
 #define MI_SMUL32(r, a, b) ((r) = (a) * (b))
 #define MI_MAD24(r, x, c, acc) ((r) = __mul24((x), (c)) + (acc))     /* txfm_gen.hip.h: v_mad_i32_i24 */
+// dev_pk16.h: two 16-bit lanes in a struct with the operators the device code uses on its clang vector type
+#define MI_PK16_DEFINED
+struct pk16 { short x, y; };
+inline pk16 operator-(pk16 a) { return pk16{ (short)-a.x, (short)-a.y }; }
+inline pk16 operator-(pk16 a, pk16 b) { return pk16{ (short)(a.x - b.x), (short)(a.y - b.y) }; }
+inline pk16 operator+(pk16 a, pk16 b) { return pk16{ (short)(a.x + b.x), (short)(a.y + b.y) }; }
+inline pk16 operator*(pk16 a, pk16 b) { return pk16{ (short)(a.x * b.x), (short)(a.y * b.y) }; }
+inline pk16 operator^(pk16 a, pk16 b) { return pk16{ (short)(a.x ^ b.x), (short)(a.y ^ b.y) }; }
+inline pk16 operator>>(pk16 a, pk16 b) { return pk16{ (short)(a.x >> b.x), (short)(a.y >> b.y) }; }
+inline pk16 &operator+=(pk16 &a, pk16 b) { a = a + b; return a; }
+inline pk16 pk_splat(int v) { return pk16{ (short)v, (short)v }; }
+inline pk16 pk_max(pk16 a, pk16 b) { return pk16{ a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y }; }
+inline pk16 pk_min(pk16 a, pk16 b) { return pk16{ a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y }; }
+inline pk16 pk_from_u32(uint32_t v) { return pk16{ (short)(v & 0xFFFF), (short)(v >> 16) }; }
+inline uint32_t pk_to_u32(pk16 v) { return (uint32_t)(uint16_t)v.x | ((uint32_t)(uint16_t)v.y << 16); }
+inline int pk_dot2(pk16 a, pk16 b, int acc) { return acc + a.x * b.x + a.y * b.y; }
 struct uchar4 { unsigned char x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
