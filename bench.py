@@ -253,7 +253,7 @@ def single_image_line(m, name, w, h, alpha, index, speed, quality, alpha_quality
     return out
 
 
-def threads_line(m, T, imgs, B, w, h, speed, quality, depth, device, steps=3):
+def threads_line(m, T, imgs, B, w, h, speed, quality, depth, device, default_tiles=0, steps=3):
     """The same batch with the tile target bounded by T threads (ravif `with_num_threads(T)` = `cavif -jT`; with T = this box's host cores: what
     the reference's `threads = None` resolves to through rayon::current_num_threads(), ravif/src/av1encoder.rs:665-668).  One batch slot, `steps` timed steps;
     the first eight files are checked against the oracle's sha256 in scripts/parity_manifest.json when it holds that T (keys cfg4s/...@jT)."""
@@ -282,6 +282,13 @@ def threads_line(m, T, imgs, B, w, h, speed, quality, depth, device, steps=3):
             checked += 1
             equal += hashlib.sha256(bt.get(i).avif_file).hexdigest() == e['sha256']
         out["output_identity"] = {"checked": checked, "equal": equal, "status": "vs the CPU oracle's sha256 for -j%d (scripts/parity_manifest.json)" % T if checked else "unchecked: no oracle entries for T=%d in scripts/parity_manifest.json" % T}
+        if not checked:
+            # T at or above the uncapped tile target asks for the same tiles as `threads = None`: the default manifest applies (the bytes do not depend on T beyond the tile split)
+            with open(os.path.join(ROOT, 'tests', 'golden', 'bench_manifest.json')) as fh:
+                dm = json.load(fh)
+            if default_tiles and bt.num_tiles() // B == default_tiles and dm['config'] == {"width": w, "height": h, "speed": speed, "quality": quality, "bit_depth": depth}:
+                eq = sum(hashlib.sha256(bt.get(i).avif_file).hexdigest() == dm['sha256'][i] for i in range(min(B, len(dm['sha256']))))
+                out["output_identity"] = {"checked": min(B, len(dm['sha256'])), "equal": int(eq), "status": "T = %d does not bound the tile target here (%d tiles per image, as with threads = None): checked against tests/golden/bench_manifest.json" % (T, default_tiles)}
     except Exception as e:
         out["output_identity"] = {"status": "unchecked: %s" % e}
     bt.close()
@@ -497,12 +504,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, args.speed, args.quality, args.depth)
             out["cpu_baseline_standin"] = cpu_standin(w, h, args.speed, args.quality, args.depth)
+    tiles_per_image = batch.num_tiles() // B
     for bt in batches:
         bt.close()
     if rank == 0:
         if world == 1 and not args.no_threads_line and B <= MANIFEST_IMAGES:
             T = max(1, os.cpu_count() or 1)
-            out["threads_host_cores"] = threads_line(m, T, synth_images(w, h, list(range(B))), B, w, h, args.speed, args.quality, args.depth, device)
+            timgs = synth_images(w, h, list(range(B)))
+            out["threads_host_cores"] = threads_line(m, T, timgs, B, w, h, args.speed, args.quality, args.depth, device, default_tiles=tiles_per_image)
+            if T != 16:       # a host of 16 threads (what round 4's CPU baseline ran on): the regime where T does bound the tile target -- 16 tiles per 1080p image, 512 per launch
+                out["threads_16"] = threads_line(m, 16, timgs, B, w, h, args.speed, args.quality, args.depth, device, default_tiles=tiles_per_image)
+            del timgs
         if args.secondary:
             aq = min((args.quality + 100.0) / 2.0, args.quality + args.quality / 4.0 + 2.0)
             out["secondary"] = [

@@ -537,6 +537,7 @@ template <typename FP, typename TP> __device__ inline void txb_ctx_wh(FP f, TP t
 
 template <int MAXN, int BSR, int NW, int TS>
 __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, int r, int c, long long budget = J_INF) {
+  static_assert(NW == 4 && MAXN <= 32, "the 2:1 block search deals its candidates to four wavefronts (its chroma stages hard-code the wave roles; no one-candidate-per-wave fallback is left)");
   constexpr int WL = BSR == BS_4X8 ? 2 : 3, HL = BSR == BS_4X8 ? 3 : 2, W_ = 1 << WL, H_ = 1 << HL, NN = W_ * H_, w4 = W_ >> 2, h4 = H_ >> 2;
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t(); LDS WaveScratch<MAXN> *S = k.s(); LDS SharedScratch<MAXN> *SH = k.sh();
   const int W = NW > 1 ? WAVE_ID : 0;

@@ -216,6 +216,9 @@ static void fill_dev(FramePlan &p, const DeviceTables &tab) {
 
 // ---- K1 launch: the tile search as a work queue of superblocks (tile_search.h) ----
 // Persistent workgroups: as many as the device holds at once for this instantiation (asked from the runtime, not assumed), capped by the number of items.
+#ifndef MI_K1_ITEMS_PER_WG_DEFAULT
+#define MI_K1_ITEMS_PER_WG_DEFAULT 0
+#endif
 template <int MAXBS, int NW, bool BU, int TS> static hipError_t launch_search_t(const FrameDev *d_frames, const TileJob *d_jobs, const SbItem *d_items, int nitems, int *d_next, uint8_t *d_snap_pool, int *grid_out, int device, hipStream_t s) {
   const size_t lds = k1_lds_bytes<MAXBS, NW>();
   static int resident[MI_MAX_DEVICES];                    // per instantiation and device; 0 = not asked yet
@@ -232,9 +235,12 @@ template <int MAXBS, int NW, bool BU, int TS> static hipError_t launch_search_t(
     if (const char *v = getenv("MI_K1_GRID_PER_CU")) { const int n = atoi(v); if (n > 0 && n < per_cu) resident[device] = n * std::max(1, cus); }
 #endif
   }
-  const int grid = std::min(nitems, resident[device]);
+  // MI_K1_ITEMS_PER_WG=n (n > 0): workgroups that leave after n items instead of persistent ones (tile_search.h); only when the list is longer than the device holds
+  static const int ipw_env = getenv("MI_K1_ITEMS_PER_WG") ? atoi(getenv("MI_K1_ITEMS_PER_WG")) : MI_K1_ITEMS_PER_WG_DEFAULT;
+  const int ipw = (ipw_env > 0 && nitems > resident[device]) ? ipw_env : 0;
+  const int grid = ipw ? (nitems + ipw - 1) / ipw : std::min(nitems, resident[device]);
   if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool
-  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU, TS>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool);
+  hipLaunchKernelGGL((tile_search_kernel<MAXBS, NW, BU, TS>), dim3(grid), dim3(64 * NW), lds, s, d_frames, d_jobs, d_items, nitems, d_next, d_snap_pool, ipw);
   return hipGetLastError();
 }
 static size_t k1_snap_bytes(int maxbs) { return MI_K1_POOL_BYTES(maxbs); }
@@ -324,6 +330,13 @@ static int search_mode(const std::vector<FramePlan> &frames) {
   }
   return (c0.encode_bottomup != 0 ? 1 : 0) | (c0.complex_pred_modes != 0 ? 2 : 0) | (speed4_switches ? 4 : 0);
 }
+// The walker and the candidate set are template parameters of the launch (taken from frames[0]): every frame must agree on them.  They follow from the speed alone, which a
+// batch shares, but mi_av1_config lets a caller override the resolved tweaks per call -- a mixed launch would run the wrong candidate set for some frames, silently.
+static bool search_mode_consistent(const std::vector<FramePlan> &frames) {
+  for (const FramePlan &p : frames)
+    if ((p.cfg.encode_bottomup != 0) != (frames[0].cfg.encode_bottomup != 0) || (p.cfg.complex_pred_modes != 0) != (frames[0].cfg.complex_pred_modes != 0)) return false;
+  return true;
+}
 static int search_launch(SearchQueue &q, int mode /* search_mode() */, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   for (int cls = 2; cls <= 4; cls++)
     HIP_OK(launch_search(cls, (mode & 1) != 0, mode >> 1, d_frames, d_jobs + class_begin[cls], q.d_items + q.q_begin[cls], q.q_begin[cls + 1] - q.q_begin[cls], q.d_next + 2 * cls, q.d_snap, nullptr, device, s));
@@ -355,6 +368,7 @@ static int search_reserve(SearchQueue &q, const std::vector<FramePlan> &frames, 
 static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, const std::vector<TileJob> &jobs, const int class_begin[6], const FrameDev *d_frames, const TileJob *d_jobs, int device, hipStream_t s) {
   q.items.clear();
   size_t snap_need = 0;
+  if (!search_mode_consistent(frames)) return MI_INVALID_ARGUMENT;
   const int mode = search_mode(frames);
   for (int cls = 2; cls <= 4; cls++) {
     q.q_begin[cls] = (int)q.items.size();
@@ -398,6 +412,7 @@ struct mi_batch {
   mi_ravif_encoder enc{}; int n = 0; uint32_t w = 0, h = 0; int channels = 3, device = 0, depth = 10;
   std::vector<uint8_t> exif;                                       // the batch's own copy of enc.exif (the caller's buffer need not outlive mi_batch_create)
   hipStream_t stream = nullptr;
+  hipStream_t stream_hi = nullptr; hipEvent_t ev_hi = nullptr;   // MI_POSTK1_PRIORITY=1 (probe): the stages after the tile search on a high-priority stream of their own
   int cap = 0;                                                     // images the batch was created for (n = images of the current run <= cap)
   uint8_t *d_pixels = nullptr; size_t pixel_bytes = 0;            // cap * w*h*channels
   uint8_t *h_pixels = nullptr;                                     // pinned staging of the same size: the H2D source (async, no pageable copies)
@@ -527,6 +542,10 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   b->enc.exif = b->exif.empty() ? nullptr : b->exif.data(); b->enc.exif_len = b->exif.size();
   b->alpha_flags.assign(n_images, 0);
   b->pixel_bytes = (size_t)n_images * w * h * channels;
+  if (getenv("MI_POSTK1_PRIORITY") && atoi(getenv("MI_POSTK1_PRIORITY")) > 0) {
+    int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&b->stream_hi, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&b->ev_hi, hipEventDisableTiming) != hipSuccess) b->stream_hi = nullptr;
+  }
   bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess && hipHostMalloc(&b->h_pixels, b->pixel_bytes) == hipSuccess &&
             hipMalloc(&b->d_alpha_flags, sizeof(int) * n_images) == hipSuccess;
   if (ok && channels == 4 && e->alpha_mode == 1)
@@ -684,11 +703,14 @@ int mi_batch_encode_async(mi_batch *b) {
     if (pass == 0) { if (int st = search_enqueue(b->queue, b->frames, b->jobs, class_begin, b->d_frames, b->d_jobs, b->device, s)) return st; }
     else if (int st = search_launch(b->queue, search_mode(b->frames), class_begin, b->d_frames, b->d_jobs, b->device, s)) return st;
     HIP_OK(hipEventRecord(b->ev[2], s));
-    HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, s, b->ev[3]));
-    HIP_OK(hipEventRecord(b->ev[4], s));
+    hipStream_t sp = s;
+    if (b->stream_hi) { sp = b->stream_hi; HIP_OK(hipStreamWaitEvent(sp, b->ev[2], 0)); }
+    HIP_OK(launch_loop_filters(b->d_frames, nframes, max_mi_cells, max_sb, max_lr, max_lr_sets, sp, b->ev[3]));
+    HIP_OK(hipEventRecord(b->ev[4], sp));
     for (int cls = 2; cls <= 4; cls++)
       HIP_OK(launch_entropy(cls, b->d_frames, b->d_jobs + class_begin[cls], class_begin[cls + 1] - class_begin[cls], b->d_precarry + (size_t)class_begin[cls] * (size_t)b->pre_cap, b->pre_cap,
-                            b->d_recbuf + (size_t)class_begin[cls] * 3 * (size_t)b->rec_cap, b->rec_cap, s));
+                            b->d_recbuf + (size_t)class_begin[cls] * 3 * (size_t)b->rec_cap, b->rec_cap, sp));
+    if (b->stream_hi) { HIP_OK(hipEventRecord(b->ev_hi, sp)); HIP_OK(hipStreamWaitEvent(s, b->ev_hi, 0)); }
   }
   HIP_OK(hipGetLastError());
   // ---- tile lengths -> offsets -> pack -> one D2H

@@ -1067,6 +1067,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
   bool cfull = false;
   if constexpr (SMALL_GROUPED && Tools<TS>::FULL) cfull = f->np > 1 && Tools<TS>::FULL;
   if constexpr (SMALL_GROUPED && Tools<TS>::FULL) if (cfull) {
+    static_assert(NW == 4 && MAXN <= 32, "the full candidate set's chroma stage deals (plane, parity) to four wavefronts");
     const uint16_t *uvcost = k.cost() + CDF_UV_CFL + best_mode * CDF_UV_CFL_STRIDE;
     unsigned long long cand_pack = 0; int nc = 0;
     auto push = [&](int m) { cand_pack |= (unsigned long long)m << (4 * nc); nc++; };
@@ -1699,7 +1700,7 @@ struct SbItem { uint32_t job; uint16_t sbr, sbc; };
 // BU: the bottom-up partition walker (speed <= 2) is a separate instantiation so that the top-down kernels do not carry its code
 template <int MAXBS, int NW, bool BU, int TS>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU : 1)) void tile_search_kernel(const FrameDev *__restrict__ frames, const TileJob *__restrict__ jobs,
-                                                                                                          const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool) {
+                                                                                                          const SbItem *__restrict__ items, int nitems, int *next_item, uint8_t *snap_pool, int items_per_wg) {
   constexpr int MAXN = k1_maxn(MAXBS);
   extern __shared__ __align__(16) uint8_t smem[];
   using K = Ctx<MAXN, NW, TS>;
@@ -1720,7 +1721,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
 #if MI_PROFILE
   const unsigned long long k_t0_ = clock64(); unsigned long long w_acc_ = 0;
 #endif
-  for (;;) {
+  // items_per_wg > 0: the workgroup leaves after that many work items and the launch has one workgroup per items_per_wg items -- workgroup slots come free all
+  // through the launch, so the kernels of the other batch slots (entropy coder, loop filters) are dispatched beside this one instead of behind it.  The
+  // no-deadlock argument is unchanged: workgroups are dispatched in index order and claim items in list order, so whatever an item waits for was claimed by a
+  // workgroup that started earlier.  0: persistent workgroups (one per resident slot) that loop until the list is empty.
+  for (int done_items = 0; items_per_wg <= 0 || done_items < items_per_wg; done_items++) {
 #if MI_PROFILE
     const unsigned long long w_t0_ = clock64();
 #endif

@@ -70,7 +70,7 @@ void av1o_code_coeffs(const Av1oFrame *f, const int32_t *qc, int eob, int plane,
   }
   /* level map with a 4-wide zero border to the right/bottom */
   const int st = n + 4;
-  static uint8_t lev[(32 + 4) * (32 + 4)];
+  static __thread uint8_t lev[(32 + 4) * (32 + 4)];
   memset(lev, 0, (size_t)st * (size_t)(nh + 4));
   for (int i = 0; i < eob; i++) { int p = scan[i]; int a = iabs(qc[p]); lev[(p >> bwl) * st + (p & (n - 1))] = (uint8_t)imin(a, 127); }
   const int area = n * nh;
@@ -223,7 +223,7 @@ static void write_block(TileW *w, int r, int c, int bs) {
   }
   if (skip) return;
   /* residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not) */
-  static int32_t qc[1024];
+  static __thread int32_t qc[1024];
   for (int p = 0; p < f->np; p++) {
     const int txs = p == 0 ? txs_y : (bs == BS_64 ? TX_32X32 : bs) /* chroma transforms stop at 32x32 (spec get_tx_size) */, n = imin(32, 1 << dim_wl(txs)), nh = imin(32, 1 << dim_hl(txs));
     const int stepw = 1 << (dim_wl(txs) - 2), steph = 1 << (dim_hl(txs) - 2), nbw = 1 << (dim_wl(bs) - dim_wl(txs)), nbh = 1 << (dim_hl(bs) - dim_hl(txs));

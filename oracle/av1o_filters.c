@@ -118,7 +118,7 @@ static void deblock_tally_line(const Av1oFrame *f, int plane, const uint16_t *re
   }
 }
 void av1o_deblock_search(Av1oFrame *f, int64_t tally[3][2][64]) {
-  static int64_t diff[3][2][65];
+  static __thread int64_t diff[3][2][65];
   memset(diff, 0, sizeof(diff));
   for (int plane = 0; plane < f->np; plane++) for (int pass = 0; pass < 2; pass++)
     for (int r = 0; r < f->mi_rows; r++) for (int c = 0; c < f->mi_cols; c++) {

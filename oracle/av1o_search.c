@@ -83,8 +83,31 @@ static void fill_map2(uint8_t *m, int ms, int r, int c, int w4, int h4, int v) {
 }
 static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) { fill_map2(m, ms, r, c, n4, n4, v); }
 
+/* Ablation switches (environment, oracle only -- the divergence ledger of BASELINE.md section 5; tools/divergence_ledger.py): each turns ONE deliberate difference from what
+ * rav1e does (as recalled) into rav1e's form, so that its effect on bytes / error can be measured.  0 / unset = this encoder's shipped behaviour (what HIP == oracle tests pin).
+ *   AV1O_ABL_SATD8=1        SATD of blocks of 8x8 and more with the 8x8 Hadamard (rav1e get_satd) instead of 4x4 Hadamards everywhere
+ *   AV1O_ABL_SEQ_TXTYPE=1   mode decision with each mode's default transform type, then the transform-type search on the winning mode only (instead of mode x type jointly)
+ *   AV1O_ABL_ONE_TXTYPE=1   one transform type for all sub-blocks of a split transform (rav1e rdo_tx_size_type) instead of one per sub-block */
+static int abl_flag(const char *name) { const char *v = getenv(name); return v && v[0] == '1'; }
+static int64_t satd8_block(const uint16_t *src, int ss, const uint16_t *pred, int ps, int w, int h) {
+  int64_t total = 0;
+  for (int by = 0; by < h; by += 8) for (int bx = 0; bx < w; bx += 8) {
+    int m[64];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) m[i * 8 + j] = (int)src[(by + i) * ss + bx + j] - (int)pred[(by + i) * ps + bx + j];
+    for (int pass = 0; pass < 2; pass++) for (int i = 0; i < 8; i++) {                       /* rows, then columns: three butterfly stages each */
+      int *v = m + (pass ? i : i * 8); const int st = pass ? 8 : 1;
+      for (int len = 1; len < 8; len <<= 1) for (int k = 0; k < 8; k += 2 * len) for (int q = 0; q < len; q++) {
+        const int a = v[(k + q) * st], b = v[(k + q + len) * st]; v[(k + q) * st] = a + b; v[(k + q + len) * st] = a - b;
+      }
+    }
+    int64_t s = 0; for (int i = 0; i < 64; i++) s += iabs(m[i]);
+    total += (s + 2) >> 2;                                                                   /* the 8x8 sum on the scale of four 4x4 ones */
+  }
+  return total;
+}
 /* 4x4 Hadamard SATD summed over the block (rav1e get_satd uses 8x8 for larger blocks) */
 static int64_t satd_block_wh(const uint16_t *src, int ss, const uint16_t *pred, int ps, int w, int h) {
+  if (w >= 8 && h >= 8 && abl_flag("AV1O_ABL_SATD8")) return satd8_block(src, ss, pred, ps, w, h);
   int64_t total = 0;
   for (int by = 0; by < h; by += 4) for (int bx = 0; bx < w; bx += 4) {
     int d[16], t[16];
@@ -116,7 +139,7 @@ static int64_t eval_tx(Search *s, int plane, int r, int c, int txs, int bs /* bl
                        int tx_off, int tx_sym, int tx_ns, uint16_t *rec_out /* n x n */, int32_t *qc_out, TxRes *tr) {
   Av1oFrame *f = s->f;
   const int n = 1 << dim_wl(txs), nh = 1 << dim_hl(txs), cs = imin(n, 32), x = c * 4, y = r * 4;      /* pred / rec_out: nh rows of n samples */
-  static int16_t resid[64 * 64]; static int32_t coef[32 * 32], dq[32 * 32];
+  static __thread int16_t resid[64 * 64]; static __thread int32_t coef[32 * 32], dq[32 * 32];
   const uint16_t *src = f->src[plane] + y * f->stride + x;
   for (int i = 0; i < nh; i++) for (int j = 0; j < n; j++) resid[i * n + j] = (int16_t)((int)src[i * f->stride + j] - (int)pred[i * n + j]);
   av1o_fwd_txfm2d(resid, n, coef, txs, txtype, f->bd);
@@ -149,7 +172,7 @@ static void commit_plane(Av1oFrame *f, int plane, int r, int c, int bs, const ui
 /* rdo_cfl_alpha: per plane, the alpha (|a| in 1..16, sign) minimising prediction SSE; 0 = CFL_SIGN_ZERO */
 static int cfl_best_alpha(Search *s, int plane, int r, int c, int bs, const uint16_t *dc_pred) {
   Av1oFrame *f = s->f; const int n = 1 << dim_wl(bs), nh = 1 << dim_hl(bs);
-  static uint16_t tmp[64 * 64];
+  static __thread uint16_t tmp[64 * 64];
   const uint16_t *src = f->src[plane] + r * 4 * f->stride + c * 4;
   int best = 0; int64_t best_sse = sse_block_wh(src, f->stride, dc_pred, n, n, nh);
   for (int mag = 1; mag <= 16; mag++) for (int sg = 0; sg < 2; sg++) {
@@ -177,8 +200,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   #define IS_SMOOTH(m) ((m) == SMOOTH_PRED || (m) == SMOOTH_V_PRED || (m) == SMOOTH_H_PRED)
   const int ftype_y = (availU && IS_SMOOTH(f->m_ymode[mi - ms])) || (availL && IS_SMOOTH(f->m_ymode[mi - 1]));
   const int ftype_uv = (availU && IS_SMOOTH(f->m_uvmode[mi - ms])) || (availL && IS_SMOOTH(f->m_uvmode[mi - 1]));
-  static uint16_t pred[64 * 64], rec_best[3][64 * 64], rec_tmp[64 * 64];
-  static int32_t qc_best[3][32 * 32], qc_tmp[32 * 32];
+  static __thread uint16_t pred[64 * 64], rec_best[3][64 * 64], rec_tmp[64 * 64];
+  static __thread int32_t qc_best[3][32 * 32], qc_tmp[32 * 32];
   const uint16_t *src = f->src[0] + y * f->stride + x;
   /* the block's segment (SegmentationLevel::Simple: from its mean activity scale) selects the quantiser of all its planes */
   const int seg = av1o_block_segment(f, x, y, n, bh);
@@ -196,8 +219,10 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   /* ---- full RD over surviving (mode, angle delta) x tx type ---- */
   int64_t best_j = INT64_MAX, best_mode_j = 0; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
   int tx_ns, tx_set;
-  for (int ci = 0; ci < ncand; ci++) {
-    const int m = order[ci];
+  int seq_second = 0;
+  for (int ci = 0; ci < ncand + (abl_flag("AV1O_ABL_SEQ_TXTYPE") ? 1 : 0); ci++) {
+    if (ci == ncand) seq_second = 1;                               /* AV1O_ABL_SEQ_TXTYPE: the extra round = the transform-type search on the winning mode */
+    const int m = seq_second ? best_mode : order[ci];
     int delta = 0;
     const int directional = m >= V_PRED && m <= D67_PRED;
     if (directional && big && f->cfg.fine_directional) {
@@ -213,7 +238,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     uint32_t mode_rate = ycost[m];
     if (directional && big) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
     const int tx_off = av1o_intra_tx_cdf(f, txs, m, &tx_ns, &tx_set);
-    const int ntx = (f->cfg.rdo_tx && tx_off >= 0) ? tx_ns : 1;
+    const int seq_tx = abl_flag("AV1O_ABL_SEQ_TXTYPE");          /* ablation: pass 0 (ci < ncand) prices the mode with its default type; pass 1 (the winner again) tries the others */
+    const int ntx = (f->cfg.rdo_tx && tx_off >= 0 && !(seq_tx && !seq_second)) ? tx_ns : 1;
     for (int ti = 0; ti < ntx; ti++) {
       int txtype;
       if (ntx > 1) txtype = av1o_symbol_to_tx_type(tx_set, ti);
@@ -249,11 +275,17 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         const int stx = dim_is_rect(bs) ? dim_min_l(bs) - 2 : bs - d, hn = 4 << stx, half = 1 << stx, G = n / hn, GH = bh / hn;
         int64_t j_split = best_mode_j + (((int64_t)dcost[d] * f->rdmult[0] + 256) >> 9);
         int sub_any = 0;
-        static uint16_t spred[32 * 32], srec[2][32 * 32]; static int32_t sqc[2][32 * 32];
+        static __thread uint16_t spred[32 * 32], srec[2][32 * 32]; static __thread int32_t sqc[2][32 * 32];
         int stx_ns, stx_set;
         const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
-        for (int k = 0; k < G * GH && j_split < best_j; k++) {
+        /* AV1O_ABL_ONE_TXTYPE: the depth is tried once per transform type with every sub-block forced to it; the best type's trial is repeated last so that the frame holds it */
+        const int one_tx = abl_flag("AV1O_ABL_ONE_TXTYPE") && sntx > 1;
+        int forced = -1, forced_best = 0; int64_t forced_best_j = INT64_MAX;
+        const int64_t j_split0 = j_split;
+        for (int ft = 0; ft < (one_tx ? sntx + 1 : 1); ft++) {
+        if (one_tx) { forced = ft < sntx ? ft : forced_best; j_split = j_split0; sub_any = 0; set_decoded(f, r, c, bs, 0); }
+        for (int k = 0; k < G * GH && (j_split < best_j || (one_tx && ft == sntx)); k++) {
           const int bi = k / G, bj_ = k % G;
           const int rr = r + bi * half, cc = c + bj_ * half;
           const int sU = availU || bi, sL = availL || bj_;
@@ -262,6 +294,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
           av1o_predict_intra(f, t, 0, cc * 4, rr * 4, 2 + stx, sL, sU, s_ar, s_bl, best_mode, best_delta, ftype_y, spred, hn);
           int64_t bj = INT64_MAX; int btx = DCT_DCT, cur = 0; TxRes btr = { 0, 0, 0, 0, 0 };
           for (int ti = 0; ti < sntx; ti++) {
+            if (forced >= 0 && ti != forced) continue;
             int txtype;
             if (sntx > 1) txtype = av1o_symbol_to_tx_type(stx_set, ti);
             else { txtype = av1o_mode_to_txtype(best_mode); if (stx_off < 0 || !av1o_tx_type_in_set(stx_set, txtype)) txtype = DCT_DCT; }
@@ -274,6 +307,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
           set_decoded(f, rr, cc, stx, 1);
           sub_any |= btr.eob > 0;
           j_split += bj;
+        }
+        if (one_tx && ft < sntx && j_split < forced_best_j) { forced_best_j = j_split; forced_best = ft; }
         }
         set_decoded(f, r, c, bs, 0);
         if (j_split < best_j) {
@@ -303,8 +338,9 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     if (f->cfg.complex_modes) for (int m = 1; m < 13; m++) if (m != best_mode) cands[nc++] = m;
     if (cfl_allowed) cands[nc++] = UV_CFL_PRED;
     int64_t best_uv = INT64_MAX; int buv = DC_PRED, bdelta = 0, bsign = 0, bau = 0, bav = 0; TxRes btr[3];
-    static uint16_t rec_c[3][64 * 64]; static int32_t qc_c[3][32 * 32];
-    static ChromaSnap64 uv_snap64; int uv_any64 = 0, uv_in_frame = 0;
+    /* (per-thread scratch: the search of different tiles may run on different threads) */
+    static __thread uint16_t rec_c[3][64 * 64]; static __thread int32_t qc_c[3][32 * 32];
+    static __thread ChromaSnap64 uv_snap64; int uv_any64 = 0, uv_in_frame = 0;
     for (int ci = 0; ci < nc; ci++) {
       const int um = cands[ci];
       int delta = (um == best_mode && um >= V_PRED && um <= D67_PRED && big) ? best_delta : 0;
@@ -427,7 +463,7 @@ static int rd_partition(Search *s, int r, int c, int bs, int64_t known_j) {
   int do_split = must_split;
   int64_t sub_j[4] = { -1, -1, -1, -1 };
   if (!must_split) {
-    static AreaSnap snap[5];
+    static __thread AreaSnap snap[5];
     const int64_t j_blk = known_j >= 0 ? known_j : try_block(s, r, c, bs);
     int64_t j_none = j_blk + (((int64_t)partition_rate(s, r, c, bs, PARTITION_NONE) * f->rdmult[0] + 256) >> 9);
     area_copy(f, &snap[bs], r, c, bs, 1);
@@ -481,7 +517,7 @@ static int64_t rd_partition_bottomup(Search *s, int r, int c, int bs) {
   const int has_rows = (r + half) < f->mi_rows, has_cols = (c + half) < f->mi_cols;
   const int must_split = bs > BS_4 && (px > f->cfg.part_max || !has_rows || !has_cols);
   const int can_split = bs > BS_4 && (px > f->cfg.part_min || must_split);
-  static AreaSnap snap[5];
+  static __thread AreaSnap snap[5];
   set_decoded(f, r, c, bs, 0);
   int64_t j_none = INT64_MAX;
   if (!must_split) {
@@ -527,12 +563,12 @@ void av1o_search_tile(Av1oFrame *f, int tile_row, int tile_col) {
   }
   /* AV1O_LIVE_CDF=1: the experiment of av1o_entropy.c av1o_live_* (rates from the tile's adaptive CDFs, refreshed after every superblock) */
   void *live = getenv("AV1O_LIVE_CDF") ? av1o_live_open(f, tile_row, tile_col) : NULL;
-  static uint32_t live_cost[CDF_TOTAL];
+  static __thread uint32_t live_cost[CDF_TOTAL];
   if (live) { memcpy(live_cost, f->cost0, sizeof(live_cost)); f->cost = live_cost; }
   for (int r = s.t.mi_row_start; r < s.t.mi_row_end; r += SB_MI)
     for (int c = s.t.mi_col_start; c < s.t.mi_col_end; c += SB_MI) {
       if (f->cfg.bottomup) rd_partition_bottomup(&s, r, c, BS_64); else rd_partition(&s, r, c, BS_64, -1);
       if (live) av1o_live_sb(live, r, c, live_cost);
     }
-  if (live) av1o_live_close(live);
+  if (live) { av1o_live_close(live); f->cost = f->cost0; }     /* the experiment's table is this call's: later stages price against the frame's own again */
 }

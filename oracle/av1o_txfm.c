@@ -50,7 +50,7 @@ void av1o_fwd_txfm2d(const int16_t *resid, int rstride, int32_t *coef, int txs, 
   const int8_t *sh = dim_is_rect(txs) ? sh_rect : sh_sq[txs];
   int ck, rk; tx_kinds(txtype, &ck, &rk);
   tx1d_fn colf = pick(1, ck, h), rowf = pick(1, rk, w);
-  static int32_t buf[64 * 64];
+  static __thread int32_t buf[64 * 64];
   int32_t t[64];
   for (int c = 0; c < w; c++) {
     for (int r = 0; r < h; r++) t[r] = rshift_round(resid[r * rstride + c], -sh[0]);
@@ -74,7 +74,7 @@ void av1o_inv_txfm2d_add(const int32_t *dq, uint16_t *dst, int dstride, int txs,
   const int row_shift = dim_is_rect(txs) ? 0 : row_shift_sq[txs];
   int ck, rk; tx_kinds(txtype, &ck, &rk);
   tx1d_fn colf = pick(0, ck, h), rowf = pick(0, rk, w);
-  static int32_t res[64 * 64];
+  static __thread int32_t res[64 * 64];
   int32_t t[64];
   const int rmax = (1 << (bd + 7)) - 1, rmin = -(1 << (bd + 7));
   const int cbits = imax(bd + 6, 16), cmax = (1 << (cbits - 1)) - 1, cmin = -(1 << (cbits - 1));

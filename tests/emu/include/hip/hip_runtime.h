@@ -137,9 +137,14 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, struct emu_event_ *, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 double emu_now_ms();
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event_{ 0.0 }; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event_{ 0.0 }; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = emu_now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
