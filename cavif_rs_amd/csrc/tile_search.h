@@ -402,7 +402,8 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
     // on rows of waves 2 and 3 (predict_nondir_group)
     if (W < 2) {
       const int g = GROUP_ID;
-      const int m = W == 0 ? (g == 0 ? V_PRED : g == 1 ? H_PRED : g == 2 ? D45_PRED : D67_PRED) : D135_PRED + g;
+      // wave 0: the predictions that read ONE edge (V, D203: left only; D45, D67: above only); wave 1: the three between 90 and 180 degrees that interpolate on both, and H
+      const int m = W == 0 ? (g == 0 ? V_PRED : g == 1 ? D203_PRED : g == 2 ? D45_PRED : D67_PRED) : (g < 3 ? D135_PRED + g : H_PRED);
       LDS GroupPredBuf *gp = &S->gpred[g];
       predict_dir_group<n>(f, x, y, availL, availU, mode_angle_of(m), ftype_y, ra, rl, gp);
       const int sd = satd_group<n>(SH->srcb[0], gp->pred);
