@@ -51,27 +51,27 @@ VALU_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 G
 
 
 def valu_roofline(kernel, cfg, launch_ms, pixels):
-    """What actually bounds the tile search: VALU issue.  From the committed SQ_* counter pass (profiles/valu_counters.json, tools/final_profile.sh; taken on this
-    workload) and THIS run's launch duration: the fraction of the chip's VALU issue cycles the kernel kept busy, the share of lanes its VALU instructions had
-    active, and the VALU work per pixel.  None when the counters are for another workload."""
+    """What actually bounds the tile search: VALU instruction issue.  From the committed SQ_* counter passes (profiles/valu_counters.json, tools/final_profile.sh; taken on
+    this workload) and THIS run's launch duration: wave-level VALU instructions issued per second against what the chip's 1024 SIMDs can issue at four clocks per
+    instruction, the share of lanes those instructions had active, and the VALU work per pixel.  None when the counters are for another workload."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'valu_counters.json')) as fh:
             d = json.load(fh)
         if any(d['config'].get(k_) != v_ for k_, v_ in cfg.items()):
             return None
         c = d['kernels'][kernel]
-        act, thr = c['SQ_ACTIVE_INST_VALU'], c['SQ_THREAD_CYCLES_VALU']
-        peak_cycles = 256 * 4 * VALU_CLOCK_GHZ * 1e9 * launch_ms / 1e3              # SIMD-cycles available during one launch at the peak clock
-        out = {"bound": "valu", "kernel": kernel, "achieved": round(act * 4.0 / (launch_ms / 1e3) / 1e12, 4), "peak": round(256 * 4 * VALU_CLOCK_GHZ / 1e3, 4), "unit": "T VALU-busy SIMD-cycles/s",
-               "frac": round(act * 4.0 / peak_cycles, 4), "lane_utilisation": round(thr / (64.0 * act), 4),
-               "valu_busy_quad_cycles_per_launch": act, "valu_busy_quad_cycles_per_pixel": round(act / pixels, 2),
+        insts, thr = c.get('SQ_INSTS_VALU', c['SQ_ACTIVE_INST_VALU']), c['SQ_THREAD_CYCLES_VALU']
+        peak = 256 * 4 * VALU_CLOCK_GHZ / 4.0                                            # G wave-instructions / s: 1024 SIMDs, one VALU instruction per 4 clocks each
+        achieved = insts / (launch_ms / 1e3) / 1e9
+        out = {"bound": "valu", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "G VALU wave-instructions/s",
+               "frac": round(achieved / peak, 4), "lane_utilisation": round(thr / (64.0 * c['SQ_ACTIVE_INST_VALU']), 4),
+               "valu_wave_instructions_per_launch": insts, "valu_wave_instructions_per_pixel": round(insts / pixels, 2),
                "counters_launch_ms": c.get('avg_launch_ms'), "launch_ms": round(launch_ms, 3),
-               "note": "frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles the SIMDs spent issuing VALU work, summed over the chip) / (1024 SIMDs x launch time x 2.4 GHz); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); counters from profiles/valu_counters.json (own rocprofv3 --pmc pass), launch time from this run"}
-        if 'SQ_INSTS_VALU' in c:
-            out["valu_wave_instructions_per_pixel"] = round(c['SQ_INSTS_VALU'] / pixels, 2)
-            out["quad_cycles_per_valu_instruction"] = round(act / c['SQ_INSTS_VALU'], 3)
+               "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks: on gfx950 the multiplies, compares, selects, min / max, left shifts, DPP, packed and dot forms and anything with an SGPR operand issue in ~4 clocks per wave, adds / logic / right shifts in ~2 (tools/probe/valu_rates.hip, profiles/r05_valu_rates.txt): frac 1.0 is reachable only by a kernel made of the first kind; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); counters from profiles/valu_counters.json (own rocprofv3 --pmc passes), launch time from this run"}
         if 'SQ_WAIT_ANY' in c and 'SQ_WAVE_CYCLES' in c:
             out["wave_time_waiting"] = round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)
+        if 'SQ_INSTS_SALU' in c:
+            out["salu_wave_instructions_per_pixel"] = round(c['SQ_INSTS_SALU'] / pixels, 2)
         return out
     except Exception:
         return None
@@ -487,7 +487,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBS, 8),
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
                                                                              "quality": args.quality, "bit_depth": args.depth}),
-                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, area snapshots and partial-line coefficient writes (not spill scratch: profiles/r04_kernel_resources.txt), served by L2 / Infinity Cache at ~0.6 TB/s -- not what limits the kernel: the step costs 2.76 ms per 1e9 VALU-active cycles of its kernels however they are overlapped (K1 at 2, 3 or 4 workgroups per CU under 3-4 batch slots: 147-148 ms per step each time, profiles/r04x_k1_grid_per_cu_vs_slots.txt; counters: profiles/r04_final_pmc_summary.json)",
+                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, the partition walker's area snapshots, partial-line coefficient writes and the walker's register spills (profiles/r05_kernel_resources.txt: 464 B of scratch per lane in the kernel body, none worth mentioning in the block searches), served by L2 / Infinity Cache; not what limits the kernel -- see roofline_valu; TCP / TCC request, hit and stall counters of the same run: profiles/r05_final_pmc_summary.json",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
                          "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
                          "overlapped_launch_ms": round(k1_overlapped, 3)},
