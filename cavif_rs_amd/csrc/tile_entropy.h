@@ -87,10 +87,11 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 // which adapter owns a CDF row: the low bits of its offset (the hot tables have strides 5 and 3: neighbouring contexts and the same context of
 // neighbouring transform sizes land on different waves)
 template <int NA> __device__ __forceinline__ int k4_row_owner(uint32_t row) {
-  static_assert(NA == 2 || NA == 4, "two or four adapters");
+  static_assert(NA == 2 || NA == 3 || NA == 4, "two, three or four adapters");
   // the parity (or the low two bits) of (context index + table block) of the stride-5 tables -- the coefficient base-level rows are 85 % of all
   // adaptive symbols and four of them (contexts 21 / 22 of the 16x16 luma and chroma blocks) carry 70 %; plain offset parity put 68 % of a 1080p
   // tile's symbols on one of two waves, this puts 53 ... 58 % there, and 35 ... 43 % on the busiest of four (measured on the oracle's symbol stream)
+  if constexpr (NA == 3) return (int)((row / 5u + row / 210u) % 3u);
   return (int)((row / 5u + row / 210u) & (uint32_t)(NA - 1));
 }
 // exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
