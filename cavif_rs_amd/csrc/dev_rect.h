@@ -860,9 +860,13 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
     const int cfl_ok = alpha_u != 0 || alpha_v != 0;
     GroupRes gr = { 0, 0, 0, 0, 0 };
     const int cw = (W & 1) == 0;                              // waves 0 (plane U) and 2 (plane V): their S->dcp already holds the plane's DC prediction
+    // (the luma mode's prediction of plane U / V by the otherwise idle wave 1 / 3, into wave 0's / 2's S->pred: tile_search.h try_block)
+    if (!cw && nplain == 2) {
+      const int p = (W >> 1) + 1;
+      predict_block_wh(f, x, y, WL, HL, availL, availU, best_mode, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, k.wave(W - 1)->pred + NN);
+    }
     if (cw) {
       const int p = (W >> 1) + 1;
-      if (nplain == 2) predict_block_wh(f, x, y, WL, HL, availL, availU, best_mode, 0, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, S->pred + NN);
       {
         const int al = p == 1 ? alpha_u : alpha_v;
         LDS uint16_t *cp = S->pred + (nc - 1) * NN;
@@ -872,6 +876,10 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
         if (LANE < NN) { const int l = ((int)SH->luma_rec[LANE] << 3) - avg, v = al * l, sc = v >= 0 ? round2_(v, 6) : -round2_(-v, 6); cp[LANE] = (uint16_t)iclamp_((int)S->dcp[LANE] + sc, 0, mx); }
       }
       WAVE_SYNC();
+    }
+    WG_SYNC();
+    if (cw) {
+      const int p = (W >> 1) + 1;
       const int g = GROUP_ID, cand = imin_(g, nc - 1);
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);

@@ -992,12 +992,15 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
     const int cfl_ok = alpha_u != 0 || alpha_v != 0;
     GroupRes gr = { 0, 0, 0, 0, 0 };
     const int cw = (W & 1) == 0;                              // waves 0 (plane U) and 2 (plane V): their S->dcp already holds the plane's DC prediction
-    if (cw) {
-      // The candidates' predictions go side by side into S->pred (4 x 64 samples; candidate 0 = DC stays in S->dcp), then
-      // row g of the wave evaluates candidate g.
+    // The candidates' predictions go side by side into the evaluating wave's S->pred (4 x 64 samples; candidate 0 = DC stays in S->dcp), then row g of that wave
+    // evaluates candidate g.  The luma mode's prediction of plane U / V is made by wave 1 / 3 (idle otherwise) straight into wave 0's / 2's S->pred while that wave
+    // builds the CfL prediction: the stage's longest chain loses one block prediction for one barrier.
+    if (!cw && nplain == 2) {
       const int p = (W >> 1) + 1;
-      const LDS uint16_t *pra = SH->ra[p] + EDGE_OFF, *prl = SH->rl[p] + EDGE_OFF;
-      if (nplain == 2) predict_block(f, x, y, log2w, availL, availU, best_mode, bdelta, ftype_uv, pra, prl, wa, wl, S->etmp, S->pred + nn);
+      predict_block(f, x, y, log2w, availL, availU, best_mode, bdelta, ftype_uv, SH->ra[p] + EDGE_OFF, SH->rl[p] + EDGE_OFF, wa, wl, S->etmp, k.wave(W - 1)->pred + nn);
+    }
+    if (cw) {
+      const int p = (W >> 1) + 1;
       {
         const int al = p == 1 ? alpha_u : alpha_v;
         LDS uint16_t *cp = S->pred + (nc - 1) * nn;
@@ -1011,6 +1014,10 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         }
       }
       WAVE_SYNC();
+    }
+    WG_SYNC();                                                // the luma mode's predictions (waves 1, 3) are in place
+    if (cw) {
+      const int p = (W >> 1) + 1;
       const int g = GROUP_ID, cand = imin_(g, nc - 1);
       const int um = cand == nc - 1 ? UV_CFL_PRED : (cand == 0 ? DC_PRED : best_mode);
       int txtype = mode_to_txtype(um);
