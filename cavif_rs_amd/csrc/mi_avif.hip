@@ -304,7 +304,7 @@ static hipError_t launch_loop_filters(FrameDev *d_frames, int nframes, int max_m
   if (ev_cdef) { hipError_t e = hipEventRecord(ev_cdef, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(cdef_kernel, dim3(max_sb, nframes), dim3(256), 0, s, d_frames, 1);
   if (max_lr_units > 0) {
-    hipLaunchKernelGGL(lr_search_kernel, dim3(max_lr_units, 3 * max_lr_sets, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(lr_search_kernel, dim3(max_lr_units, 3, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(lr_kernel, dim3(max_lr_units, 3, nframes), dim3(256), 0, s, d_frames);
   }
   return hipGetLastError();

@@ -222,13 +222,14 @@ __device__ __forceinline__ int lr_chunks(const FrameDev *f, int ur, int uc, int 
   return n;
 }
 
-// One candidate of the search: (unit, plane, parameter set) -> least-squares weights, activity-scaled SSE, RD cost.
-// grid = (units, planes * nsets, frames).  Results go to f->lr_cand[(plane * units + unit) * 16 + set index].
+// The search: (unit, plane) x every parameter set of the frame's list -> least-squares weights, activity-scaled SSE, RD cost per set.
+// grid = (units, planes, frames).  Results go to f->lr_cand[(plane * units + unit) * 16 + set index].  One workgroup walks the sets one after the other on ONE staged
+// window (until round 5 every set had its own workgroup, which staged the same window and read the same source samples again: 4 x the planes' bytes per launch).
 struct LrCand { long long cost; int xq0, xq1; };
 __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__restrict__ frames) {
   const FrameDev *f = frames + blockIdx.z;
   const int nsets = f->sgr_full ? 16 : 4;
-  const int plane = blockIdx.y / nsets, si = blockIdx.y - plane * nsets;
+  const int plane = blockIdx.y;
   if (plane >= f->np || !f->enable_restoration || frame_idle(f)) return;
   const int ucols = lr_units_of(f->w), urows = lr_units_of(f->h);
   const int ui = blockIdx.x;
@@ -243,10 +244,12 @@ __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__res
   const int st = f->stride, bd = f->bd, mx = (1 << bd) - 1;
   const uint16_t *src = f->src[plane];
   const int reduced[4] = { 1, 3, 6, 11 };
-  const int set = f->sgr_full ? si : reduced[si & 3];
-  int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
   __syncthreads();
   const int nch = nch_s;
+#pragma unroll 1
+  for (int si = 0; si < nsets; si++) {
+  const int set = f->sgr_full ? si : reduced[si & 3];
+  int r0, s0, r1, s1; sgr_param(set, &r0, &s0, &r1, &s1);
   int flt[16];
   for (int k = 0; k < 16; k++) flt[k] = 0;
   long long acc[6];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__res
     for (int q = 0; q < nch; q++) {
       const LrChunk c = ch[q];
       if (sweep == 0 || nch > 1) {
-        lr_load_window(L, f, plane, c);
+        if (si == 0 || nch > 1) lr_load_window(L, f, plane, c);       // a one-chunk unit's window stays staged for all its sets
         if (r0) { lr_box_AB<2>(L, c, s0, bd); lr_box_F(L, c, 0, flt); }
         if (r1) { lr_box_AB<1>(L, c, s1, bd); lr_box_F(L, c, 1, flt); }
       }
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(256, 4) void lr_search_kernel(const FrameDev *__res
         ((LrCand *)f->lr_cand)[(size_t)(plane * ucols * urows + ui) * 16 + si] = cnd;
       }
     }
+  }
+  __syncthreads();                                             // the next set reuses the (A, B) maps and the reduction slots
   }
 }
 
