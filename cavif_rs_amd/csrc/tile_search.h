@@ -706,6 +706,9 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
             const int q = P == 0 ? q0 : q1, bi = q / G, bj = q % G;
             const int sx = x + bj * hn, sy = y + bi * hn;
             const int sU = availU || bi, sL = availL || bj;
+            // The pair's first wave carries the slot's serial chain (edges -> prediction -> four evaluations) while the other waves have a quarter of that or
+            // nothing: it takes issue priority on its SIMD over the waves other workgroups have there until its evaluations are in (-1 % K1, profiles/r05zh_*).
+            if (WP == 0 && q >= 0) __builtin_amdgcn_s_setprio(3);
             if (WP == 0 && q >= 0) {
               const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
               const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
@@ -780,6 +783,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
               }
             }
             if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+            __builtin_amdgcn_s_setprio(0);
             PH(25);
             WG_SYNC();
             PH(26);

@@ -56,6 +56,7 @@ extern thread_local alignas(16) uint8_t k4_smem[];
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __threadfence() {}
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) emu::spin_yield()      /* a workgroup waiting for another one: let its OS thread run */
 inline int __shfl(int v, int src, int width = 64) { (void)width; return emu::xlane(emu::X_SHFL, v, 0, src, 0, 0, 0, -1); }
 inline void __syncthreads() { emu::wg_barrier(); }
