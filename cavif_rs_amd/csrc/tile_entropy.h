@@ -629,6 +629,10 @@ __global__ __launch_bounds__(MI_K4_THREADS_OF(NA) MI_K4_LB_EXTRA) void tile_entr
   const int tile = tj.tile_row * f->tile_cols + tj.tile_col;
   if (frame_idle(f)) { if (threadIdx.x == 0) f->tile_len[tile] = 0; return; }
   const int wave = uni32((int)(threadIdx.x >> 6));             // 0 producer, 1 .. NA adapters, NA + 1 coder
+  // Issue priorities by stage: a tile lasts as long as its busiest stage, and every SIMD hosts one stage of each of four tiles.  The last adapter (the busiest stage:
+  // 24.1 M busy cycles per tile against the producer's 15.9 M, profiles/r04_k4_phase_profile.txt) goes first, then the other adapters, the coder, the producer:
+  // 20.3 -> 17.3 ms on the 1024-tile batch (profiles/r05zj_ab_k4prio2.txt; adapters first and equal 18.0, coder first 19.5).
+  if (wave == NA) __builtin_amdgcn_s_setprio(3); else if (wave >= 1 && wave < NA) __builtin_amdgcn_s_setprio(2); else if (wave == NA + 1) __builtin_amdgcn_s_setprio(1);
   uint32_t *const bufs = recbuf + (size_t)job * 3 * rec_cap;
   const int row0 = f->tile_row_start[tj.tile_row] * 16, row1 = imin_(f->tile_row_start[tj.tile_row + 1] * 16, f->mi_rows);
   const int col0 = f->tile_col_start[tj.tile_col] * 16, col1 = imin_(f->tile_col_start[tj.tile_col + 1] * 16, f->mi_cols);
