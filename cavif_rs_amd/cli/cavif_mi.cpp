@@ -52,9 +52,35 @@ int usage(const char *msg) {
 
 #include <chrono>
 #include <unistd.h>
+#include <malloc.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
   const double t_start = now_s(); const bool timing = getenv("CAVIF_MI_TIMING") != nullptr;
+  // The loaders' buffers (file, inflate output, RGBA: ~8 MB each) come from the heap arenas and stay there: as anonymous mappings every one of them is an
+  // mmap + page faults + munmap (a TLB shootdown across the loader threads), all under the address-space lock the HIP runtime needs while it starts.
+  mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  // Device teardown off the caller's clock: the work runs in a child; once every output is on disk the child reports its status through a pipe, the
+  // parent returns it at once, and the child's exit (the kernel unpins the staging, frees the arenas and destroys the queues: ~0.35 s) goes on unattended.
+  int done_fd = -1;
+  if (!getenv("CAVIF_MI_FOREGROUND_EXIT")) {
+    int pfd[2];
+    if (pipe(pfd) == 0) {
+      const pid_t child = fork();
+      if (child > 0) {
+        close(pfd[1]);
+        unsigned char st = 0; ssize_t n;
+        do n = read(pfd[0], &st, 1); while (n < 0 && errno == EINTR);
+        if (n == 1) _exit(st);
+        int ws = 0; while (waitpid(child, &ws, 0) < 0 && errno == EINTR) {}                     // the child ended without reporting (usage error, crash): its status is ours
+        _exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws));
+      }
+      if (child == 0) { close(pfd[0]); done_fd = pfd[1]; prctl(PR_SET_PDEATHSIG, SIGKILL); }
+      else { close(pfd[0]); close(pfd[1]); }                                                  // no fork: everything in this process
+    }
+  }
   float quality = 80.f; int speed = 4, threads = 0, depth = 0, color_model = 0, rdo_passes = 1;
   bool overwrite = false, quiet = false, dirty_alpha = false, have_output = false, output_stdio = false;
   std::string output; std::vector<std::string> images; std::vector<int> devices;
@@ -149,19 +175,25 @@ int main(int argc, char **argv) {
   // stay at most `window` images ahead of the images the encoder has released (pixels copied to its staging and freed here), so
   // host memory is bounded for any number of files.
   std::mutex mu; std::condition_variable cv; std::vector<char> loaded(files.size(), 0);
-  const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(threads > 0 ? (unsigned)threads : 64u, std::thread::hardware_concurrency())));
+  // A 1080p PNG decodes in ~25 ms and one GPU takes an image every ~4 ms: a dozen loaders per GPU keep up with room to spare, and 24 hand the first run
+  // over in one round.  More of them only contend with the HIP runtime's start (64 loaders: runtime + first batch object up after 0.55 s instead of 0.2 s,
+  // profiles/r05zk_e2e_knobs.txt).  The pool starts before the device count is known and grows once it is.
+  const unsigned loaders_per_device = 12, loaders_first = getenv("CAVIF_MI_LOADERS") ? (unsigned)atoi(getenv("CAVIF_MI_LOADERS")) : 2 * loaders_per_device;
+  const unsigned loaders_cap = std::max(1u, threads > 0 ? std::min((unsigned)threads, std::thread::hardware_concurrency()) : std::thread::hardware_concurrency());
+  const size_t nw = std::min<size_t>(files.size(), std::max(1u, std::min(loaders_first, loaders_cap)));
   std::atomic<size_t> window{ 4 * 32 + nw };                        // widened below once the device count is known (loaders start first)
   size_t released = 0;                                              // guarded by mu: images the encoder is done reading (or that failed to load)
   std::atomic<size_t> next{ 0 };
   std::vector<std::thread> pool;
-  for (size_t t = 0; t < nw; t++) pool.emplace_back([&] {
+  auto loader = [&] {
     for (size_t i; (i = next.fetch_add(1)) < files.size();) {
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return i < released + window; }); }
       load(i);
       { std::lock_guard<std::mutex> lk(mu); loaded[i] = 1; if (!jobs[i].error.empty()) released++; }
       cv.notify_all();
     }
-  });
+  };
+  for (size_t t = 0; t < nw; t++) pool.emplace_back(loader);
   struct Ctx { std::vector<Job> *jobs; std::mutex *mu; std::condition_variable *cv; std::vector<char> *loaded; size_t *released; } ctx{ &jobs, &mu, &cv, &loaded, &released };
   auto fetch = [](void *user, size_t i, mi_image_desc *d) -> int {
     Ctx *c = (Ctx *)user;
@@ -181,7 +213,9 @@ int main(int argc, char **argv) {
   std::vector<mi_encoded_image> enc_out(jobs.size()); std::vector<int> status(jobs.size(), MI_OK);
   if (timing) fprintf(stderr, "[timing] setup %.3f s\n", now_s() - t_start);
   const size_t ndev_used = devices.empty() ? (size_t)std::max(1, mi_device_count()) : devices.size();      // brings the HIP runtime up while the loaders run
-  { std::lock_guard<std::mutex> lk(mu); window = 4 * 32 * ndev_used + nw; }
+  const size_t nw_all = std::min<size_t>(files.size(), std::min<size_t>(loaders_cap, getenv("CAVIF_MI_LOADERS") ? nw : loaders_per_device * (ndev_used + 1)));
+  { std::lock_guard<std::mutex> lk(mu); window = 4 * 32 * ndev_used + nw_all; }
+  for (size_t t = nw; t < nw_all; t++) pool.emplace_back(loader);
   cv.notify_all();
   if (timing) fprintf(stderr, "[timing] HIP runtime up %.3f s\n", now_s() - t_start);
   const int rc_all = mi_ravif_encode_stream(&enc, jobs.size(), fetch, release, &ctx, enc_out.data(), status.data(), devices.empty() ? nullptr : devices.data(), (int)devices.size());
@@ -214,6 +248,11 @@ int main(int argc, char **argv) {
     if (!j.error.empty()) { failures++; if (!quiet) fprintf(stderr, "error: %s: error: %s\n", j.in_name.c_str(), j.error.c_str()); }
   }
   // every output is on disk: leave without the HIP runtime's teardown (freeing pinned staging and contexts costs ~0.3 s)
+  if (timing) {                                                    // wall-clock stamps for a caller that times process start and exit (tools/e2e_timeline.py)
+    const double wall = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[timing] main entered at %.6f, leaving at %.6f (unix time)\n", wall - (now_s() - t_start), wall);
+  }
   fflush(stdout); fflush(stderr);
+  if (done_fd >= 0) { const unsigned char st = failures ? 1 : 0; close(0); close(1); close(2); if (write(done_fd, &st, 1) != 1) {} }
   _exit(failures ? 1 : 0);
 }

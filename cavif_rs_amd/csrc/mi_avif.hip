@@ -22,6 +22,12 @@
 
 // The product library reads no environment variables; probe builds (-DMI_TUNING_KNOBS: tools/) get MI_AVIF_TIMING=1 (host-side timeline on stderr),
 // MI_K1_GRID_PER_CU=n (fewer persistent search workgroups per CU) and, with -DMI_DEBUG_HOOKS=1, MI_DEBUG_LEVEL (bisect levels of the tile search).
+// the streaming form's rotation: resident batch objects per image shape, and the first run's share of a full run
+#ifndef MI_STREAM_SLOTS_DEFAULT
+#define MI_STREAM_SLOTS_DEFAULT 3
+#endif
+#define MI_STREAM_FIRST_RUN_NUM 1
+#define MI_STREAM_FIRST_RUN_DEN 2
 static inline bool mi_timing_enabled() {
 #ifdef MI_TUNING_KNOBS
   static const bool on = getenv("MI_AVIF_TIMING") != nullptr; return on;
@@ -929,15 +935,20 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
     size_t budget = (size_t)48 << 30;
     { size_t fr = 0, tot = 0; if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = fr / 10 * 6; }
     { int sharing = 0; for (int d2 : devs) sharing += d2 == dev; budget /= (size_t)std::max(1, sharing); }      // workers on the same ordinal (devices = [0, 0]) split what is free
-    constexpr int NSLOT = 3;
+    static constexpr int NSLOT_MAX = 4;
+    int NSLOT = MI_STREAM_SLOTS_DEFAULT;
+#ifdef MI_TUNING_KNOBS
+    if (const char *v = getenv("MI_STREAM_SLOTS")) NSLOT = std::min(NSLOT_MAX, std::max(1, atoi(v)));
+#endif
     struct Slot { mi_batch *b = nullptr; std::future<mi_batch *> making; std::vector<size_t> idx; bool busy = false; size_t bytes = 0; };
-    struct Shape { uint32_t w, h; int ch; size_t cap; Slot slot[NSLOT]; int next = 0; size_t runs = 0, last_use = 0; };
+    struct Shape { uint32_t w, h; int ch; size_t cap; Slot slot[NSLOT_MAX]; int next = 0; size_t runs = 0, last_use = 0; };
     std::vector<std::unique_ptr<Shape>> shapes;
     size_t live_bytes = 0, tick = 0;
     auto collect = [&](Slot &sl) {
       if (!sl.busy) return;
       const int rc = mi_batch_wait(sl.b);
-      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu done\n", since(), dev, sl.idx.size());
+      if (timing) fprintf(stderr, "[mi_avif %8.1f ms] dev %d: run of %zu done (on the device: front end %.1f, tile search %.1f, deblock %.1f, cdef + restoration %.1f, entropy %.1f, pack + D2H %.1f ms)\n", since(), dev, sl.idx.size(),
+                          mi_batch_stage_ms(sl.b, 0), mi_batch_stage_ms(sl.b, 1), mi_batch_stage_ms(sl.b, 2), mi_batch_stage_ms(sl.b, 3), mi_batch_stage_ms(sl.b, 4), mi_batch_stage_ms(sl.b, 5));
       for (size_t k = 0; k < sl.idx.size(); k++) st[sl.idx[k]] = rc == MI_OK ? mi_batch_get(sl.b, (int)k, &out[sl.idx[k]]) : rc;
       sl.busy = false;
     };
@@ -1009,7 +1020,11 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
     size_t claims = 0;
     for (;;) {
       // the first claim is half a run: it starts encoding while the caller's loaders are still producing the next (shorter runs leave the GPU part empty)
-      const size_t want = claims++ == 0 ? std::max<size_t>(1, (max_run + 1) / 2) : max_run;
+      size_t first_run = std::max<size_t>(1, max_run * MI_STREAM_FIRST_RUN_NUM / MI_STREAM_FIRST_RUN_DEN);
+#ifdef MI_TUNING_KNOBS
+      if (const char *v = getenv("MI_STREAM_FIRST_RUN")) first_run = std::min(max_run, (size_t)std::max(1, atoi(v)));
+#endif
+      const size_t want = claims++ == 0 ? first_run : max_run;
       const size_t i0 = cursor.fetch_add(want);                // claim the index range [i0, i1)
       if (i0 >= n) break;
       const size_t i1 = std::min(n, i0 + want);
