@@ -1499,6 +1499,10 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // belongs to its own superblock or to one earlier in the work list, so the no-deadlock argument of the list order holds unchanged; the decoded
 // flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
 // superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
+// The acquire after a dependency wait: ONE wavefront invalidates (an agent-scope acquire is `buffer_inv sc1`: the compute unit's vector cache and this XCD's L2 lose their
+// lines, for everybody), the workgroup barrier hands the ordering on to the other three -- four invalidations per wait cost ~1 % of the launch (profiles/r05zn_ab_k1_acquire.txt;
+// the same file: with every L2 writeback / invalidation of the launch removed, which breaks the results across XCDs, the launch is no faster than this).
+#define MI_K1_ACQUIRE() do { if (WAVE_ID == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); WG_SYNC(); } while (0)
 __device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) | (bj & 1) | ((bi & 2) << 2) | ((bj & 2) << 1); }   // Morton index in the superblock
 template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
@@ -1522,7 +1526,7 @@ template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(
     need(0, -1, false); need(-1, 0, false); need(-1, -1, false); need(-1, 1, true); need(1, -1, true);
   }
   WG_SYNC();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  MI_K1_ACQUIRE();
 }
 template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_publish(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
@@ -1791,7 +1795,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
         if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(gf), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       WG_SYNC();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      MI_K1_ACQUIRE();
     }
     unsigned long long *tc = gf->tile_clk + (size_t)(tj.tile_row * gf->tile_cols + tj.tile_col) * 4;
     if (threadIdx.x == 0 && sbr == 0 && sbc == 0) tc[0] = wall_clock64();
