@@ -115,46 +115,53 @@ __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__re
   __shared__ int cnt_s;
   if (threadIdx.x < 65) ldiff[threadIdx.x] = 0;
   const int nlines = deblock_queue_lines(f, plane, pass, (uint32_t)blockIdx.x * MI_DBK_CHUNK, (LDS uint32_t *)list_s, (LDS int *)&cnt_s);
-  for (int j = threadIdx.x; j < nlines; j += 256) {
-    const uint32_t e = list_s[j];
-    const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3, fsz = 4 << (e >> 28);
-    const int s8 = f->bd - 8, half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8), one = 1 << s8;
-    const int step = pass == 0 ? 1 : f->stride;
-    const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
-    const uint16_t *rec = f->rec[plane] + o, *src = f->src[plane] + o;
-    int R[16], S[16];
+  // A lane works on one line at a time and on one FILTER RUN of it per pass of the outer loop.  Above its lowest level lmin the level reaches the filter only through
+  // the high-edge-variance threshold (L >> 4), and hev only falls as L grows: one run at lmin, and when hev held there a second one at the first multiple of 16 where
+  // it no longer does -- each run's SSE change is booked from its level to the next run's (or to 64).  Lines whose lmin is above 63 never get this far: a lane
+  // without a run refills from the queue first, so the filter runs execute on fuller wavefronts (2.54 -> 2.32 ms; lane utilisation of the kernel was 34 %).
+  const int s8 = f->bd - 8, one = 1 << s8, step = pass == 0 ? 1 : f->stride;
+  int j = threadIdx.x, a = 0, a_next = 64, sse0 = 0, fsz = 4;
+  int R[16], S[16];
+  bool have = false;
+  for (;;) {
+    while (!have && j < nlines) {
+      const uint32_t e = list_s[j];
+      j += 256;
+      const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3;
+      fsz = 4 << (e >> 28);
+      const int half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8);
+      const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
+      const uint16_t *rec = f->rec[plane] + o, *src = f->src[plane] + o;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const int q = k - 8; const bool in = q >= -half && q < half; R[k] = in ? (int)rec[(long long)q * step] : 0; S[k] = in ? (int)src[(long long)q * step] : 0; }
-    const int flen = fsz == 4 ? 4 : (plane != 0 ? 6 : (fsz == 8 ? 8 : 16));
-    int dmax = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
-    if (flen >= 6) dmax = imax_(dmax, imax_(iabs_(R[5] - R[6]), iabs_(R[10] - R[9])));
-    if (flen >= 8) dmax = imax_(dmax, imax_(iabs_(R[4] - R[5]), iabs_(R[11] - R[10])));
-    const int b = iabs_(R[7] - R[8]) * 2 + iabs_(R[6] - R[9]) / 2;
-    const int B = (b + one - 1) >> s8;
-    const int lmin = imax_(1, imax_((dmax + one - 1) >> s8, B > 4 ? (B - 2) / 3 : 0));
-    if (lmin <= 63) {
-      int sse0 = 0;
+      for (int k = 0; k < 16; k++) { const int q = k - 8; const bool in = q >= -half && q < half; R[k] = in ? (int)rec[(long long)q * step] : 0; S[k] = in ? (int)src[(long long)q * step] : 0; }
+      const int flen = fsz == 4 ? 4 : (plane != 0 ? 6 : (fsz == 8 ? 8 : 16));
+      int dmax = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
+      if (flen >= 6) dmax = imax_(dmax, imax_(iabs_(R[5] - R[6]), iabs_(R[10] - R[9])));
+      if (flen >= 8) dmax = imax_(dmax, imax_(iabs_(R[4] - R[5]), iabs_(R[11] - R[10])));
+      const int b = iabs_(R[7] - R[8]) * 2 + iabs_(R[6] - R[9]) / 2;
+      const int B = (b + one - 1) >> s8;
+      const int lmin = imax_(1, imax_((dmax + one - 1) >> s8, B > 4 ? (B - 2) / 3 : 0));
+      if (lmin <= 63) {
+        have = true; a = lmin;
+        const int hm = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
+        const int k16 = ((hm + one - 1) >> s8) << 4;          // the first multiple of 16 whose threshold is not below hm
+        a_next = (hm > ((lmin >> 4) << s8) && k16 < 64) ? k16 : 64;
+        sse0 = 0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) { const int d = R[k] - S[k]; sse0 += d * d; }
-      // above lmin the level reaches the filter only through the high-edge-variance threshold (L >> 4): consecutive ranges with the same
-      // hev decision share one filtered line and one (first level, end) pair -- at most two filter runs per line (hev only falls as L grows)
-      const int hm = imax_(iabs_(R[6] - R[7]), iabs_(R[9] - R[8]));
-      long long dl = 0; int hev_open = -1, a_open = 0;
-      for (int a = lmin; a < 64; a = (a | 15) + 1) {
-        const int hev = hm > ((a >> 4) << s8);
-        if (hev == hev_open) continue;
-        if (dl) { atomicAdd((unsigned long long *)&ldiff[a_open], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[a], (unsigned long long)(-dl)); }
-        uint16_t t[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) t[k] = (uint16_t)R[k];
-        filter_edge_sample_dev(t + 8, 1, fsz, plane, a, 0, f->bd);
-        int sse = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const int d = (int)t[k] - S[k]; sse += d * d; }
-        dl = (long long)(sse - sse0); hev_open = hev; a_open = a;
+        for (int k = 0; k < 16; k++) { const int d = R[k] - S[k]; sse0 += d * d; }
       }
-      if (dl) { atomicAdd((unsigned long long *)&ldiff[a_open], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[64], (unsigned long long)(-dl)); }
     }
+    if (!have) break;
+    uint16_t t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = (uint16_t)R[k];
+    filter_edge_sample_dev(t + 8, 1, fsz, plane, a, 0, f->bd);
+    int sse = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int d = (int)t[k] - S[k]; sse += d * d; }
+    const long long dl = (long long)(sse - sse0);
+    if (dl) { atomicAdd((unsigned long long *)&ldiff[a], (unsigned long long)dl); atomicAdd((unsigned long long *)&ldiff[a_next], (unsigned long long)(-dl)); }
+    if (a_next < 64) { a = a_next; a_next = 64; } else have = false;
   }
   __syncthreads();
   if (threadIdx.x < 65 && ldiff[threadIdx.x]) atomicAdd((unsigned long long *)&f->lf_tally[(plane * 2 + pass) * 65 + threadIdx.x], (unsigned long long)ldiff[threadIdx.x]);
