@@ -457,21 +457,23 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
   bool refine_grouped = false;
   if constexpr (SMALL_GROUPED) refine_grouped = refine && ncand == 3;
   if constexpr (SMALL_GROUPED) if (refine_grouped) {
-    // 18 (candidate, delta) probes in 16 + 2 rows: waves 0..2 take deltas -1, 1, -2, 2 of candidate W, wave 3 takes the
-    // +-3 probes of candidates 0 and 1, then those of candidate 2
+    // Six probes per DIRECTIONAL candidate among the three, dealt densely to the 16 rows of the workgroup (probe p: pass p / 16, wave (p / 4) % 4, row p % 4): one
+    // pass when at most two candidates are directional, and only wave 0 takes a second one (two rows) when all three are.  (Until round 5 wave 3 always owned
+    // the +-3 probes in two passes of its own: the phase's longest wave at 5.9 % of the kernel against 3.5 % for the others.)
     const int g = GROUP_ID;
-    for (int pass = 0; pass < (W == 3 ? 2 : 1); pass++) {
-      int ci, q;
-      if (W < 3) { ci = W; q = g; } else if (pass == 0) { ci = g >> 1; q = 4 + (g & 1); } else { ci = 2; q = 4 + (g & 1); }
+    const int o0 = SH->order[0], o1 = SH->order[1], o2 = SH->order[2];
+    const bool d0 = o0 >= V_PRED && o0 <= D67_PRED, d1 = o1 >= V_PRED && o1 <= D67_PRED, d2 = o2 >= V_PRED && o2 <= D67_PRED;
+    const int nprobe = 6 * ((int)d0 + (int)d1 + (int)d2);
+    for (int pass = 0; pass * 16 + W * 4 < nprobe; pass++) {   // wave-uniform
+      const int pr = pass * 16 + W * 4 + g;
+      const bool live = pr < nprobe;
+      const int kd = live ? pr / 6 : 0, q = live ? pr - kd * 6 : 0;
+      const int ci = d0 ? (kd == 0 ? 0 : (d1 ? (kd == 1 ? 1 : 2) : 2)) : (d1 ? (kd == 0 ? 1 : 2) : 2);     // the kd-th directional candidate
       const int m = SH->order[ci];
-      const bool live = m >= V_PRED && m <= D67_PRED && !(W == 3 && pass == 1 && g >= 2);
-      const int m1 = SH->order[W < 3 ? W : (pass == 0 ? 0 : 2)], m2 = SH->order[W == 3 && pass == 0 ? 1 : (W < 3 ? W : 2)];
-      if ((m1 >= V_PRED && m1 <= D67_PRED) || (m2 >= V_PRED && m2 <= D67_PRED)) {          // wave-uniform: anything to do in this pass?
-        LDS GroupPredBuf *gp = &S->gpred[g];
-        predict_dir_group<n>(f, x, y, availL, availU, live ? mode_angle_of(m) + 3 * dl_of(q) : 90, ftype_y, ra, rl, gp);
-        const int sd = satd_group<n>(SH->srcb[0], gp->pred);
-        if (live && GROUP_LANE == 0) SH->dsd[ci][q] = (long long)sd;
-      }
+      LDS GroupPredBuf *gp = &S->gpred[g];
+      predict_dir_group<n>(f, x, y, availL, availU, live ? mode_angle_of(m) + 3 * dl_of(q) : 90, ftype_y, ra, rl, gp);
+      const int sd = satd_group<n>(SH->srcb[0], gp->pred);
+      if (live && GROUP_LANE == 0) SH->dsd[ci][q] = (long long)sd;
     }
     PH(5);
     WG_SYNC();
