@@ -85,6 +85,22 @@ def test_cli_matches_library_and_reports_like_the_reference(tmp_path):
     assert (tmp_path / 'one.avif').read_bytes() == want.avif_file
 
 
+def test_cli_files_are_complete_when_the_command_returns_in_both_exit_modes(tmp_path):
+    """Default: the work runs in a child that reports through a pipe once every file is written (the device teardown is off the caller's clock);
+    CAVIF_MI_FOREGROUND_EXIT=1: one process.  Same bytes, same report, every file complete at return."""
+    import os
+    files = []
+    for i in range(5):
+        Image.fromarray(rgba_gradient(64 + 8 * i, 48), 'RGBA').save(tmp_path / ('f%d.png' % i)); files.append(str(tmp_path / ('f%d.png' % i)))
+    outs = []
+    for env in ({}, {'CAVIF_MI_FOREGROUND_EXIT': '1'}):
+        r = subprocess.run([CLI, '-f'] + files, capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs.append(([(tmp_path / ('f%d.avif' % i)).read_bytes() for i in range(5)], sorted(r.stdout.splitlines())))   # read at once: nothing is still being written
+        for i in range(5): (tmp_path / ('f%d.avif' % i)).unlink()
+    assert outs[0] == outs[1] and all(len(b) > 100 for b in outs[0][0])
+
+
 def test_cli_output_directory_stdio_and_dirty_alpha(tmp_path):
     rgba = rgba_gradient(64, 48)
     Image.fromarray(rgba, 'RGBA').save(tmp_path / 'g.png')
