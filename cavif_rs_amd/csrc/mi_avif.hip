@@ -378,29 +378,31 @@ static int search_enqueue(SearchQueue &q, const std::vector<FramePlan> &frames, 
   const int mode = search_mode(frames);
   for (int cls = 2; cls <= 4; cls++) {
     q.q_begin[cls] = (int)q.items.size();
+    // Synchronisation grain and list order.  Blocks up to 16x16 (classes below 4): per root block (tile_search.h root_wait / root_publish), where a superblock can start
+    // ~0.75 of a superblock time after its left neighbour and ~1.125 after the one above; the list is ordered by 3 * row + 2 * column -- any a * row + b * column
+    // with a > b > 0 lists a superblock after its left and its above-right neighbour, and 1.5 columns per row is the closest of the small ratios to what the roots
+    // allow.  Until round 5 a full batch used whole-superblock flags and 2 * row + column: K1 106.6 -> 103.0 ms on 32 x 1080p, 121.1 -> 110.6 ms with 16 tiles per
+    // image, where the longest tile's chain and not the device's throughput bounds the launch (profiles/r05zr_k1_sync_grain_and_order.txt).  64x64 superblocks
+    // are their own roots: whole-superblock flags, two columns per row.
+    bool fine = cls < 4;
+    int key_a = fine ? 3 : 2, key_b = fine ? 2 : 1;
+#ifdef MI_TUNING_KNOBS
+    if (const char *v = getenv("MI_K1_FINE")) fine = cls < 4 && atoi(v) != 0;
+    if (const char *v = getenv("MI_K1_KEY")) { int a = 0, b = 0; if (sscanf(v, "%d,%d", &a, &b) == 2 && a > b && b > 0 && a < 64) { key_a = a; key_b = b; } }
+#endif
     std::vector<std::vector<SbItem>> by_key;
     for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
       const TileJob &tj = jobs[j]; const FramePlan &p = frames[tj.frame];
       const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
       const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
-      if ((int)by_key.size() < 2 * rows + cols) by_key.resize(2 * rows + cols);
-      for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) by_key[2 * r + c].push_back(SbItem{ (uint32_t)(j - class_begin[cls]), (uint16_t)r, (uint16_t)c });
+      if ((int)by_key.size() < key_a * rows + key_b * cols) by_key.resize(key_a * rows + key_b * cols);
+      for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) by_key[key_a * r + key_b * c].push_back(SbItem{ (uint32_t)(j - class_begin[cls]), (uint16_t)r, (uint16_t)c });
     }
     for (auto &v : by_key) q.items.insert(q.items.end(), v.begin(), v.end());
     const int nitems = (int)q.items.size() - q.q_begin[cls];
     int grid = 0;
     HIP_OK(launch_search(cls, (mode & 1) != 0, mode >> 1, nullptr, nullptr, nullptr, nitems, nullptr, nullptr, &grid, device, s));
-    // How many superblocks can be at work at once under whole-superblock dependencies (a tile's wavefront is min(rows, cols / 2) wide): when that
-    // leaves resident workgroups idle the launch synchronises per root block instead (tile_search.h root_wait); a full batch keeps the cheaper
-    // one-acquire-one-release-per-superblock protocol.
-    long runnable = 0;
-    for (int j = class_begin[cls]; j < class_begin[cls + 1]; j++) {
-      const TileJob &tj = jobs[j]; const FramePlan &p = frames[tj.frame];
-      const int rows = std::min(p.tiles.row_start[tj.tile_row + 1], p.sb_rows) - p.tiles.row_start[tj.tile_row];
-      const int cols = std::min(p.tiles.col_start[tj.tile_col + 1], p.sb_cols) - p.tiles.col_start[tj.tile_col];
-      runnable += std::min(rows, (cols + 1) / 2);
-    }
-    if (cls < 4 && runnable < grid) for (int i = q.q_begin[cls]; i < (int)q.items.size(); i++) q.items[i].job |= 0x80000000u;
+    if (fine) for (int i = q.q_begin[cls]; i < (int)q.items.size(); i++) q.items[i].job |= 0x80000000u;
     snap_need = std::max(snap_need, (size_t)grid * k1_snap_bytes(cls));
   }
   q.q_begin[5] = (int)q.items.size();

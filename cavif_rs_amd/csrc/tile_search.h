@@ -1501,6 +1501,9 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // belongs to its own superblock or to one earlier in the work list, so the no-deadlock argument of the list order holds unchanged; the decoded
 // flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
 // superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
+#ifndef MI_K1_ROOT_SKIP
+#define MI_K1_ROOT_SKIP 1
+#endif
 // The acquire after a dependency wait: ONE wavefront invalidates (an agent-scope acquire is `buffer_inv sc1`: the compute unit's vector cache and this XCD's L2 lose their
 // lines, for everybody), the workgroup barrier hands the ordering on to the other three -- four invalidations per wait cost ~1 % of the launch (profiles/r05zn_ab_k1_acquire.txt;
 // the same file: with every L2 writeback / invalidation of the launch removed, which breaks the results across XCDs, the launch is no faster than this).
@@ -1509,6 +1512,9 @@ __device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) |
 template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f(); const LDS TileB *t = k.t();
+  // a root below the superblock's first row and right of its first column reads its own superblock only (left, above, above-left, above-right are inside it, the
+  // below-left one is inside it or later in coding order): nothing to wait for, nothing to invalidate -- 9 of the 16 roots of a 64x64 superblock
+  if (MI_K1_ROOT_SKIP && ((r >> MAXBS) & (G - 1)) != 0 && ((c >> MAXBS) & (G - 1)) != 0) return;
   if (threadIdx.x == 0) {
     const int *mask = f->sb_prog + f->sb_rows * f->tile_cols;
     const int gr = r >> MAXBS, gc = c >> MAXBS, zc = root_z(gr & (G - 1), gc & (G - 1)), sr = r >> 4, sc = c >> 4;
@@ -1516,6 +1522,7 @@ template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(
       const int rr = (gr + dr) << MAXBS, cc = (gc + dc) << MAXBS;
       if (rr < t->mi_row_start || rr >= t->mi_row_end || cc < t->mi_col_start || cc >= t->mi_col_end) return;
       const int sr2 = rr >> 4, sc2 = cc >> 4, z2 = root_z((gr + dr) & (G - 1), (gc + dc) & (G - 1));
+      if (MI_K1_ROOT_SKIP && sr2 == sr && sc2 == sc) return;               // a root of this superblock: this workgroup did it (program order), and it may never be published
       if (only_if_earlier && !(sr2 < sr || (sr2 == sr && (sc2 < sc || (sc2 == sc && z2 < zc))))) return;
       const int *w = mask + sr2 * f->sb_cols + sc2;
       // Bounded (~2^25 polls are tens of seconds: a protocol error, a preempted or shared device must not hang the GPU), and a wait that gives up marks the frame:
@@ -1533,6 +1540,9 @@ template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(
 template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_publish(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
   const LDS FrameDev *f = k.f();
+  // only the last row and the last column of a superblock's roots are read from outside it (by the superblocks right, below, below-left of it): the other 9 of 16
+  // are never polled, and their data is covered by the release of the next root that is
+  if (MI_K1_ROOT_SKIP && ((r >> MAXBS) & (G - 1)) != G - 1 && ((c >> MAXBS) & (G - 1)) != G - 1) return;
   WG_SYNC();                                                               // every wave's stores of this root are issued
   if (threadIdx.x == 0) {
     int *w = f->sb_prog + f->sb_rows * f->tile_cols + (r >> 4) * f->sb_cols + (c >> 4);
