@@ -1501,6 +1501,9 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // belongs to its own superblock or to one earlier in the work list, so the no-deadlock argument of the list order holds unchanged; the decoded
 // flags stay exact because a later neighbour of a block always waits for it.  Steady state for 16x16 roots: a superblock starts 0.75 of a
 // superblock time after its left neighbour and 1.125 after the one above, against 1 and 2 (profiles/r03m_*).
+// Since round 5 every launch of the 16x16 class runs this way (mi_avif.hip search_enqueue: list order 3 * row + 2 * column), and only the roots that other superblocks
+// read take part: a root waits only if it lies in its superblock's first row or column (the others read nothing outside it), publishes only if it lies in the last row or
+// column (nothing else is ever polled), and a waiting root polls foreign superblocks' bits only -- 7 waits and 7 publishes per 16 roots (MI_K1_ROOT_SKIP=0: all 16).
 #ifndef MI_K1_ROOT_SKIP
 #define MI_K1_ROOT_SKIP 1
 #endif
