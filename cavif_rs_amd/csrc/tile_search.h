@@ -1531,8 +1531,12 @@ template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(
       // Bounded (~2^25 polls are tens of seconds: a protocol error, a preempted or shared device must not hang the GPU), and a wait that gives up marks the frame:
       // the entropy stage then reports every tile of it as failed (tile_len = 0xFFFFFFFF) and the host returns MI_ENCODING_ERROR instead of a stream whose
       // reconstruction the search did not see.
+      // (once any wait of the frame has given up, the others leave at their next check instead of each running to its own bound: a broken launch ends in about one bound)
       unsigned spin = 0;
-      while (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; }
+      while (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25)) {
+        __builtin_amdgcn_s_sleep(16); spin++;
+        if ((spin & 4095u) == 0u && __hip_atomic_load(search_error_word(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) spin = 1u << 25;
+      }
       if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(f), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     need(0, -1, false); need(-1, 0, false); need(-1, -1, false); need(-1, 1, true); need(1, -1, true);
@@ -1805,8 +1809,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
       // every tile of it and the host returns MI_ENCODING_ERROR -- a protocol error or a preempted device must not hang the GPU in the default (coarse) mode either.
       if (threadIdx.x == 0) {
         unsigned spin = 0;
-        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; }
-        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; } }
+        auto gave_up = [&]() { return (spin & 4095u) == 0u && __hip_atomic_load(search_error_word(gf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; };   // another wait of the frame did
+        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = 1u << 25; }
+        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = 1u << 25; } }
         if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(gf), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       WG_SYNC();
