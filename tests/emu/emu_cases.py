@@ -15,6 +15,17 @@ assert 'emu' in _enc.library_path(), _enc.library_path()
 which = sys.argv[2] if len(sys.argv) > 2 else 'quick'
 oracle.build(); oracle.lib()
 
+if which == 'giveup':                              # with MI_EMU_DROP_PUBLISH=1: no root is ever published -> the waits give up -> the encode fails loudly, in bounded time
+    w, h, bd = 136, 136, 8
+    pl = planes(h, w, seed=w + h, bd=bd, mono=False)
+    t = time.time()
+    try:
+        m.encode_planes(pl, bd, 121, 10, False)
+        outcome = 'returned a stream'
+    except m.AvifError as e:
+        outcome = 'AvifError: %s' % e
+    print(json.dumps({'case': 'giveup', 'ok': outcome.startswith('AvifError'), 'outcome': outcome, 's': round(time.time() - t, 1)}), flush=True)
+    sys.exit(0)
 PLANE_CASES = {
     'quick': [(64, 64, 8, 4, 121, False, 0), (72, 40, 10, 4, 121, False, 2), (48, 40, 10, 1, 121, False, 0), (64, 48, 8, 10, 121, False, 0), (96, 64, 10, 4, 66, True, 0),
               (136, 136, 8, 4, 121, False, 0)],      # 3 x 3 superblocks in one tile: the work queue's waits on the left neighbour and the row above

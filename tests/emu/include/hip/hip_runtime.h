@@ -75,7 +75,11 @@ template <typename T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(
 #define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
 #define __hip_atomic_store(ptr, v, order, scope) __atomic_store_n((ptr), (v), (order))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) __atomic_fetch_add((ptr), (v), (order))
-#define __hip_atomic_fetch_or(ptr, v, order, scope) __atomic_fetch_or((ptr), (v), (order))
+// MI_EMU_DROP_PUBLISH=1 (tests/test_emu_kernels.py): the tile search's root bits are never published, so every dependency wait runs into its poll bound -- the
+// failure path (sticky error word -> every tile of the frame fails -> MI_ENCODING_ERROR) without touching the product code
+inline bool emu_drop_publish() { static const bool on = getenv("MI_EMU_DROP_PUBLISH") != nullptr; return on; }
+template <typename T> inline T emu_fetch_or(T *p, T v, int order) { return emu_drop_publish() ? __atomic_load_n(p, order == __ATOMIC_RELEASE ? __ATOMIC_ACQUIRE : order) : __atomic_fetch_or(p, v, order); }
+#define __hip_atomic_fetch_or(ptr, v, order, scope) emu_fetch_or((ptr), (__typeof__(*(ptr)))(v), (order))
 // wave ballot from the cross-lane shuffle the emulator has (butterfly OR of the lanes' own bits)
 inline unsigned long long emu_ballot64(bool p) {
   const int l = (int)(threadIdx.x & 63);

@@ -62,6 +62,15 @@ def test_emulated_batch_api_equals_oracle(emu_env):
     assert len(rows) == 6 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
 
 
+def test_a_dependency_wait_that_never_ends_fails_the_encode_in_bounded_time(emu_env):
+    """tile_search.h root_wait: bounded polls.  The emulator drops every root publish (MI_EMU_DROP_PUBLISH): the first wait of the frame runs into its bound and sets
+    the frame's sticky error word, the other waits leave at their next check, the entropy stage fails every tile, the host returns MI_ENCODING_ERROR -- no hang,
+    no stream whose reconstruction the search did not see."""
+    p, rows = _run(emu_env, 'giveup', 900, MI_EMU_DROP_PUBLISH='1')
+    assert len(rows) == 1 and rows[0]['ok'] and p.returncode == 0, (rows, p.stderr[-2000:])
+    assert 'ncod' in rows[0]['outcome'] or 'rror' in rows[0]['outcome'], rows
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m
