@@ -24,7 +24,7 @@
 // MI_K1_GRID_PER_CU=n (fewer persistent search workgroups per CU) and, with -DMI_DEBUG_HOOKS=1, MI_DEBUG_LEVEL (bisect levels of the tile search).
 // the streaming form's rotation: resident batch objects per image shape, and the first run's share of a full run
 #ifndef MI_STREAM_SLOTS_DEFAULT
-#define MI_STREAM_SLOTS_DEFAULT 3
+#define MI_STREAM_SLOTS_DEFAULT 2          /* 256 x 1080p files end to end: 1.32 s with two, 1.48 with three, 1.51 with four (profiles/r05zk_e2e_knobs.txt, matrix 5) */
 #endif
 #define MI_STREAM_FIRST_RUN_NUM 1
 #define MI_STREAM_FIRST_RUN_DEN 2
@@ -924,7 +924,7 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
   const bool timing = mi_timing_enabled();
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3; };
-  // Per device: up to three resident batch objects (from the pool) per image shape.  While one batch encodes, the host fills the next one's
+  // Per device: two resident batch objects (from the pool) per image shape (MI_STREAM_SLOTS_DEFAULT).  While one batch encodes, the host fills the next one's
   // pinned staging and enqueues its H2D + encode, so uploads, tile search, entropy coding and the host-side assembly of consecutive runs overlap
   // (the same rotation bench.py drives).  Memory is bounded: a batch object holds as many images of its shape as fit MI_SLOT_BYTES (one 12 MP RGBA
   // image needs ~1.5 GB: such a shape gets runs of a few images, not 32), and before a new object is made the worker gives back the objects of the
