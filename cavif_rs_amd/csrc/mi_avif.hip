@@ -26,8 +26,8 @@
 #ifndef MI_STREAM_SLOTS_DEFAULT
 #define MI_STREAM_SLOTS_DEFAULT 2          /* 256 x 1080p files end to end: 1.32 s with two, 1.48 with three, 1.51 with four (profiles/r05zk_e2e_knobs.txt, matrix 5) */
 #endif
-#define MI_STREAM_FIRST_RUN_NUM 1
-#define MI_STREAM_FIRST_RUN_DEN 2
+#define MI_STREAM_FIRST_RUN_NUM 1         /* a worker's first run as a share of a full one: a whole run (a half run started the GPU ~0.03 s earlier and cost two runs of 16 images, */
+#define MI_STREAM_FIRST_RUN_DEN 1         /* 0.09 s of tile search each against 0.10 for 32: worker phase 1.24 -> 1.20 s on 256 files, profiles/r05zk_e2e_knobs.txt matrix 6) */
 static inline bool mi_timing_enabled() {
 #ifdef MI_TUNING_KNOBS
   static const bool on = getenv("MI_AVIF_TIMING") != nullptr; return on;
@@ -1021,7 +1021,7 @@ int mi_ravif_encode_stream(const mi_ravif_encoder *e, size_t n, mi_fetch_fn fetc
     };
     size_t claims = 0;
     for (;;) {
-      // the first claim is half a run: it starts encoding while the caller's loaders are still producing the next (shorter runs leave the GPU part empty)
+      // every claim is a full run, the first one included (MI_STREAM_FIRST_RUN_NUM / _DEN)
       size_t first_run = std::max<size_t>(1, max_run * MI_STREAM_FIRST_RUN_NUM / MI_STREAM_FIRST_RUN_DEN);
 #ifdef MI_TUNING_KNOBS
       if (const char *v = getenv("MI_STREAM_FIRST_RUN")) first_run = std::min(max_run, (size_t)std::max(1, atoi(v)));
