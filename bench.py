@@ -173,41 +173,48 @@ def check_identity(batches, image_index, B, cfg, manifest=None):
     return r
 
 
-def _oracle_worker(job):
-    idx, w, h, speed, quality, depth = job
+def _oracle_worker(jobs):
+    """One worker process: its images first (the generator is numpy, not the encoder under test), then the encodes back to back; returns the wall-clock stamps."""
     sys.path.insert(0, ROOT)
     from cavif_rs_amd.synth import synth_image
     from tests.helpers import oracle
-    img = synth_image(w, h, index=idx)
-    t = time.time()
-    data, cs, _ = oracle.ravif_encode(img, quality=quality, speed=speed, depth=depth)
-    return time.time() - t, len(data)
+    oracle.lib()
+    imgs = [synth_image(w, h, index=idx) for idx, w, h, _, _, _ in jobs]
+    t0 = time.time(); n = 0
+    for img, (idx, w, h, speed, quality, depth) in zip(imgs, jobs):
+        data, cs, _ = oracle.ravif_encode(img, quality=quality, speed=speed, depth=depth)
+        n += len(data)
+    return t0, time.time(), n, len(jobs)
 
 
-def _aom_worker(job):
-    idx, w, h, speed, quality, depth = job
+def _aom_worker(jobs):
     import io
     sys.path.insert(0, ROOT)
     from PIL import Image
     from cavif_rs_amd.synth import synth_image
-    im = Image.fromarray(synth_image(w, h, index=idx), 'RGB')
-    t = time.time()
-    buf = io.BytesIO()
-    im.save(buf, format='AVIF', quality=int(quality), speed=speed, codec='aom', subsampling='4:4:4', max_threads=1)
-    return time.time() - t, buf.tell()
+    ims = [Image.fromarray(synth_image(w, h, index=idx), 'RGB') for idx, w, h, _, _, _ in jobs]
+    t0 = time.time(); n = 0
+    for im, (idx, w, h, speed, quality, depth) in zip(ims, jobs):
+        buf = io.BytesIO()
+        im.save(buf, format='AVIF', quality=int(quality), speed=speed, codec='aom', subsampling='4:4:4', max_threads=1)
+        n += buf.tell()
+    return t0, time.time(), n, len(jobs)
 
 
-def _pool_baseline(worker, w, h, speed, quality, depth, n_images, kind, what):
+def _pool_baseline(worker, w, h, speed, quality, depth, per_worker, kind, what):
+    """Image-parallel over ALL of the host's logical cores (what the reference's files.into_par_iter() does, src/main.rs:223): one worker process per core,
+    `per_worker` images each.  The clock runs from the first worker's first encode to the last worker's last (process start, imports and the synthetic image
+    generator are outside it)."""
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    jobs = [(i, w, h, speed, quality, depth) for i in range(n_images if n_images else cores)]
-    t = time.time()
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    chunks = [[(k * per_worker + i, w, h, speed, quality, depth) for i in range(per_worker)] for k in range(cores)]
     with mp.get_context('spawn').Pool(cores) as pool:
-        res = pool.map(worker, jobs)
-    wall = time.time() - t
-    return {"value": round(len(jobs) * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": kind,
-            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, %s, one process per image, %.1f s wall (%.1f s mean per image, %.0f bytes mean)"
-                      % (len(jobs), w, h, speed, quality, depth, what, wall, sum(r[0] for r in res) / len(res), sum(r[1] for r in res) / len(res))}
+        res = pool.map(worker, chunks, chunksize=1)
+    wall = max(r[1] for r in res) - min(r[0] for r in res)
+    n = sum(r[3] for r in res)
+    return {"value": round(n * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": kind,
+            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, %s, one process per logical core x %d images each, %.1f s from the first encode's start to the last one's end (%.1f s mean per image, %.0f bytes mean)"
+                      % (n, w, h, speed, quality, depth, what, per_worker, wall, sum(r[1] - r[0] for r in res) / n, sum(r[2] for r in res) / n)}
 
 
 def cpu_baseline(w, h, speed, quality, depth):
@@ -217,7 +224,7 @@ def cpu_baseline(w, h, speed, quality, depth):
         oracle.lib()
     except Exception as e:      # oracle not built: report nothing rather than a fake number
         return {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": "oracle unavailable: %s" % e}
-    return _pool_baseline(_oracle_worker, w, h, speed, quality, depth, 0, "port", "oracle/ scalar C restatement of THIS encoder (not rav1e)")
+    return _pool_baseline(_oracle_worker, w, h, speed, quality, depth, 2, "port", "oracle/ scalar C restatement of THIS encoder (not rav1e)")
 
 
 def cpu_standin(w, h, speed, quality, depth):
@@ -227,7 +234,7 @@ def cpu_standin(w, h, speed, quality, depth):
         import PIL._avif as _avif
         if not _avif.encoder_codec_available('aom'):
             raise RuntimeError('Pillow has no aom encoder')
-        r = _pool_baseline(_aom_worker, w, h, speed, quality, 8, 0, "stand-in", "libaom via Pillow (8-bit 4:4:4, single-threaded per image; NOT the reference)")
+        r = _pool_baseline(_aom_worker, w, h, speed, quality, 8, 2, "stand-in", "libaom via Pillow (8-bit 4:4:4, single-threaded per image; NOT the reference)")
         r["note"] = "a different encoder (libaom, not rav1e) at its own speed %d; comparable settings, not comparable output" % speed
         return r
     except Exception as e:
@@ -309,23 +316,23 @@ def end_to_end(n_files, w, h, speed, quality, depth, encode_only_s=None):
         files = sorted(os.path.join(d, 'in', f) for f in os.listdir(os.path.join(d, 'in')))
         cmd = [cli, '-s', str(speed), '-Q', '%g' % quality, '--depth', str(depth), '-f', '-q', '-o', os.path.join(d, 'out')] + files
         runs = []
-        # the command as a user runs it, then with the device teardown inside the measured process (CAVIF_MI_FOREGROUND_EXIT: by default the work runs in a
-        # child that reports through a pipe once every file is written; the kernel's unpin / free / queue teardown of that child is off the caller's clock)
-        for env in ({}, {'CAVIF_MI_FOREGROUND_EXIT': '1'}):
-            if env: time.sleep(1.0)                              # the first run's worker is still being torn down
+        # the command as a user runs it (one process: the device teardown is inside the measured time), then with the opt-in exit hand-off (CAVIF_MI_BACKGROUND_EXIT=1:
+        # the work runs in a child that reports through a pipe once every file is written; the kernel's unpin / free / queue teardown of that child is off the caller's clock)
+        for env in ({}, {'CAVIF_MI_BACKGROUND_EXIT': '1'}):
             t = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, CAVIF_MI_TIMING='1', **env))
             dt = time.perf_counter() - t
             runs.append((dt, r, len(os.listdir(os.path.join(d, 'out')))))
             for f in os.listdir(os.path.join(d, 'out')): os.unlink(os.path.join(d, 'out', f))
-    (dt, r, n_out), (dt_fg, r_fg, n_fg) = runs
-    out = {"files": n_files, "ok": r.returncode == 0 and n_out == n_files and r_fg.returncode == 0 and n_fg == n_files,
+    (dt, r, n_out), (dt_bg, r_bg, n_bg) = runs
+    out = {"files": n_files, "ok": r.returncode == 0 and n_out == n_files and r_bg.returncode == 0 and n_bg == n_files,
            "phases": [l for l in r.stderr.decode().splitlines() if l.startswith('[timing]') and 'unix time' not in l], "seconds": round(dt, 3), "MPix_per_s": round(n_files * w * h / 1e6 / dt, 2),
-           "seconds_foreground_exit": round(dt_fg, 3), "phases_foreground_exit": [l for l in r_fg.stderr.decode().splitlines() if l.startswith('[timing]') and 'unix time' not in l],
-           "what": "cavif_mi -s%d -Q%g --depth %d -o out/ in/*.png: PNG decode on the host cores + RGBA8 upload + encode + file writes, process start included; the clock stops when the command returns "
-                   "(every file complete on disk; the device teardown of the worker process goes on unattended). seconds_foreground_exit: the same with the teardown inside the measured process" % (speed, quality, depth)}
+           "seconds_background_exit": round(dt_bg, 3), "phases_background_exit": [l for l in r_bg.stderr.decode().splitlines() if l.startswith('[timing]') and 'unix time' not in l],
+           "what": "cavif_mi -s%d -Q%g --depth %d -o out/ in/*.png (no -j: the tile target is bounded by this host's logical cores, like the reference's `threads: None`): PNG decode on the host cores + "
+                   "RGBA8 upload + encode + file writes, process start AND device teardown included; the clock stops when the command returns. seconds_background_exit: the opt-in "
+                   "CAVIF_MI_BACKGROUND_EXIT=1 mode, in which the command returns when every file is complete on disk and the worker's device teardown goes on unattended" % (speed, quality, depth)}
     if encode_only_s:
-        out["encode_only_seconds"] = round(encode_only_s, 3); out["vs_encode_only"] = round(dt / encode_only_s, 3); out["vs_encode_only_foreground_exit"] = round(dt_fg / encode_only_s, 3)
+        out["encode_only_seconds"] = round(encode_only_s, 3); out["vs_encode_only"] = round(dt / encode_only_s, 3); out["vs_encode_only_background_exit"] = round(dt_bg / encode_only_s, 3)
     return out
 
 
@@ -348,7 +355,7 @@ def main():
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
     ap.add_argument('--threads', type=int, default=0, help='ravif with_num_threads / cavif -j: T bounds the tile target (av1encoder.rs:665-668); 0 = unspecified (None): uncapped on a GPU')
     ap.add_argument('--no-threads-line', action='store_true', help='skip the secondary line at T = host cores (what `cavif -j0` would ask for on this box)')
-    ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search; 4 measured best on MI355X: profiles/r04y_slots_probe.txt)')
+    ap.add_argument('--pipeline', type=int, default=2, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the other searches); 2 = what the product stream path keeps per image shape (MI_STREAM_SLOTS_DEFAULT, mi_avif.hip); since round 5 one, two and four slots measure the same (profiles/r05y_slots_sweep.txt)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -507,6 +514,8 @@ def main():
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
                                                                              "quality": args.quality, "bit_depth": args.depth}),
                          "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, the partition walker's area snapshots, partial-line coefficient writes and the walker's register spills (profiles/r05_kernel_resources.txt: 464 B of scratch per lane in the kernel body, none worth mentioning in the block searches), served by L2 / Infinity Cache; not what limits the kernel -- see roofline_valu; TCP / TCC request, hit and stall counters of the same run: profiles/r05_final_pmc_summary.json",
+                         "frac_of_step": round(algo / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 8),
+                         "frac_note": "frac = algorithmic bytes / the dominant kernel's launch time; frac_of_step = the same bytes / the driver-timed step (every kernel of the step: the 4 B/px RGB read belongs to the front-end kernel, the 6 B/px plane reads to the tile search)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
                          "launch_ms_note": "HIP events on the batch stream around the launch, one step with nothing else in flight (= rocprofv3 kernel-trace average)",
                          "overlapped_launch_ms": round(k1_overlapped, 3)},

@@ -3,6 +3,7 @@
 //   cavif_mi [-Q n] [-s n] [-j n] [-f] [-o path] [-q] [--dirty-alpha] [--color ycbcr|rgb] [--depth 8|10|auto] IMAGES...
 // Differences, deliberate: PNG input only (the reference also reads JPEG through load_image), `--devices a,b,..`
 // selects HIP devices (default: all), and there is no CPU fallback -- without a GPU every file fails loudly.
+#include <sched.h>
 #include <sys/stat.h>
 #include <cerrno>
 #include <cmath>
@@ -42,6 +43,14 @@ bool read_all(FILE *f, std::vector<uint8_t> &out) {
   while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.insert(out.end(), buf, buf + n);
   return !ferror(f);
 }
+// rayon::current_num_threads() of a default global pool: RAYON_NUM_THREADS when set, else std::thread::available_parallelism() -- the CPUs this process may
+// run on (its affinity mask; cgroup CPU quotas, which Rust also honours, are not looked at here)
+int host_threads() {
+  if (const char *e = getenv("RAYON_NUM_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+  cpu_set_t set; CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return CPU_COUNT(&set);
+  return (int)std::max(1u, std::thread::hardware_concurrency());
+}
 int usage(const char *msg) {
   fprintf(stderr, "error: %s\nusage: cavif_mi [-Q quality 1-100] [-s speed 1-10] [-j threads] [-f|--overwrite] [-o path] [-q] [--dirty-alpha]\n"
                   "                [--color ycbcr|rgb] [--depth 8|10|auto] [--devices 0,1,..] [--rdo-passes 1|2] IMAGES...   (\"-\" = stdin/stdout)\n", msg);
@@ -62,12 +71,15 @@ int main(int argc, char **argv) {
   // The loaders' buffers (file, inflate output, RGBA: ~8 MB each) come from the heap arenas and stay there: as anonymous mappings every one of them is an
   // mmap + page faults + munmap (a TLB shootdown across the loader threads), all under the address-space lock the HIP runtime needs while it starts.
   mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  // Device teardown off the caller's clock: the work runs in a child; once every output is on disk the child reports its status through a pipe, the
-  // parent returns it at once, and the child's exit (the kernel unpins the staging, frees the arenas and destroys the queues: ~0.35 s) goes on unattended.
+  // CAVIF_MI_BACKGROUND_EXIT=1 (opt-in): device teardown off the caller's clock.  The work runs in a child; once every output is on disk the child reports its
+  // status through a pipe, the parent returns it at once, and the child's exit (the kernel unpins the staging, frees the arenas and destroys the queues: ~0.35 s)
+  // goes on unattended.  The GPU stays busy with that teardown for a moment after the command has returned: a caller that chains invocations back to back gains
+  // nothing, and the orphaned child is reaped by PID 1 (a container whose PID 1 does not reap collects zombies).  Default: one process, teardown included.
   int done_fd = -1;
-  if (!getenv("CAVIF_MI_FOREGROUND_EXIT")) {
+  if (getenv("CAVIF_MI_BACKGROUND_EXIT") && !getenv("CAVIF_MI_FOREGROUND_EXIT")) {
     int pfd[2];
     if (pipe(pfd) == 0) {
+      const pid_t parent = getpid();
       const pid_t child = fork();
       if (child > 0) {
         close(pfd[1]);
@@ -77,7 +89,11 @@ int main(int argc, char **argv) {
         int ws = 0; while (waitpid(child, &ws, 0) < 0 && errno == EINTR) {}                     // the child ended without reporting (usage error, crash): its status is ours
         _exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws));
       }
-      if (child == 0) { close(pfd[0]); done_fd = pfd[1]; prctl(PR_SET_PDEATHSIG, SIGKILL); }
+      if (child == 0) {
+        close(pfd[0]); done_fd = pfd[1];
+        prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (getppid() != parent) _exit(1);                                                     // the parent died between fork and prctl: nobody is waiting
+      }
       else { close(pfd[0]); close(pfd[1]); }                                                  // no fork: everything in this process
     }
   }
@@ -148,7 +164,10 @@ int main(int argc, char **argv) {
   enc.quality = quality;
   enc.alpha_quality = std::fmin((quality + 100.f) / 2.f, quality + quality / 4.f + 2.f);                                   // :115
   enc.speed = (uint8_t)speed; enc.depth = (uint8_t)depth; enc.color_model = (uint8_t)color_model; enc.rdo_passes = rdo_passes;
-  enc.alpha_mode = dirty_alpha ? 0 : 1; enc.threads = threads > 0 ? threads : 0;
+  enc.alpha_mode = dirty_alpha ? 0 : 1;
+  // -j absent or 0: the reference resolves `threads: None` to rayon::current_num_threads() = the host's logical cores (ravif/src/av1encoder.rs:665-668), which bounds
+  // the tile target min(T, w*h / min_tile_size^2): the same file on the same host gets the same tiles from `cavif` and from `cavif_mi`
+  enc.threads = threads > 0 ? threads : host_threads();
 
   // load + decide output paths (process(), :169-200); failures are collected per file and reported at the end
   struct Job { std::string in_name, out_path; bool out_stdio = false; uint8_t *rgba = nullptr; uint32_t w = 0, h = 0; std::string error; };

@@ -504,10 +504,18 @@ __device__ inline void predict_nondir_group(int mode, int have_left, int have_ab
   WAVE_SYNC();
 }
 
-// 4x4-Hadamard SATD of one row's prediction (satd_dev with 16 lanes: one lane per column x group of four rows)
+// SATD of one row's prediction (satd_dev with 16 lanes): N == 4: one 4x4 Hadamard (one lane per column); N == 8: the 8x8 Hadamard of the block, four samples per lane
+// (satd8_lane, tile_search.h), on the scale of four 4x4 ones
+__device__ __forceinline__ int satd8_lane(int d0, int d1, int d2, int d3);
 template <int N> __device__ inline int satd_group(const LDS uint16_t *src, const LDS uint16_t *pred) {
   constexpr int units = N * (N / 4);              // 16 for 8x8, 4 for 4x4: whole quads
   const int u = GROUP_LANE;
+  if constexpr (N == 8) {
+    const int xx = (u & 3) + ((u >> 1) & 4), o = (u & 4) * N + xx;
+    const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + N] - (int)pred[o + N];
+    const int d2 = (int)src[o + 2 * N] - (int)pred[o + 2 * N], d3 = (int)src[o + 3 * N] - (int)pred[o + 3 * N];
+    return (row_sum_i32(satd8_lane(d0, d1, d2, d3)) + 2) >> 2;
+  }
   int s = 0;
   if (u < units) {
     const int xx = u % N, o = (u / N) * 4 * N + xx;

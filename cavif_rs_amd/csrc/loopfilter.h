@@ -100,7 +100,7 @@ __device__ __forceinline__ int deblock_queue_lines(const FrameDev *f, int plane,
   for (uint32_t it = 0; it < MI_DBK_CHUNK; it += 256) {
     int r, c, i;
     const int fsz = deblock_edge(f, plane, pass, base + it + threadIdx.x, &r, &c, &i);
-    if (fsz) list[__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint32_t)c | ((uint32_t)(r * 4 + i) << 12) | ((uint32_t)(fsz >> 3) << 28);   // fsz 4 / 8 / 16 -> 0 / 1 / 2
+    if (fsz) list[__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint32_t)c | ((uint32_t)(r * 4 + i) << 14) | ((uint32_t)(fsz >> 3) << 30);   // fsz 4 / 8 / 16 -> 0 / 1 / 2; 14 + 16 + 2 bits: 4x4 columns < 16384 and lines < 65536 = the 65536 x 65536 the entry points accept
   }
   __syncthreads();
   return *cnt;
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void deblock_tally_kernel(const FrameDev *__re
     while (!have && j < nlines) {
       const uint32_t e = list_s[j];
       j += 256;
-      const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3;
-      fsz = 4 << (e >> 28);
+      const int c = (int)(e & 0x3FFF), line = (int)((e >> 14) & 0xFFFF), r = line >> 2, i = line & 3;
+      fsz = 4 << (e >> 30);
       const int half = fsz == 4 ? 2 : (fsz == 8 ? 4 : 8);
       const size_t o = pass == 0 ? (size_t)(r * 4 + i) * f->stride + c * 4 : (size_t)(r * 4) * f->stride + c * 4 + i;
       const uint16_t *rec = f->rec[plane] + o, *src = f->src[plane] + o;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(const FrameDev *__restrict
   const int nlines = deblock_queue_lines(f, plane, pass, (uint32_t)blockIdx.x * MI_DBK_CHUNK, (LDS uint32_t *)list_s, (LDS int *)&cnt_s);
   for (int j = threadIdx.x; j < nlines; j += 256) {
     const uint32_t e = list_s[j];
-    const int c = (int)(e & 0xFFF), line = (int)((e >> 12) & 0xFFFF), r = line >> 2, i = line & 3, fsz = 4 << (e >> 28);
+    const int c = (int)(e & 0x3FFF), line = (int)((e >> 14) & 0xFFFF), r = line >> 2, i = line & 3, fsz = 4 << (e >> 30);
     const int x = c * 4, y = r * 4;
     uint16_t *px = pass == 0 ? f->rec[plane] + (size_t)(y + i) * f->stride + x : f->rec[plane] + (size_t)y * f->stride + x + i;
     filter_edge_sample_dev(px, pass == 0 ? 1 : f->stride, fsz, plane, L, f->lf_sharp, f->bd);

@@ -242,7 +242,11 @@ template <int MAXBS, int NW, bool BU, int TS> static hipError_t launch_search_t(
 #endif
   }
   // MI_K1_ITEMS_PER_WG=n (n > 0): workgroups that leave after n items instead of persistent ones (tile_search.h); only when the list is longer than the device holds
+#ifdef MI_TUNING_KNOBS                                  // probe builds only: the product library reads no environment variable on the encode path
   static const int ipw_env = getenv("MI_K1_ITEMS_PER_WG") ? atoi(getenv("MI_K1_ITEMS_PER_WG")) : MI_K1_ITEMS_PER_WG_DEFAULT;
+#else
+  static const int ipw_env = MI_K1_ITEMS_PER_WG_DEFAULT;
+#endif
   const int ipw = (ipw_env > 0 && nitems > resident[device]) ? ipw_env : 0;
   const int grid = ipw ? (nitems + ipw - 1) / ipw : std::min(nitems, resident[device]);
   if (grid_out) { *grid_out = grid; return hipSuccess; }   // dry run: the caller sizes the snapshot pool
@@ -536,8 +540,15 @@ size_t mi_avif_serialize(const uint8_t *color, size_t color_len, const uint8_t *
   return v.size();
 }
 
+// The filters address samples inside a plane with 32-bit offsets (row * stride + column): a padded plane must stay below 2^31 samples.  That is 60 x the largest picture
+// any AV1 level allows (level 6.x: 35.6 MPix); beyond it the entry points answer MI_INVALID_ARGUMENT instead of filtering the wrong samples.
+static bool mi_plane_too_large(uint32_t w, uint32_t h) {
+  const uint64_t pw = ((uint64_t)w + 63) & ~63ull, ph = ((uint64_t)h + 63) & ~63ull;
+  return (pw + 64) * (ph + 64) >= (1ull << 31);
+}
 mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, uint32_t h, int channels) {
   if (!e || n_images < 1 || w < 1 || h < 1 || w > 65536 || h > 65536 || (channels != 3 && channels != 4) || e->alpha_mode > 2) return nullptr;
+  if (mi_plane_too_large(w, h)) return nullptr;
   if (e->speed < 1 || e->speed > 10 || !(e->quality >= 1.f && e->quality <= 100.f) || !(e->alpha_quality >= 1.f && e->alpha_quality <= 100.f)) return nullptr;
   if (mi_device_count() <= e->device) { fprintf(stderr, "mi_avif: no HIP device %d (the HIP path is mandatory; there is no CPU fallback)\n", e->device); return nullptr; }
   if (hipSetDevice(e->device) != hipSuccess) return nullptr;
@@ -550,10 +561,12 @@ mi_batch *mi_batch_create(const mi_ravif_encoder *e, int n_images, uint32_t w, u
   b->enc.exif = b->exif.empty() ? nullptr : b->exif.data(); b->enc.exif_len = b->exif.size();
   b->alpha_flags.assign(n_images, 0);
   b->pixel_bytes = (size_t)n_images * w * h * channels;
+#ifdef MI_TUNING_KNOBS                                  // probe builds only (profiles/r05r_prio_probe.txt: no gain)
   if (getenv("MI_POSTK1_PRIORITY") && atoi(getenv("MI_POSTK1_PRIORITY")) > 0) {
     int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&b->stream_hi, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&b->ev_hi, hipEventDisableTiming) != hipSuccess) b->stream_hi = nullptr;
   }
+#endif
   bool ok = hipStreamCreate(&b->stream) == hipSuccess && hipMalloc(&b->d_pixels, b->pixel_bytes) == hipSuccess && hipHostMalloc(&b->h_pixels, b->pixel_bytes) == hipSuccess &&
             hipMalloc(&b->d_alpha_flags, sizeof(int) * n_images) == hipSuccess;
   if (ok && channels == 4 && e->alpha_mode == 1)
@@ -820,6 +833,8 @@ void mi_batch_destroy(mi_batch *b) {
   if (b->d_clean_tmp) (void)hipFree(b->d_clean_tmp);
   if (b->d_alpha_acc) (void)hipFree(b->d_alpha_acc);
   for (int i = 0; i < 8; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->ev_hi) (void)hipEventDestroy(b->ev_hi);
+  if (b->stream_hi) (void)hipStreamDestroy(b->stream_hi);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -1075,7 +1090,7 @@ int mi_ravif_encode_rgb(const mi_ravif_encoder *e, const uint8_t *rgb, uint32_t 
 int mi_av1_encode_planes(const mi_av1_config *cfg, const void *const planes[3], const size_t stride_bytes[3], uint8_t **out_obu, size_t *out_len, uint16_t *recon[3]) {
   if (!cfg || !planes || !planes[0] || !stride_bytes || !out_obu || !out_len || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return MI_INVALID_ARGUMENT;
   // rav1e rejects these with InvalidWidth / InvalidHeight (the sequence header carries at most 16 bits per dimension)
-  if (cfg->width < 1 || cfg->height < 1 || cfg->width > 65536 || cfg->height > 65536) return MI_INVALID_ARGUMENT;
+  if (cfg->width < 1 || cfg->height < 1 || cfg->width > 65536 || cfg->height > 65536 || mi_plane_too_large(cfg->width, cfg->height)) return MI_INVALID_ARGUMENT;
   auto pow2_4_64 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
   if (!pow2_4_64(cfg->part_min) || !pow2_4_64(cfg->part_max) || cfg->part_min > cfg->part_max || cfg->chroma > 1) return MI_INVALID_ARGUMENT;
   if (mi_device_count() <= cfg->device) { fprintf(stderr, "mi_avif: no HIP device %d (no CPU fallback)\n", cfg->device); return MI_NO_DEVICE; }

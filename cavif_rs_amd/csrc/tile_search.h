@@ -197,17 +197,54 @@ __device__ __forceinline__ int decoded_before(int cur_r, int cur_c, int shape, i
   return ((morton4_(pr & 15) << 1) | morton4_(pc & 15)) < ((morton4_(cur_r & 15) << 1) | morton4_(cur_c & 15));
 }
 
-// 4x4-Hadamard SATD of (src - pred) over an n x n block; both in LDS with pitch n.
-// One lane per (column, group of 4 rows): the vertical butterflies run in registers, the horizontal ones across the
-// four lanes of a quad with DPP quad_perm -- every lane of the wave works for n >= 16 (the sum of |H D H^T| does not
-// depend on the order of the passes, so the value equals the oracle's row-then-column form exactly).
+// SATD of (src - pred) over an n x n block; both in LDS with pitch n (oracle satd_block_wh): 4x4 Hadamards for a 4x4 block, one 8x8 Hadamard per 8x8 cell for everything
+// larger (rav1e get_satd), each cell's sum brought to the scale of four 4x4 ones ((s + 2) >> 2).
+// 4x4: one lane per (column, group of 4 rows): the vertical butterflies run in registers, the horizontal ones across the four lanes of a quad with DPP quad_perm (the
+// sum of |H D H^T| does not depend on the order of the passes, so the value equals the oracle's row-then-column form exactly).
 template <int CTRL> __device__ __forceinline__ int satd_quad_step(int v, int odd_mask) {
   const int p = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
   return (LANE & odd_mask) ? p - v : v + p;
 }
+// 8x8: an 8x8 cell occupies one 16-lane DPP row, four samples of one column per lane -- lane bits 0, 1 = column & 3, bit 2 = which four rows, bit 3 = column >> 2.  Two of
+// the three vertical stages run in registers; the third (rows r and r + 4: lane ^ 4) and the three horizontal ones (lane ^ 1, ^ 2, ^ 8) run across lanes.  DPP has no
+// "lane ^ 4", so that stage pairs lane i with lane 7 - i (row_half_mirror) and runs FIRST: the upper half then holds its differences in reverse order, the two quad
+// stages transform a reversed vector -- a Walsh-Hadamard transform of an index-complemented input is the same transform up to signs --, and which of (A + B, A - B) lands
+// where does not matter to a sum of magnitudes.  Returns the lane's share of the cell's sum of |H8 D H8^T|.
+__device__ __forceinline__ int satd8_lane(int d0, int d1, int d2, int d3) {
+  const int a = d0 + d1, b = d0 - d1, c = d2 + d3, e = d2 - d3;
+  const int t[4] = { a + c, b + e, a - c, b - e };
+  const int m4 = (LANE & 4) ? -1 : 0, m1 = (LANE & 1) ? -1 : 0, m2 = (LANE & 2) ? -1 : 0, m8 = (LANE & 8) ? -1 : 0;     // (v ^ m) - m = -v where the lane's bit is set
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int v = t[i];
+    v = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false) + ((v ^ m4) - m4);     // row_half_mirror
+    v = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false) + ((v ^ m1) - m1);      // quad_perm [1,0,3,2]
+    v = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false) + ((v ^ m2) - m2);      // quad_perm [2,3,0,1]
+    v = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false) + ((v ^ m8) - m8);     // row_ror 8
+    s += iabs_(v);
+  }
+  return s;                                       // <= 4 * 64 * 1023 per lane; a cell's sum <= 64 * 64 * 1023 < 2^23
+}
+__device__ __forceinline__ int satd_row_sum_(int v) {    // all-reduce over the 16-lane row (row_ror 8, 4, 2, 1)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false); v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
+  return v;
+}
 __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t *pred, int n) {
-  const int units = n * (n >> 2);                 // multiple of 4: quads are either fully active or fully idle
   int total = 0;
+  if (n >= 8) {
+    const int cells = n >> 3, units = n * (n >> 2);         // sixteen lanes per 8x8 cell: whole DPP rows are active or idle
+    for (int u = LANE; u < units; u += 64) {
+      const int cell = u >> 4, x = (cell % cells) * 8 + (u & 3) + ((u >> 1) & 4), y = (cell / cells) * 8 + (u & 4), o = y * n + x;
+      const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + n] - (int)pred[o + n];
+      const int d2 = (int)src[o + 2 * n] - (int)pred[o + 2 * n], d3 = (int)src[o + 3 * n] - (int)pred[o + 3 * n];
+      const int cs = satd_row_sum_(satd8_lane(d0, d1, d2, d3));
+      if ((u & 15) == 0) total += (cs + 2) >> 2;            // <= 64 cells (64x64) * 2^21 fits int
+    }
+    return (long long)wave_sum_i32(total);
+  }
+  const int units = n * (n >> 2);                 // multiple of 4: quads are either fully active or fully idle
   for (int u = LANE; u < units; u += 64) {
     const int x = u % n, o = (u / n) * 4 * n + x;
     const int d0 = (int)src[o] - (int)pred[o], d1 = (int)src[o + n] - (int)pred[o + n];
@@ -221,9 +258,9 @@ __device__ inline long long satd_dev(const LDS uint16_t *src, const LDS uint16_t
       v = satd_quad_step<0x4E>(v, 2);             // quad_perm [2,3,0,1]
       s += iabs_(v);
     }
-    total += s;                                   // <= 16 units per lane (64x64) * 4 * 16 * 1023 fits int
+    total += s;
   }
-  return (long long)wave_sum_i32(total);         // whole-block SATD <= 64*64 * 16 * 1023 < 2^31
+  return (long long)wave_sum_i32(total);
 }
 __device__ inline long long sse_dev(const LDS uint16_t *a, const LDS uint16_t *b, int nn) {
   int s = 0;                                     // per lane <= 64 samples * 1023^2 < 2^27
@@ -1510,7 +1547,19 @@ template <typename SHT> __device__ __forceinline__ long long part_j(const LDS SH
 // The acquire after a dependency wait: ONE wavefront invalidates (an agent-scope acquire is `buffer_inv sc1`: the compute unit's vector cache and this XCD's L2 lose their
 // lines, for everybody), the workgroup barrier hands the ordering on to the other three -- four invalidations per wait cost ~1 % of the launch (profiles/r05zn_ab_k1_acquire.txt;
 // the same file: with every L2 writeback / invalidation of the launch removed, which breaks the results across XCDs, the launch is no faster than this).
+// This leans on the target, not on the HIP / LLVM memory model: on gfx942 / gfx950 in the default (non-tgsplit) mode the four waves of a workgroup share one vector L1,
+// so wave 0's invalidation serves all of them.  Any other target fences on every wave.
+#if defined(__gfx942__) || defined(__gfx950__)
 #define MI_K1_ACQUIRE() do { if (WAVE_ID == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); WG_SYNC(); } while (0)
+#else
+#define MI_K1_ACQUIRE() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); WG_SYNC(); } while (0)
+#endif
+// Bound of the dependency polls (log2): 2^25 polls x s_sleep 16 are tens of seconds -- long enough for any legitimate wait of a product launch.  Experiment builds
+// (tools/build_variant.sh) use 2^20, so that a variant with a broken protocol costs seconds of the GPU lease, not the lease.
+#ifndef MI_K1_POLL_LOG2
+#define MI_K1_POLL_LOG2 25
+#endif
+#define MI_K1_POLL_MAX (1u << MI_K1_POLL_LOG2)
 __device__ __forceinline__ int root_z(int bi, int bj) { return ((bi & 1) << 1) | (bj & 1) | ((bi & 2) << 2) | ((bj & 2) << 1); }   // Morton index in the superblock
 template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(const Ctx<MAXN, NW, TS> k, int r, int c) {
   constexpr int G = 1 << (4 - MAXBS);
@@ -1533,11 +1582,11 @@ template <int MAXBS, int MAXN, int NW, int TS> __device__ inline void root_wait(
       // reconstruction the search did not see.
       // (once any wait of the frame has given up, the others leave at their next check instead of each running to its own bound: a broken launch ends in about one bound)
       unsigned spin = 0;
-      while (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < (1u << 25)) {
+      while (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> z2) & 1) && spin < MI_K1_POLL_MAX) {
         __builtin_amdgcn_s_sleep(16); spin++;
-        if ((spin & 4095u) == 0u && __hip_atomic_load(search_error_word(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) spin = 1u << 25;
+        if ((spin & 4095u) == 0u && __hip_atomic_load(search_error_word(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) spin = MI_K1_POLL_MAX;
       }
-      if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(f), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spin >= MI_K1_POLL_MAX) __hip_atomic_store(search_error_word(f), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     need(0, -1, false); need(-1, 0, false); need(-1, -1, false); need(-1, 1, true); need(1, -1, true);
   }
@@ -1810,9 +1859,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MAXBS == 2 ? MI_K1_WG_PER_CU :
       if (threadIdx.x == 0) {
         unsigned spin = 0;
         auto gave_up = [&]() { return (spin & 4095u) == 0u && __hip_atomic_load(search_error_word(gf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; };   // another wait of the frame did
-        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = 1u << 25; }
-        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spin < (1u << 25)) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = 1u << 25; } }
-        if (spin >= (1u << 25)) __hip_atomic_store(search_error_word(gf), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sbc > 0) while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sbc && spin < MI_K1_POLL_MAX) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = MI_K1_POLL_MAX; }
+        if (sbr > 0) { const int need = imin_(sbc + 2, ncols); while (__hip_atomic_load(prog - gf->tile_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spin < MI_K1_POLL_MAX) { __builtin_amdgcn_s_sleep(16); spin++; if (gave_up()) spin = MI_K1_POLL_MAX; } }
+        if (spin >= MI_K1_POLL_MAX) __hip_atomic_store(search_error_word(gf), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       WG_SYNC();
       MI_K1_ACQUIRE();

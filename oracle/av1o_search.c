@@ -84,11 +84,25 @@ static void fill_map2(uint8_t *m, int ms, int r, int c, int w4, int h4, int v) {
 static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) { fill_map2(m, ms, r, c, n4, n4, v); }
 
 /* Ablation switches (environment, oracle only -- the divergence ledger of BASELINE.md section 5; tools/divergence_ledger.py): each turns ONE deliberate difference from what
- * rav1e does (as recalled) into rav1e's form, so that its effect on bytes / error can be measured.  0 / unset = this encoder's shipped behaviour (what HIP == oracle tests pin).
- *   AV1O_ABL_SATD8=1        SATD of blocks of 8x8 and more with the 8x8 Hadamard (rav1e get_satd) instead of 4x4 Hadamards everywhere
+ * rav1e does (as recalled) into rav1e's form -- or, for a difference that has since been closed, back into this encoder's earlier form --, so that its effect on bytes / error
+ * can be measured.  0 / unset = this encoder's shipped behaviour (what HIP == oracle tests pin).  Read once per process.
+ *   AV1O_ABL_SATD4=1        (round 6: closed) SATD of every block with 4x4 Hadamards, as rounds 1-5 shipped, instead of the 8x8 Hadamard for blocks of 8x8 and more (rav1e get_satd)
  *   AV1O_ABL_SEQ_TXTYPE=1   mode decision with each mode's default transform type, then the transform-type search on the winning mode only (instead of mode x type jointly)
  *   AV1O_ABL_ONE_TXTYPE=1   one transform type for all sub-blocks of a split transform (rav1e rdo_tx_size_type) instead of one per sub-block */
-static int abl_flag(const char *name) { const char *v = getenv(name); return v && v[0] == '1'; }
+enum { ABL_SATD4 = 1, ABL_SEQ_TXTYPE = 2, ABL_ONE_TXTYPE = 4 };
+static int abl_flags(void) {
+  static int cached = -1;                                     /* (a benign race: every thread computes the same value) */
+  if (cached < 0) {
+    int v = 0; const char *e;
+    if ((e = getenv("AV1O_ABL_SATD4")) && e[0] == '1') v |= ABL_SATD4;
+    if ((e = getenv("AV1O_ABL_SEQ_TXTYPE")) && e[0] == '1') v |= ABL_SEQ_TXTYPE;
+    if ((e = getenv("AV1O_ABL_ONE_TXTYPE")) && e[0] == '1') v |= ABL_ONE_TXTYPE;
+    cached = v;
+  }
+  return cached;
+}
+/* SATD of blocks of 8x8 and more: the 8x8 Hadamard per 8x8 cell (rav1e get_satd), its sum brought to the scale of four 4x4 Hadamards.  Three butterfly stages per
+ * direction; the sum of |H D H^T| does not depend on the order of the stages or of the two directions (cavif_rs_amd/csrc: satd_dev / satd_group<8> run them in another). */
 static int64_t satd8_block(const uint16_t *src, int ss, const uint16_t *pred, int ps, int w, int h) {
   int64_t total = 0;
   for (int by = 0; by < h; by += 8) for (int bx = 0; bx < w; bx += 8) {
@@ -105,9 +119,9 @@ static int64_t satd8_block(const uint16_t *src, int ss, const uint16_t *pred, in
   }
   return total;
 }
-/* 4x4 Hadamard SATD summed over the block (rav1e get_satd uses 8x8 for larger blocks) */
+/* SATD of a block: 8x8 Hadamards where both dimensions reach 8 (above), 4x4 Hadamards for the 4x4, 8x4 and 4x8 blocks */
 static int64_t satd_block_wh(const uint16_t *src, int ss, const uint16_t *pred, int ps, int w, int h) {
-  if (w >= 8 && h >= 8 && abl_flag("AV1O_ABL_SATD8")) return satd8_block(src, ss, pred, ps, w, h);
+  if (w >= 8 && h >= 8 && !(abl_flags() & ABL_SATD4)) return satd8_block(src, ss, pred, ps, w, h);
   int64_t total = 0;
   for (int by = 0; by < h; by += 4) for (int bx = 0; bx < w; bx += 4) {
     int d[16], t[16];
@@ -220,7 +234,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   int64_t best_j = INT64_MAX, best_mode_j = 0; int best_mode = DC_PRED, best_delta = 0, best_tx = DCT_DCT; TxRes best_tr = { 0, 0, 0, 0, 0 };
   int tx_ns, tx_set;
   int seq_second = 0;
-  for (int ci = 0; ci < ncand + (abl_flag("AV1O_ABL_SEQ_TXTYPE") ? 1 : 0); ci++) {
+  for (int ci = 0; ci < ncand + ((abl_flags() & ABL_SEQ_TXTYPE) ? 1 : 0); ci++) {
     if (ci == ncand) seq_second = 1;                               /* AV1O_ABL_SEQ_TXTYPE: the extra round = the transform-type search on the winning mode */
     const int m = seq_second ? best_mode : order[ci];
     int delta = 0;
@@ -238,7 +252,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
     uint32_t mode_rate = ycost[m];
     if (directional && big) mode_rate += f->cost[CDF_ANGLE + (m - V_PRED) * CDF_ANGLE_STRIDE + delta + 3];
     const int tx_off = av1o_intra_tx_cdf(f, txs, m, &tx_ns, &tx_set);
-    const int seq_tx = abl_flag("AV1O_ABL_SEQ_TXTYPE");          /* ablation: pass 0 (ci < ncand) prices the mode with its default type; pass 1 (the winner again) tries the others */
+    const int seq_tx = (abl_flags() & ABL_SEQ_TXTYPE);          /* ablation: pass 0 (ci < ncand) prices the mode with its default type; pass 1 (the winner again) tries the others */
     const int ntx = (f->cfg.rdo_tx && tx_off >= 0 && !(seq_tx && !seq_second)) ? tx_ns : 1;
     for (int ti = 0; ti < ntx; ti++) {
       int txtype;
@@ -280,7 +294,7 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
         /* AV1O_ABL_ONE_TXTYPE: the depth is tried once per transform type with every sub-block forced to it; the best type's trial is repeated last so that the frame holds it */
-        const int one_tx = abl_flag("AV1O_ABL_ONE_TXTYPE") && sntx > 1;
+        const int one_tx = (abl_flags() & ABL_ONE_TXTYPE) && sntx > 1;
         int forced = -1, forced_best = 0; int64_t forced_best_j = INT64_MAX;
         const int64_t j_split0 = j_split;
         for (int ft = 0; ft < (one_tx ? sntx + 1 : 1); ft++) {

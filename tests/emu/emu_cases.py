@@ -59,6 +59,39 @@ if which == 'quick':
         ok = obu == r['obu'] and all(np.array_equal(a, b) for a, b in zip(rec, r['recon']))
         ok_all &= ok
         print(json.dumps({'case': 'noise %dx%d bd%d s%d q%d' % (w, h, bd, speed, q), 'ok': bool(ok), 'bytes': len(obu), 's': round(time.time() - t, 2)}), flush=True)
+if which == 'twodev':                              # MI_EMU_DEVICES=2: two DISTINCT emulated devices (own tables, arenas, budgets, compute-unit counts); the emulator aborts when a
+    import ctypes                                  # copy or a kernel argument names the other device's memory
+    from cavif_rs_amd.synth import synth_image
+    assert m.device_count() == 2, m.device_count()
+    L = ctypes.CDLL(_enc.library_path()); L.emu_launch_count.restype = ctypes.c_long
+    ok_all = True
+    shapes = [(72, 40), (40, 56), (64, 64)]
+    imgs = [synth_image(*shapes[k2 % 3], index=k2, alpha=(k2 % 5 == 4)) for k2 in range(10)]
+    e = m.Encoder().with_quality(70).with_speed(8)
+    ref = [oracle.ravif_encode(im, quality=70, alpha_quality=80, speed=8)[0] for im in imgs]
+    t = time.time()
+    before = [L.emu_launch_count(0), L.emu_launch_count(1)]
+    got = [g.avif_file for g in m.encode_many(e, imgs, devices=[0, 1])]
+    used = [L.emu_launch_count(0) - before[0], L.emu_launch_count(1) - before[1]]
+    ok = got == ref and used[0] > 0 and used[1] > 0
+    ok_all &= ok
+    print(json.dumps({'case': 'stream over devices [0, 1], 3 shapes, 10 images', 'ok': bool(ok), 'launches': used, 's': round(time.time() - t, 2)}), flush=True)
+    got = [g.avif_file for g in m.encode_many(e, imgs)]           # devices = None: every visible device
+    ok = got == ref
+    ok_all &= ok
+    print(json.dumps({'case': 'stream over every visible device', 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
+    # a batch object and the single-image entry points on device 1 while device 0's tables exist (and the other way round)
+    for dev in (1, 0):
+        e1 = m.Encoder().with_quality(80).with_speed(4).with_bit_depth(10).with_device(dev)
+        im2 = [synth_image(136, 72, index=30 + i) for i in range(2)]
+        b = m.BatchEncoder(e1, 2, 136, 72, 3)
+        for i, im in enumerate(im2): b.upload(i, im)
+        t = time.time(); b.encode()
+        ok = all(b.get(i).avif_file == oracle.ravif_encode(im, quality=80, speed=4, depth=10)[0] for i, im in enumerate(im2)) and e1.encode_rgb(im2[0]).avif_file == b.get(0).avif_file
+        b.close()
+        ok_all &= ok
+        print(json.dumps({'case': 'batch object + encode_rgb on device %d' % dev, 'ok': bool(ok), 's': round(time.time() - t, 2)}), flush=True)
+    sys.exit(0 if ok_all else 1)
 if which == 'blk64':                               # the 64x64 level (dev_blk64.h): smooth pictures on which 64x64 blocks win, bottom-up (speed 1) and top-down, 4:4:4 and 4:0:0
     from tests.test_oracle_dav1d import smooth_planes
     ok_all = True

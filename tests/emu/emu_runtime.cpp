@@ -31,7 +31,40 @@ void *emu_alloc(size_t n) {
   *(size_t *)p = total;
   return (uint8_t *)p + 64;
 }
-void emu_free(void *p) { if (p) { void *b = (uint8_t *)p - 64; munmap(b, *(size_t *)b); } }
+// ---- several emulated devices (MI_EMU_DEVICES): which device an allocation belongs to, checked wherever the host names device memory ----
+#include <map>
+#include <mutex>
+static std::mutex g_reg_mu;
+static std::map<uintptr_t, std::pair<size_t, int>> g_reg;          // base -> (bytes, device)
+static std::atomic<long> g_launches[64];
+namespace emu {
+int device_count() { static const int n = [] { const char *e = getenv("MI_EMU_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }(); return n; }
+int &cur_dev() { static thread_local int d = 0; return d; }
+void note_launch() { g_launches[cur_dev()]++; }
+void check_dev_ptr(const void *p, const char *what) {
+  if (!p || device_count() == 1) return;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = g_reg.upper_bound((uintptr_t)p);
+  if (it == g_reg.begin()) return;
+  --it;
+  if ((uintptr_t)p >= it->first + it->second.first) return;       // host memory
+  if (it->second.second != cur_dev()) {
+    fprintf(stderr, "emu: %s names memory of device %d while the thread's current device is %d\n", what, it->second.second, cur_dev());
+    abort();
+  }
+}
+}
+extern "C" long emu_launch_count(int dev) { return dev >= 0 && dev < 64 ? g_launches[dev].load() : -1; }
+void *emu_alloc_dev(size_t n) {
+  void *p = emu_alloc(n);
+  if (p) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg[(uintptr_t)p] = { n ? n : 1, emu::cur_dev() }; }
+  return p;
+}
+void emu_free(void *p) {
+  if (!p) return;
+  { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase((uintptr_t)p); }
+  void *b = (uint8_t *)p - 64; munmap(b, *(size_t *)b);
+}
 double emu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" void emu_switch(void **save_sp, void *load_sp);

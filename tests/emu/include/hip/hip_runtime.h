@@ -120,25 +120,31 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDe
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
+// MI_EMU_DEVICES=n (default 1): n emulated devices.  hipSetDevice is per host thread, every hipMalloc belongs to the thread's current device, and a copy, a memset or a
+// kernel argument that names another device's memory aborts the process (emu::check_dev_ptr): per-device tables, arenas and budgets of the multi-device fan-out are
+// exercised for real.  The devices differ: device d reports 3 - (d & 1) compute units and 192 - 64 * (d & 1) MB of free memory.
+namespace emu { int device_count(); int &cur_dev(); void check_dev_ptr(const void *p, const char *what); void note_launch(); }
+inline hipError_t hipGetDeviceCount(int *n) { *n = emu::device_count(); return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu::device_count()) return hipErrorInvalidValue; emu::cur_dev() = d; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)192 << 20; *tot = (size_t)4 << 30; return hipSuccess; }   // a small device: the stream's eviction path gets exercised
+inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)(192 - 64 * (emu::cur_dev() & 1)) << 20; *tot = (size_t)4 << 30; return hipSuccess; }   // small devices: the stream's eviction path gets exercised
 void *emu_alloc(size_t n);
+void *emu_alloc_dev(size_t n);
 void emu_free(void *p);
-template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)emu_alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)emu_alloc_dev(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)emu_alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void *p) { emu_free(p); return hipSuccess; }
 inline hipError_t hipHostFree(void *p) { emu_free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { emu::check_dev_ptr(d, "hipMemcpy dst"); emu::check_dev_ptr(s, "hipMemcpy src"); memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
 inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind) {
+  emu::check_dev_ptr(d, "hipMemcpy2D dst"); emu::check_dev_ptr(s, "hipMemcpy2D src");
   for (size_t y = 0; y < h; y++) memmove((uint8_t *)d + y * dp, (const uint8_t *)s + y * sp, w);
   return hipSuccess;
 }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
-inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { emu::check_dev_ptr(d, "hipMemset"); memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
@@ -157,6 +163,11 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 // a small "device": 3 compute units x 2 resident workgroups, so that persistent-workgroup launches see fewer workgroups than work items
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
-inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int dev) { *v = 3 - (dev & 1); return hipSuccess; }
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
-#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); })
+namespace emu {
+template <typename T> inline void check_arg(const T &) {}
+template <typename T> inline void check_arg(T *const &p) { check_dev_ptr((const void *)p, "kernel argument"); }
+template <typename... A> inline void check_args(const A &...a) { (check_arg(a), ...); note_launch(); }
+}
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) (emu::check_args(__VA_ARGS__), emu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); }))

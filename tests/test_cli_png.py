@@ -142,19 +142,19 @@ def test_cli_skips_existing_output_and_fails_loudly_without_gpu(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(CLI), reason='CLI not built')
 def test_cli_exit_handoff_reports_what_the_foreground_exit_reports(tmp_path):
-    """The work runs in a child whose status reaches the caller through a pipe (device teardown off the caller's clock): same exit status, same
-    stderr / stdout, streams closed when the command returns -- with and without CAVIF_MI_FOREGROUND_EXIT, for usage errors (the child returns from
+    """CAVIF_MI_BACKGROUND_EXIT=1 (opt-in): the work runs in a child whose status reaches the caller through a pipe (device teardown off the caller's clock): same exit
+    status, same stderr / stdout, streams closed when the command returns as in the default one-process mode, for usage errors (the child returns from
     main before reporting), per-file failures (it reports 1) and a child that dies (signal -> 128 + signo)."""
     import signal, time
     p = tmp_path / 'a.png'
     Image.new('RGB', (16, 16), (10, 200, 30)).save(p)
     (tmp_path / 'a.avif').write_bytes(b'existing')
     for args in ([], ['-Q', '0', str(p)], [str(p)], [str(tmp_path / 'missing.png')]):
-        a = _run(args)
-        b = _run(args, env=dict(os.environ, CAVIF_MI_FOREGROUND_EXIT='1'))
+        a = _run(args, env=dict(os.environ, CAVIF_MI_BACKGROUND_EXIT='1'))
+        b = _run(args)
         assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr) and a.returncode == 1
     # a child that is killed: the parent returns 128 + the signal (stdin keeps the child waiting inside read_all)
-    pr = subprocess.Popen([CLI, '-o', str(tmp_path / 'o.avif'), '-'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    pr = subprocess.Popen([CLI, '-o', str(tmp_path / 'o.avif'), '-'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, CAVIF_MI_BACKGROUND_EXIT='1'))
     time.sleep(0.3)
     kids = subprocess.run(['ps', '-o', 'pid=', '--ppid', str(pr.pid)], capture_output=True).stdout.split()
     assert len(kids) == 1

@@ -71,6 +71,14 @@ def test_a_dependency_wait_that_never_ends_fails_the_encode_in_bounded_time(emu_
     assert 'ncod' in rows[0]['outcome'] or 'rror' in rows[0]['outcome'], rows
 
 
+def test_two_distinct_emulated_devices(emu_env):
+    """the multi-device fan-out (mi_ravif_encode_stream: one host thread per device, shared cursor, per-device tables / arenas / memory budgets) had only
+    ever run with devices=[0, 0].  MI_EMU_DEVICES=2 gives the emulator two devices that differ in compute units and free memory and that refuse each other's memory
+    (a copy or a kernel argument naming the other device's allocation aborts).  Both devices must do work; every file == oracle.  Unmeasured on real multi-GPU hardware."""
+    p, rows = _run(emu_env, 'twodev', 1200, MI_EMU_DEVICES='2')
+    assert len(rows) == 4 and all(r['ok'] for r in rows) and p.returncode == 0, (rows, p.stderr[-2000:])
+
+
 def test_product_library_is_not_the_emulator():
     """The product library is built by hipcc for gfx950 and knows nothing of the emulator; without a GPU it reports no device."""
     import cavif_rs_amd as m

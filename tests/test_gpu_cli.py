@@ -86,14 +86,14 @@ def test_cli_matches_library_and_reports_like_the_reference(tmp_path):
 
 
 def test_cli_files_are_complete_when_the_command_returns_in_both_exit_modes(tmp_path):
-    """Default: the work runs in a child that reports through a pipe once every file is written (the device teardown is off the caller's clock);
-    CAVIF_MI_FOREGROUND_EXIT=1: one process.  Same bytes, same report, every file complete at return."""
+    """Default: one process, device teardown included.  CAVIF_MI_BACKGROUND_EXIT=1 (opt-in): the work runs in a child that reports through a pipe once every
+    file is written (the device teardown is off the caller's clock).  Same bytes, same report, every file complete at return."""
     import os
     files = []
     for i in range(5):
         Image.fromarray(rgba_gradient(64 + 8 * i, 48), 'RGBA').save(tmp_path / ('f%d.png' % i)); files.append(str(tmp_path / ('f%d.png' % i)))
     outs = []
-    for env in ({}, {'CAVIF_MI_FOREGROUND_EXIT': '1'}):
+    for env in ({}, {'CAVIF_MI_BACKGROUND_EXIT': '1'}):
         r = subprocess.run([CLI, '-f'] + files, capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
         outs.append(([(tmp_path / ('f%d.avif' % i)).read_bytes() for i in range(5)], sorted(r.stdout.splitlines())))   # read at once: nothing is still being written

@@ -294,3 +294,41 @@ def test_saturated_primaries_through_the_front_end_kernel(oracle, avifdec, depth
         if exp is not None:
             # quantizer 0 is not lossless: allow the finest step's rounding around the clipped known answer
             assert all(abs(a - min(b, mx)) <= 2 for a, b in zip(dec, exp)), (i, dec, exp)
+
+
+def test_wide_picture_beyond_4096_columns_of_4x4_cells(oracle):
+    """the deblock stages queue edge lines as packed (4x4 column, line, filter size) words; the column field was 12 bits, so pictures of 16384 samples
+    and more across filtered the wrong lines.  16400 x 16 (4100 cells across, one superblock row, several tiles by the 4096-sample tile-width limit): HIP == oracle."""
+    import cavif_rs_amd as m
+    w, h, bd = 16400, 16, 10
+    pl = planes(h, w, seed=w + h, bd=bd)
+    cfg = oracle.make_config(w, h, bd, False, 121, 6)
+    r = oracle.encode_planes(cfg, pl)
+    obu, rec = m.encode_planes(pl, bd, 121, 6, False)
+    assert obu == r['obu']
+    for a, b in zip(rec, r['recon']):
+        assert np.array_equal(a, b)
+
+
+def test_cli_without_j_takes_the_host_core_count(tmp_path):
+    """`threads: None` of the reference resolves to rayon::current_num_threads() = the host's logical cores (ravif/src/av1encoder.rs:665-668), and that bounds the tile
+    target.  cavif_mi without -j (and with -j0) == cavif_mi -jN == the library with with_num_threads(N), N = this process's CPUs; RAYON_NUM_THREADS overrides N as it
+    does for rayon's global pool.  768x512 at speed 4 asks for min(N, 6) tiles: on hosts with fewer than six CPUs the bound is live."""
+    Image = pytest.importorskip('PIL.Image')
+    import cavif_rs_amd as m
+    from cavif_rs_amd.synth import synth_image
+    img = synth_image(768, 512, index=11)
+    Image.fromarray(img, 'RGB').save(tmp_path / 'a.png')
+    n = len(os.sched_getaffinity(0))
+    outs = {}
+    for name, args, env in (('none', [], {}), ('j0', ['-j0'], {}), ('jN', ['-j%d' % min(n, 255)], {}), ('rayon3', [], {'RAYON_NUM_THREADS': '3'}), ('j3', ['-j3'], {})):
+        r = subprocess.run([CLI, '-f', '-q', '-o', str(tmp_path / (name + '.avif'))] + args + [str(tmp_path / 'a.png')], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs[name] = (tmp_path / (name + '.avif')).read_bytes()
+    assert outs['none'] == outs['j0'] == outs['jN']
+    assert outs['rayon3'] == outs['j3']
+    aq = min((80.0 + 100.0) / 2.0, 80.0 + 80.0 / 4.0 + 2.0)
+    rgba = np.dstack([img, np.full(img.shape[:2], 255, np.uint8)])
+    want_n = m.Encoder().with_quality(80).with_alpha_quality(aq).with_speed(4).with_num_threads(min(n, 255)).encode_rgba(rgba).avif_file
+    want_3 = m.Encoder().with_quality(80).with_alpha_quality(aq).with_speed(4).with_num_threads(3).encode_rgba(rgba).avif_file
+    assert outs['jN'] == want_n and outs['j3'] == want_3 and want_3 != want_n or n <= 3

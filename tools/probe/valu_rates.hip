@@ -70,6 +70,48 @@ CHAIN(k_cnd_e64vcc, "v_cndmask_b32_e64 %0, %0, %1, vcc")
 CHAIN(k_pkmin, "v_pk_min_i16 %0, %0, %1")
 CHAIN(k_subrevs, "v_subrev_u32 %0, %2, %0")
 CHAIN(k_sad32, "v_sad_u32 %0, %0, %1, 0")
+CHAIN(k_fmax, "v_max_f32 %0, %0, %1")
+CHAIN(k_fmin, "v_min_f32 %0, %0, %1")
+CHAIN(k_fmed3, "v_med3_f32 %0, %0, %1, %1")
+CHAIN(k_fmax3, "v_max3_f32 %0, %0, %1, %0")
+CHAIN(k_fcmp, "v_cmp_lt_f32 vcc, %0, %1")
+CHAIN(k_fcmpcnd, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
+CHAIN(k_fmul, "v_mul_f32 %0, %0, %1")
+CHAIN(k_fsub, "v_sub_f32 %0, %0, %1")
+CHAIN(k_fmac, "v_fmac_f32 %0, %1, %1")
+CHAIN(k_cvt_f_i, "v_cvt_f32_i32 %0, %0")
+CHAIN(k_cvt_i_f, "v_cvt_i32_f32 %0, %0")
+CHAIN(k_cvt_f_ub0, "v_cvt_f32_ubyte0 %0, %0")
+CHAIN(k_fabsadd, "v_add_f32 %0, |%0|, %1")
+CHAIN(k_fnegadd, "v_sub_f32 %0, %1, %0")
+CHAIN(k_ffloor, "v_floor_f32 %0, %0")
+CHAIN(k_frndne, "v_rndne_f32 %0, %0")
+CHAIN(k_fmaxlit, "v_max_f32 %0, 0, %0")
+CHAIN(k_fminlit, "v_min_f32 %0, 0x447fc000, %0")
+CHAIN(k_h_add, "v_add_f16 %0, %0, %1")
+CHAIN(k_h_max, "v_max_f16 %0, %0, %1")
+CHAIN(k_pkh_add, "v_pk_add_f16 %0, %0, %1")
+CHAIN(k_pkh_max, "v_pk_max_f16 %0, %0, %1")
+CHAIN(k_pkh_min, "v_pk_min_f16 %0, %0, %1")
+CHAIN(k_pkh_fma, "v_pk_fma_f16 %0, %0, %1, %0")
+CHAIN(k_pkh_mul, "v_pk_mul_f16 %0, %0, %1")
+CHAIN(k_maxu, "v_max_u32 %0, %0, %1")
+CHAIN(k_maxu16, "v_max_u16 %0, %0, %1")
+CHAIN(k_addu16, "v_add_u16 %0, %0, %1")
+CHAIN(k_subu16, "v_sub_u16 %0, %0, %1")
+CHAIN(k_bfi, "v_bfi_b32 %0, %0, %1, %0")
+CHAIN(k_alignbit, "v_alignbit_b32 %0, %0, %1, 16")
+CHAIN(k_xad, "v_xad_u32 %0, %0, %1, %0")
+CHAIN(k_lshlor, "v_lshl_or_b32 %0, %0, 2, %1")
+CHAIN(k_or3, "v_or3_b32 %0, %0, %1, %0")
+CHAIN(k_not, "v_not_b32 %0, %0")
+CHAIN(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
+CHAIN(k_ffbh, "v_ffbh_u32 %0, %0")
+CHAIN(k_absdiff, "v_sub_u32 %0, %0, %1\n v_max_i32 %0, %0, %1")
+CHAIN(k_dppmov, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+CHAIN(k_dppfadd, "v_add_f32_dpp %0, %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf")
+CHAIN(k_sdwa, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1")
+CHAIN(k_movsdwa, "v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1")
 __global__ __launch_bounds__(256) void k_mad64(int *out, int a, int b, int iters) {
   unsigned long long x0 = threadIdx.x + a, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
   for (int i = 0; i < iters; i++) {
@@ -93,6 +135,7 @@ int main() {
   printf("v_add_u32 %.3f ms for %d x 128 instr per wave, 4 waves/SIMD -> %.2f GHz-equivalent\n", base, iters, iters * 128.0 * 4 * 4 / (base * 1e6));
 #define R(k) printf("%-10s %.3f ms  x%.2f\n", #k, run(k, d, iters), run(k, d, iters) / base)
   R(k_add); R(k_cnd64); R(k_cmp); R(k_cmps); R(k_addco); R(k_addc); R(k_mov); R(k_sub); R(k_and); R(k_max); R(k_lshl); R(k_adds); R(k_addlit); R(k_mad24s); R(k_mul24lit); R(k_lshladd); R(k_sube64); R(k_perm); R(k_readlane); R(k_salu); R(k_cmpcnd); R(k_cmpcnds); R(k_cndvccdef); R(k_cnd_e64vcc); R(k_min); R(k_pkmin); R(k_or); R(k_xor); R(k_lshr); R(k_lshlv); R(k_ashrv); R(k_fma); R(k_fadd); R(k_mulu24); R(k_addlsh); R(k_and_or); R(k_subrevs); R(k_max3); R(k_sad32); R(k_cmpcnd); R(k_cmpcnds); R(k_cndvccdef); R(k_cnd_e64vcc); R(k_min); R(k_pkmin); R(k_or); R(k_xor); R(k_lshr); R(k_lshlv); R(k_ashrv); R(k_fma); R(k_fadd); R(k_mulu24); R(k_addlsh); R(k_and_or); R(k_subrevs); R(k_max3); R(k_sad32); R(k_mul24); R(k_mad24); R(k_mullo); R(k_mulhi); R(k_pkadd); R(k_pkmul); R(k_pkmad); R(k_dot2); R(k_sad16); R(k_dpp); R(k_dpprow); R(k_cndmask); R(k_add3); R(k_ashr); R(k_bfe); R(k_med3); R(k_cvtf); R(k_sqrt); R(k_rcp);
+  printf("--- round 6: the float pipe, 16-bit, bit ops ---\n"); R(k_fmax); R(k_fmin); R(k_fmed3); R(k_fmax3); R(k_fcmp); R(k_fcmpcnd); R(k_fmul); R(k_fsub); R(k_fmac); R(k_cvt_f_i); R(k_cvt_i_f); R(k_cvt_f_ub0); R(k_fabsadd); R(k_fnegadd); R(k_ffloor); R(k_frndne); R(k_fmaxlit); R(k_fminlit); R(k_h_add); R(k_h_max); R(k_pkh_add); R(k_pkh_max); R(k_pkh_min); R(k_pkh_fma); R(k_pkh_mul); R(k_maxu); R(k_maxu16); R(k_addu16); R(k_subu16); R(k_bfi); R(k_alignbit); R(k_xad); R(k_lshlor); R(k_or3); R(k_not); R(k_bcnt); R(k_ffbh); R(k_absdiff); R(k_dppmov); R(k_dppfadd); R(k_sdwa); R(k_movsdwa);
   printf("%-10s %.3f ms  x%.2f (per instr; 4 chains)\n", "k_mad64", run(k_mad64, d, iters), run(k_mad64, d, iters) / base);
   return 0;
 }
