@@ -16,7 +16,8 @@
 // HBM scratch of one persistent workgroup, behind its area snapshots
 struct Blk64Hbm {
   uint16_t lrec[4][64 * 64]; int32_t lqc[4][32 * 32];                 // luma: each wave's best undivided candidate
-  uint16_t trec[64 * 64]; int32_t tqc[64 * 64];                       // luma transform-size trial in progress: sub-block q's levels at tqc + q * (coded samples per sub-block)
+  uint16_t trec[64 * 64]; int32_t tqc[64 * 64];                       // luma transform-size trial: the best chain so far; sub-block q's levels at tqc + q * (coded samples per sub-block)
+  uint16_t crec4[4][64 * 64]; int32_t cqc4[4][64 * 64];               // luma transform-size trial: each wave's chain in progress (one transform type for the whole block)
   uint16_t crec[2][2][2][64 * 64]; int32_t cqc[2][2][2][4 * 32 * 32]; // chroma [wave pair][buffer][plane - 1]: the pair's candidate in progress and its best so far
 };
 typedef unsigned int v2u_t __attribute__((vector_size(8)));    // 8- / 16-byte LDS -> HBM copies (built-in vectors: assignable across address spaces)
@@ -254,97 +255,121 @@ __device__ MI_K1_TRY_ATTR long long try_block64(const Ctx<32, NW, TS> k, int r, 
       auto trial = [&](auto depth_c) -> bool {
         constexpr int D = decltype(depth_c)::value;
         constexpr int SBS = BS - D, G = 1 << D, hn = n >> D, half = n4 >> D, hnn = hn * hn, sqn = hnn, scp = hn / 8, pcp = 8;
-        LDS uint16_t *brow = SH->x64.bnd, *rcol = SH->x64.bnd + G * G * hn;       // bottom row / right column of sub-block q at + q * hn
+        static_assert(2 * G * G * hn <= 512, "a chain's boundaries fit a quarter of x64.bnd");
+        LDS uint16_t *brow = SH->x64.bnd + W * 512, *rcol = brow + G * G * hn;    // this wave's chain: bottom row / right column of sub-block q at + q * hn
         long long j_split = SH->lm_mode_j + (((long long)dcost[D] * f->rdmult + 256) >> 9);
         int stx_ns = 0, stx_set = 0;
         const int stx_off = intra_tx_cdf_r(f, Tools<TS>::reduced_tx_set(f), SBS, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
         int sub_any = 0;
+        // One chain per wavefront and round (transform type rd * NW + W for the whole block: rav1e rdo_tx_type_decision), every wave on its own: sub-source, raw edges from its
+        // chain's boundaries, prediction and evaluation in its private scratch (sub-source = rec[1], prediction = dcp), reconstruction and levels in its HBM canvas; a
+        // barrier only between rounds: the best complete chain so far moves to trec / tqc, the next round's chains must beat it (a later type never wins a tie).
+        LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF, *psrc = S->rec[1];
+        LDS int *ppsv = (LDS int *)S->etmp, *ppact = ppsv + 16;                   // (etmp is predict_block's temporary: free between two predictions)
+        LDS uint32_t *cmeta = (LDS uint32_t *)SH->cj + W * 16;
+        uint16_t *crec = H->crec4[W]; int32_t *cqc = H->cqc4[W];
+        const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+        const uint16_t *grec = f->rec[0];
+        const long long j0 = j_split;
+        long long best_chain = J_INF;
 #pragma unroll 1
-        for (int q = 0; q < G * G; q++) {
-          if (j_split >= budget && luma_j >= budget) return true;
-          if (!(j_split < luma_j)) break;
-          const int bi = q / G, bj = q % G;
-          const int sx = x + bj * hn, sy = y + bi * hn;
-          const int sU = availU || bi, sL = availL || bj;
-          // all waves: the sub-source; wave 0: its psychovisual references, its raw edges and the prediction
-          for (int idx = threadIdx.x; idx < hnn; idx += 64 * NW) SH->ssrc[idx] = SH->x64.src64[(bi * hn + idx / hn) * n + bj * hn + idx % hn];
-          if (W == 0) {
-            if (LANE < scp * scp) { const int pc = (bi * scp + LANE / scp) * pcp + bj * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
-            // above-right / below-left availability (spec BlockDecoded): what lies right of or below a 64x64 block -- the next superblocks -- is never decoded yet
-            const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : 0);
-            const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : 0;
-            LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
-            const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
-            const uint16_t *grec = f->rec[0];
-            const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
-            auto px = [&](int ax, int ay) -> int {                  // absolute sample position -> value
-              const int xr = ax - x, yr = ay - y;
-              if (xr >= 0 && xr < n && yr >= 0 && yr < n) {
-                const int qq = (yr / hn) * G + xr / hn;
-                return (yr % hn) == hn - 1 ? (int)brow[qq * hn + xr % hn] : (int)rcol[qq * hn + yr % hn];   // only rows / columns next to a later sub-block are asked for
+        for (int rd = 0; rd * NW < sntx; rd++) {
+          const int e = rd * NW + W;
+          const bool has_chain = e < sntx;
+          long long thr = luma_j < budget ? luma_j : budget;
+          if (best_chain < thr) thr = best_chain;
+          int txtype;
+          if (sntx > 1) txtype = sym_to_txtype(stx_set, has_chain ? e : 0);
+          else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+          const int tx_sym = stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0;
+          long long jc = has_chain ? j0 : J_INF;
+          int any = 0;
+          if (has_chain) {
+#pragma unroll 1
+            for (int q = 0; q < G * G; q++) {
+              if (!(jc < thr)) break;                              // wave-uniform
+              const int bi = q / G, bj = q % G;
+              const int sx = x + bj * hn, sy = y + bi * hn;
+              const int sU = availU || bi, sL = availL || bj;
+              for (int idx = LANE; idx < hnn; idx += 64) psrc[idx] = SH->x64.src64[(bi * hn + idx / hn) * n + bj * hn + idx % hn];
+              {
+                // above-right / below-left availability (spec BlockDecoded): what lies right of or below a 64x64 block -- the next superblocks -- is never decoded yet
+                const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : 0);
+                const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : 0;
+                const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
+                auto px = [&](int ax, int ay) -> int {                  // absolute sample position -> value
+                  const int xr = ax - x, yr = ay - y;
+                  if (xr >= 0 && xr < n && yr >= 0 && yr < n) {
+                    const int qq = (yr / hn) * G + xr / hn;
+                    return (yr % hn) == hn - 1 ? (int)brow[qq * hn + xr % hn] : (int)rcol[qq * hn + yr % hn];   // only rows / columns next to a later sub-block are asked for
+                  }
+                  if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
+                  if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
+                  return (int)grec[(size_t)ay * rs + ax];
+                };
+                for (int i = LANE; i <= 2 * hn; i += 64) {
+                  const bool corner = i == 2 * hn;
+                  int a, l;
+                  if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+                  if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+                  if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+                  if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+                }
+                WAVE_SYNC();
+                predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, S->dcp);
               }
-              if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
-              if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
-              return (int)grec[(size_t)ay * rs + ax];
-            };
-            for (int i = LANE; i <= 2 * hn; i += 64) {
-              const bool corner = i == 2 * hn;
-              int a, l;
-              if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
-              if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
-              if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
-              if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+              if (LANE < scp * scp) { const int pc = (bi * scp + LANE / scp) * pcp + bj * scp + LANE % scp; ppsv[LANE] = SH->psv[pc]; ppact[LANE] = SH->pact[pc]; }
+              // contexts of the sub-block: neighbours outside the block from the staged maps, inside from this chain's sub-blocks
+              int ssc, sdc;
+              {
+                // (the oracle's av1o_txb_ctx leaves out neighbour cells beyond the frame: the staged outer contexts are zero there, an inner neighbour counts its cells inside)
+                int top = 0, left = 0, dcs = 0;
+                const int nti = iclamp_(f->mi_cols - (c + bj * half), 0, half), nli = iclamp_(f->mi_rows - (r + bi * half), 0, half);
+                const uint32_t mt = bi ? cmeta[q - G] : 0u, ml = bj ? cmeta[q - 1] : 0u;
+                if (bi == 0) { for (int k2 = 0; k2 < half; k2++) { const int l = SH->nb_top[bj * half + k2][0], d = SH->nb_top[bj * half + k2][1]; top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0); } }
+                else if (nti > 0) { const int d = (int)(mt >> 24); top = (int)((mt >> 16) & 0xFF); dcs += nti * (d == 1 ? -1 : (d == 2 ? 1 : 0)); }
+                if (bj == 0) { for (int k2 = 0; k2 < half; k2++) { const int l = SH->nb_left[bi * half + k2][0], d = SH->nb_left[bi * half + k2][1]; left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0); } }
+                else if (nli > 0) { const int d = (int)(ml >> 24); left = (int)((ml >> 16) & 0xFF); dcs += nli * (d == 1 ? -1 : (d == 2 ? 1 : 0)); }
+                sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+                if (top == 0 && left == 0) ssc = 1;
+                else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+                else if (imax_(top, left) <= 3) ssc = 4;
+                else if (imin_(top, left) <= 3) ssc = 5;
+                else ssc = 6;
+              }
+              WAVE_SYNC();
+              TxRes tr;
+              jc += eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, S->dcp, txtype, stx_off, tx_sym, S->rec[0], S->qc[0], &tr, psrc, (const LDS int *)ppsv, (const LDS int *)ppact);
+              {
+                // the chain keeps the sub-block: boundaries in LDS (the next sub-blocks' edges), reconstruction and levels in its HBM canvas
+                const LDS uint16_t *srec = S->rec[0]; const LDS int32_t *sqc = S->qc[0];
+                for (int i = LANE; i < hn; i += 64) { brow[q * hn + i] = srec[(hn - 1) * hn + i]; rcol[q * hn + i] = srec[i * hn + hn - 1]; }
+                const int ro = bi * hn * n + bj * hn;
+                for (int i = LANE; i < hnn; i += 64) crec[ro + (i / hn) * n + (i % hn)] = srec[i];
+                for (int i = LANE; i < sqn; i += 64) cqc[q * sqn + i] = sqc[i];
+                if (LANE == 0) cmeta[q] = (uint32_t)tr.eob | ((uint32_t)tr.cul << 16) | ((uint32_t)tr.dcc << 24);
+              }
+              any |= tr.eob > 0;
+              WAVE_SYNC();
             }
-            WAVE_SYNC();
-            predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, SH->spred);
           }
-          // contexts of the sub-block: neighbours outside the block from the staged maps, inside from the sub-blocks done
-          int ssc, sdc;
-          {
-            // (the oracle's av1o_txb_ctx leaves out neighbour cells beyond the frame: the staged outer contexts are zero there, an inner neighbour counts its cells inside)
-            int top = 0, left = 0, dcs = 0;
-            const int nti = iclamp_(f->mi_cols - (c + bj * half), 0, half), nli = iclamp_(f->mi_rows - (r + bi * half), 0, half);
-            if (bi == 0) { for (int k2 = 0; k2 < half; k2++) { const int l = SH->nb_top[bj * half + k2][0], d = SH->nb_top[bj * half + k2][1]; top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0); } }
-            else if (nti > 0) { const int d = sub_dcc[q - G]; top = sub_cul[q - G]; dcs += nti * (d == 1 ? -1 : (d == 2 ? 1 : 0)); }
-            if (bj == 0) { for (int k2 = 0; k2 < half; k2++) { const int l = SH->nb_left[bi * half + k2][0], d = SH->nb_left[bi * half + k2][1]; left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0); } }
-            else if (nli > 0) { const int d = sub_dcc[q - 1]; left = sub_cul[q - 1]; dcs += nli * (d == 1 ? -1 : (d == 2 ? 1 : 0)); }
-            sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
-            if (top == 0 && left == 0) ssc = 1;
-            else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
-            else if (imax_(top, left) <= 3) ssc = 4;
-            else if (imin_(top, left) <= 3) ssc = 5;
-            else ssc = 6;
-          }
-          WG_SYNC();                                             // sub-source, references and prediction staged
-          long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, scur = 0;
-#pragma unroll 1
-          for (int e = W; e < sntx; e += NW) {
-            int txtype;
-            if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
-            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-            TxRes tr;
-            const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, SH->spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
-                                                   SH->ssrc, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
-            if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
-          }
-          if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
+          if (LANE == 0) { SH->wbest_j[W] = jc < thr ? jc : J_INF; SH->wbest_e[W] = any; }
           WG_SYNC();
           int sw = 0;
-          for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
-          const long long sub_j = SH->wbest_j[sw];
-          if (W == sw) {                                         // the winner: boundaries stay in LDS, reconstruction and levels wait in HBM
-            const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-            for (int i = LANE; i < hn; i += 64) { brow[q * hn + i] = srec[(hn - 1) * hn + i]; rcol[q * hn + i] = srec[i * hn + hn - 1]; }
-            const int ro = bi * hn * n + bj * hn;
-            for (int i = LANE; i < hnn; i += 64) H->trec[ro + (i / hn) * n + (i % hn)] = srec[i];
-            for (int i = LANE; i < sqn; i += 64) H->tqc[q * sqn + i] = sqc[i];
-            if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
+          for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw]) sw = w2;            // the lowest wave = the lowest symbol among equals
+          const long long rj = SH->wbest_j[sw];
+          if (rj < best_chain) {                                 // (thr made it strictly smaller than every earlier round's)
+            best_chain = rj; sub_any = SH->wbest_e[sw];
+            if (W == sw) {
+              for (int i = LANE; i < nn / 4; i += 64) ((v2u_t *)H->trec)[i] = ((const v2u_t *)crec)[i];
+              for (int i = LANE; i < G * G * sqn / 4; i += 64) ((v4u_t *)H->tqc)[i] = ((const v4u_t *)cqc)[i];
+              if (LANE < G * G) { const uint32_t m = cmeta[LANE]; const int eob = (int)(m & 0xFFFF); sub_eob[LANE] = eob; sub_cul[LANE] = (int)((m >> 16) & 0xFF); sub_dcc[LANE] = (int)(m >> 24); sub_tx[LANE] = eob ? txtype : DCT_DCT; }
+            }
           }
           WG_SYNC();
-          sub_any |= sub_eob[q] > 0;
-          j_split += sub_j;
         }
+        j_split = best_chain;
         if (j_split < luma_j) {
           // this depth wins: its reconstruction, levels and contexts replace the best so far in the frame
           luma_j = j_split; any_coef = sub_any;

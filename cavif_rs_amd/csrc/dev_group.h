@@ -417,10 +417,10 @@ __device__ __forceinline__ void edge_upsample_group(LDS uint16_t *buf, int num_p
 }
 
 // pa: prediction angle of this row (mode angle + 3 * delta), row-uniform.  Rows with live == false still walk the code
-// (pa = 90 keeps them cheap).  Output: gp->pred[N*N].
+// (pa = 90 keeps them cheap).  Output: gp->pred[N*N], or `out` (row-uniform) when given.
 template <int N>
 __device__ inline void predict_dir_group(const LDS FrameDev *f, int x, int y, int have_left, int have_above, int pa, int ftype,
-                                         const LDS uint16_t *ra, const LDS uint16_t *rl, LDS GroupPredBuf *gp) {
+                                         const LDS uint16_t *ra, const LDS uint16_t *rl, LDS GroupPredBuf *gp, LDS uint16_t *out = nullptr) {
   constexpr int log2w = N == 4 ? 2 : 3, nn = N * N;
   const int gl = GROUP_LANE, bd = f->bd;
   const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1;
@@ -459,7 +459,7 @@ __device__ inline void predict_dir_group(const LDS FrameDev *f, int x, int y, in
       v = round2_(wl[base] * (32 - sh) + wl[base + 1] * sh, 5);
     } else if (pa == 90) v = wa[j];
     else v = wl[i];
-    gp->pred[idx] = (uint16_t)v;
+    (out ? out : (LDS uint16_t *)gp->pred)[idx] = (uint16_t)v;
   }
   WAVE_SYNC();
 }

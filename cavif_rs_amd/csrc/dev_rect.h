@@ -702,98 +702,119 @@ __device__ MI_K1_TRY_ATTR long long try_block_rect(const Ctx<MAXN, NW, TS> k, in
       const int sntx = stx_off >= 0 ? stx_ns : 1;
       LDS uint16_t *split_rec = (LDS uint16_t *)SH->ssrc + 64;             // [NN] (ssrc[0..31] = the two sub-sources)
       LDS int32_t *split_qc = MAXN <= 16 ? (LDS int32_t *)SH->lpred : (LDS int32_t *)SH->split_qc;   // [2][16]
-      LDS int *sub = (LDS int *)SH->dsd;                                     // [2][4]: tx, eob, cul, dcc of the halves
+      LDS int *sub = (LDS int *)SH->dsd;                                     // [2][4]: tx, eob, cul, dcc of the halves; [8..11]: the halves' outer neighbour contexts
       int sub_any = 0;
       if (W == 0) for (int idx = LANE; idx < NN; idx += 64) { const int q = W_ == 8 ? ((idx & 7) >> 2) : (idx >> 4), i = (idx >> WL) & 3, j = idx & 3; SH->ssrc[q * 16 + i * 4 + j] = SH->srcb[0][idx]; }
+      if (W == 1 && LANE < 4) {
+        // outer neighbour contexts of the two halves (txb_ctx_wh's loads): lane = 2 * half + (0: above, 1: left); level | dc << 8 | available << 16.  The second half's
+        // inner neighbour (the first half) comes from the chain.
+        const int q = LANE >> 1, side = LANE & 1, rr = r + (H_ == 8 ? q : 0), cc = c + (W_ == 8 ? q : 0);
+        const bool inner = q == 1 && (side == 0 ? H_ == 8 : W_ == 8);
+        const bool have = !inner && (side == 0 ? (rr - 1 >= t->mi_row_start && cc < f->mi_cols) : (cc - 1 >= t->mi_col_start && rr < f->mi_rows));
+        const int ia = have ? (side == 0 ? (rr - 1) * ms + cc : rr * ms + cc - 1) : rr * ms + cc;
+        const int l = f->m_lvl[0][ia], d = f->m_dc[0][ia];
+        sub[8 + LANE] = have ? (l | (d << 8) | (1 << 16)) : 0;
+      }
       WG_SYNC();
-#pragma unroll 1
-      for (int q = 0; q < 2; q++) {
-        if (j_split >= budget && luma_j >= budget) return luma_j;
-        if (!(j_split < luma_j)) break;
-        const int bi = H_ == 8 ? q : 0, bj = W_ == 8 ? q : 0, rr = r + bi, cc = c + bj, sx = x + bj * 4, sy = y + bi * 4;
-        const int sU = availU || bi, sL = availL || bj;
-        if (W == 0) {
-          // availability of the halves' above-right / below-left runs (oracle: the decoded flags of the cells they start in)
-          const bool c_ar = sU && cc + 1 < t->mi_col_end, c_bl = sL && rr + 1 < t->mi_row_end;
-          const int s_ar = c_ar && decoded_before(r, c, SHAPE, rr - 1, cc + 1), s_bl = c_bl && decoded_before(r, c, SHAPE, rr + 1, cc - 1);   // (both cells lie outside the block)
-          LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+      // One chain per transform type (rav1e rdo_tx_type_decision: both halves with the same type), each on a 16-lane row like the square blocks' trial (tile_search.h):
+      // five types: the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1; otherwise four per wave on waves 0 and 1.  Chain state in waves 2 / 3's scratch.
+      {
+        constexpr int CH_BYTES = NN * 2 + NN * 4 + 2 * 4;
+        const int g = GROUP_ID, gl = GROUP_LANE;
+        const int e = sntx == 5 ? (W == 0 ? g + 1 : ((W == 1 && g == 0) ? 0 : 64)) : W * 4 + g;
+        const bool has_chain = e < sntx, wave_has = sntx == 5 ? W < 2 : W * 4 < sntx;
+        LDS long long *const cres_j = (LDS long long *)SH->cj; LDS int *const cres_any = (LDS int *)(cres_j + 8);
+        const long long thr = luma_j < budget ? luma_j : budget;
+        if (wave_has) {
+          LDS uint8_t *cst = (LDS uint8_t *)k.wave(2 + W) + g * CH_BYTES;
+          LDS uint16_t *canvas = (LDS uint16_t *)cst; LDS int32_t *cqc = (LDS int32_t *)(cst + NN * 2); LDS uint32_t *cmeta = (LDS uint32_t *)(cst + NN * 2 + NN * 4);
+          LDS uint16_t *A = S->pred + g * 64 + EDGE_OFF, *Lf = A + 32, *ppred = S->dcp + g * 64;
+          int txtype;
+          if (sntx > 1) txtype = sym_to_txtype(stx_set, has_chain ? e : 0);
+          else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+          const int tx_sym = stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0;
+          const bool dirm = best_mode >= V_PRED && best_mode <= D67_PRED;
+          const int pa = dirm ? mode_angle_of(best_mode) : 0;
           const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
           const uint16_t *grec = f->rec[0];
-          const int lim_a = imin_(max_x, sx + (s_ar ? 8 : 4) - 1), lim_l = imin_(max_y, sy + (s_bl ? 8 : 4) - 1);
-          auto px = [&](int ax, int ay) -> int {
-            const int xr = ax - x, yr = ay - y;
-            if (xr >= 0 && xr < W_ && yr >= 0 && yr < H_) return (int)split_rec[yr * W_ + xr];
-            if (yr == -1 && xr >= -1 && xr < W_ + H_) return (int)ra[xr];
-            if (xr == -1 && yr >= 0 && yr < W_ + H_) return (int)rl[yr];
-            return (int)grec[(size_t)ay * rs + ax];
-          };
-          for (int i = LANE; i <= 8; i += 64) {
-            const bool corner = i == 8;
-            int a, l;
-            if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
-            if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
-            if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
-            if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
-          }
-          WAVE_SYNC();
-          predict_block(f, sx, sy, 2, sL, sU, best_mode, 0, ftype_y, A, Lf, wa, wl, S->etmp, SH->spred);
-          int ssc, sdc;
-          txb_ctx_wh(f, t, 0, rr, cc, 1, 1, 0, &ssc, &sdc);                  // the first half's contexts are in the frame by the time the second asks (committed below)
-          if (LANE == 0) { SH->spsv[0] = SH->psv4[q]; SH->spact[0] = SH->pact[0]; sub[8] = ssc; sub[9] = sdc; }
-        }
-        WG_SYNC();
-        const int ssc = sub[8], sdc = sub[9];
-        long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, scur = 0, sg = 0;
-        bool sgrouped = false;
-        if constexpr (CAN_GROUP) sgrouped = sntx == 5;
-        if constexpr (CAN_GROUP) if (sgrouped && W < 2) {        // the four DCT / ADST combinations on wave 0's rows, IDTX alone on wave 1 (as in the square trial)
-          const int g = GROUP_ID, e = W == 0 ? g + 1 : (g == 0 ? 0 : 64);
-          const bool live = e < sntx;
-          const int txtype = sym_to_txtype(stx_set, live ? e : 0);
-          GroupRes gr;
-          eval_group<4>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * 16, SH->spred, 0, 0, txtype, ssc, sdc, stx_off, txtype_to_sym(stx_set, txtype),
-                        Tools<TS>::tune_psnr(f) ? -1 : SH->psv4[q], SH->pact[0], &gr);
-          long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
-          if (!live) j = J_INF;
-#pragma unroll
-          for (int gg = 0; gg < 4; gg++) {
-            const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
-            const int eg = __builtin_amdgcn_readlane(e, gg * 16);
-            if (jg < sj || (jg == sj && eg < se)) {
-              sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
-              s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+          long long jc = has_chain ? j_split : J_INF;
+          int any = 0;
+#pragma unroll 1
+          for (int q = 0; q < 2; q++) {
+            if (MI_BALLOT64(jc < thr) == 0ull) break;
+            const int bi = H_ == 8 ? q : 0, bj = W_ == 8 ? q : 0, rr = r + bi, cc = c + bj, sx = x + bj * 4, sy = y + bi * 4;
+            const int sU = availU || bi, sL = availL || bj;
+            {
+              // availability of the halves' above-right / below-left runs (oracle: the decoded flags of the cells they start in)
+              const bool c_ar = sU && cc + 1 < t->mi_col_end, c_bl = sL && rr + 1 < t->mi_row_end;
+              const int s_ar = c_ar && decoded_before(r, c, SHAPE, rr - 1, cc + 1), s_bl = c_bl && decoded_before(r, c, SHAPE, rr + 1, cc - 1);   // (both cells lie outside the block)
+              const int lim_a = imin_(max_x, sx + (s_ar ? 8 : 4) - 1), lim_l = imin_(max_y, sy + (s_bl ? 8 : 4) - 1);
+              auto px = [&](int ax, int ay) -> int {
+                const int xr = ax - x, yr = ay - y;
+                if (xr >= 0 && xr < W_ && yr >= 0 && yr < H_) return (int)canvas[yr * W_ + xr];
+                if (yr == -1 && xr >= -1 && xr < W_ + H_) return (int)ra[xr];
+                if (xr == -1 && yr >= 0 && yr < W_ + H_) return (int)rl[yr];
+                return (int)grec[(size_t)ay * rs + ax];
+              };
+              for (int i = gl; i <= 8; i += 16) {
+                const bool corner = i == 8;
+                int a, l;
+                if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+                if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+                if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+                if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+              }
             }
+            WAVE_SYNC();
+            if (dirm) predict_dir_group<4>(f, sx, sy, sL, sU, pa, ftype_y, A, Lf, &S->gpred[g], ppred);
+            else predict_nondir_group<4>(best_mode, sL, sU, bd, A, Lf, ppred);
+            int ssc, sdc;
+            {
+              const uint32_t m0 = q ? cmeta[0] : 0u;
+              const int inner = (int)(((m0 >> 16) & 0xFF) | ((m0 >> 24) << 8) | (1u << 16));      // the first half as a neighbour: level | dc << 8 | available
+              const int nt = (q == 1 && H_ == 8) ? inner : sub[8 + 2 * q], nl = (q == 1 && W_ == 8) ? inner : sub[8 + 2 * q + 1];
+              const int top = (nt >> 16) ? (nt & 0xFF) : 0, left = (nl >> 16) ? (nl & 0xFF) : 0, dt = (nt >> 16) ? ((nt >> 8) & 0xFF) : 0, dl = (nl >> 16) ? ((nl >> 8) & 0xFF) : 0;
+              const int dcs = (dt == 1 ? -1 : (dt == 2 ? 1 : 0)) + (dl == 1 ? -1 : (dl == 2 ? 1 : 0));
+              sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+              if (top == 0 && left == 0) ssc = 1;
+              else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+              else if (imax_(top, left) <= 3) ssc = 4;
+              else if (imin_(top, left) <= 3) ssc = 5;
+              else ssc = 6;
+            }
+            GroupRes gr;
+            eval_group<4>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], SH->ssrc + q * 16, ppred, 0, 0, txtype, ssc, sdc, stx_off, tx_sym, Tools<TS>::tune_psnr(f) ? -1 : SH->psv4[q], SH->pact[0], &gr);
+            if (has_chain) jc += rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
+            {
+              const LDS uint16_t *srec = S->grp[g].rec; const LDS int32_t *sqc = S->grp[g].qc;
+              canvas[(bi * 4 + (gl >> 2)) * W_ + bj * 4 + (gl & 3)] = srec[gl]; cqc[q * 16 + gl] = sqc[gl];
+              cmeta[q] = (uint32_t)gr.eob | ((uint32_t)gr.cul << 16) | ((uint32_t)gr.dcc << 24);
+            }
+            any |= gr.eob > 0;
+            WAVE_SYNC();
           }
+          // (every lane stores, rows without a chain into a slot nobody reads: see the square blocks' trial in tile_search.h for why no divergent region ends here)
+          const int slot = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g;
+          cres_j[slot] = (has_chain && jc < thr) ? jc : J_INF; cres_any[slot] = any;
         }
-        if (!sgrouped)
-        for (int e = W; e < sntx; e += NW) {
-          int txtype;
-          if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
-          else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-          TxRes tr;
-          const long long j = eval_tx<MAXN, 0, NW>(k, 0, ssc, sdc, SH->spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
-                                                 SH->ssrc + q * 16, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
-          if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
-        }
-        if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
         WG_SYNC();
-        int sw = 0;
-        for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
-        const long long sub_j = SH->wbest_j[sw];
-        if (W == sw) {
-          const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-          if constexpr (CAN_GROUP) if (sgrouped) { srec = S->grp[sg].rec; sqc = S->grp[sg].qc; }
-          for (int i = LANE; i < 16; i += 64) { split_rec[(bi * 4 + (i >> 2)) * W_ + bj * 4 + (i & 3)] = srec[i]; split_qc[q * 16 + i] = sqc[i]; }
-          if (LANE == 0) {
-            sub[q * 4 + 0] = s_eob ? stx : DCT_DCT; sub[q * 4 + 1] = s_eob; sub[q * 4 + 2] = s_cul; sub[q * 4 + 3] = s_dcc;
-            // the second half reads the first one's contexts from the frame maps (txb_ctx_wh above): leave them there for the trial; the undivided
-            // transform's values come back below if the split loses
-            f->m_lvl[0][rr * ms + cc] = (uint8_t)s_cul; f->m_dc[0][rr * ms + cc] = (uint8_t)s_dcc;
+        int be = -1; long long bjc = J_INF;
+        for (int e2 = 0; e2 < sntx; e2++) { const long long v = cres_j[e2]; if (v < bjc) { bjc = v; be = e2; } }
+        j_split = bjc;
+        if (be >= 0) {
+          const int ow = sntx == 5 ? (be == 0 ? 1 : 0) : be >> 2, og = sntx == 5 ? (be == 0 ? 0 : be - 1) : be & 3;
+          if (W == ow) {
+            const LDS uint8_t *cst = (const LDS uint8_t *)k.wave(2 + W) + og * CH_BYTES;
+            const LDS uint16_t *canvas = (const LDS uint16_t *)cst; const LDS int32_t *cqc = (const LDS int32_t *)(cst + NN * 2); const LDS uint32_t *cmeta = (const LDS uint32_t *)(cst + NN * 2 + NN * 4);
+            if (LANE < NN) { split_rec[LANE] = canvas[LANE]; split_qc[LANE] = cqc[LANE]; }
+            int btx;
+            if (sntx > 1) btx = sym_to_txtype(stx_set, be);
+            else { btx = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, btx) < 0) btx = DCT_DCT; }
+            if (LANE < 2) { const uint32_t m = cmeta[LANE]; const int eob = (int)(m & 0xFFFF); sub[LANE * 4 + 0] = eob ? btx : DCT_DCT; sub[LANE * 4 + 1] = eob; sub[LANE * 4 + 2] = (int)((m >> 16) & 0xFF); sub[LANE * 4 + 3] = (int)(m >> 24); }
           }
+          sub_any = cres_any[be];
+          WG_SYNC();
         }
-        WG_SYNC();
-        sub_any |= sub[q * 4 + 1] > 0;
-        j_split += sub_j;
       }
       if (j_split < luma_j) {
         luma_j = j_split; any_coef = sub_any;

@@ -20,8 +20,21 @@
 // The shape of the search's code, fixed explicitly (left to the inliner's cost model it flips with unrelated edits: with the block searches inlined into
 // separate partition functions K1 <2,4> went from 116 to 142 ms): the block searches are functions of their own -- entered with every argument in registers
 // and, not being tail-called, given LLVM's no-callee-saved-registers treatment --, the partition walkers are inlined into the kernel.
+#ifndef MI_BALLOT64                                      /* (the CPU test harness tests/emu/ predefines it) */
+#define MI_BALLOT64(p) __builtin_amdgcn_ballot_w64(p)
+#endif
 #define MI_K1_TRY_ATTR __attribute__((noinline, not_tail_called))
 #define MI_K1_WALK_INLINE __forceinline__
+// The loop over the four children of a split node: unrolled, the recursion's inlining multiplies the node's code by four per level (64 copies of the 8x8 node's body in the
+// 16x16 class: ~600 KB of code, 1127 SGPR spills in the kernel body); rolled (-DMI_K1_WALK_ROLLED=1), one copy per level.
+#ifndef MI_K1_WALK_ROLLED
+#define MI_K1_WALK_ROLLED 0
+#endif
+#if MI_K1_WALK_ROLLED
+#define MI_K1_WALK_SPLIT_LOOP _Pragma("unroll 1")
+#else
+#define MI_K1_WALK_SPLIT_LOOP _Pragma("unroll")
+#endif
 #define MI_K1_WG_PER_CU 4                            /* the 16x16 class: 40.9 KB of LDS and 128 VGPRs per workgroup -> exactly four per CU */
 #define WAVE_ID ((int)(threadIdx.x >> 6))
 #ifndef MI_PROFILE
@@ -60,7 +73,7 @@
 // wave's scratch -- the 64x64 prediction (reconstructed in place), the 32 rows of the column pass that the row pass keeps, the 32x32 coded area.
 struct Blk64Wave { uint16_t pred[64 * 64]; int32_t tbuf[32 * 65]; int32_t cbuf[32 * 32]; int32_t qc[32 * 32]; };
 struct Blk64None { uint8_t none_; };
-struct Blk64Shared { uint16_t src64[64 * 64], bnd[1024]; uint8_t cnb_top[2][16][2], cnb_left[2][16][2]; };
+struct Blk64Shared { uint16_t src64[64 * 64], bnd[2048];     /* bnd: four waves' chain boundaries (dev_blk64.h) */ uint8_t cnb_top[2][16][2], cnb_left[2][16][2]; };
 template <int N> struct WaveScratch {            // private to one wavefront
   static constexpr int CS = N < 32 ? N : 32, NBUF = 2, DCP_LEN = N * N, E = N == 32 ? 64 : N;   // E: the largest block whose edges the wave prepares
   uint16_t wa[EDGE_LEN(E)], wl[EDGE_LEN(E)], etmp[2 * E + 16];
@@ -720,73 +733,91 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         }
         WG_SYNC();
         PH(22);
+        [[maybe_unused]] const int x_ = x, y_ = y, r_ = r, c_ = c, availU_ = availU, availL_ = availL, have_ar_ = have_ar, have_bl_ = have_bl, best_mode_ = best_mode, best_delta_ = best_delta, ftype_y_ = ftype_y;
         if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) {
-          // 4x4 / 8x8 sub-blocks: at most eight tx types per sub-block fit two waves (four per wave, one per 16-lane row), so the workgroup runs as
-          // two wave pairs on two sub-blocks at a time wherever the coding order's dependencies allow it.  A sub-block needs its left neighbour,
-          // the row above up to its above-right neighbour and nothing below: the 4 x 4 grid runs as a wavefront skewed by two (slot = bj + 2 bi,
-          // 10 slots for 16 sub-blocks); the 2 x 2 grid can only pair (0,1) with (1,0), which is legal when the prediction reads no above-right
-          // samples (every mode but the directional ones below 90 degrees).  Costs are sums, the pruning rules only ever discard a losing trial,
-          // and every context a sub-block reads was written in an earlier slot: decisions and bytes are those of the raster-order walk.
-          const int P = W >> 1, WP = W & 1;
-          LDS WaveScratch<MAXN> *SL = k.wave(P * 2);           // the pair's first wave owns the pair's edge scratch and prediction
-          LDS uint16_t *ppred = SL->dcp;                        // (dcp is idle during the trial)
-          const bool dirm = best_mode >= V_PRED && best_mode <= D67_PRED;
-          const bool uses_ar = dirm && mode_angle_of(best_mode) + 3 * best_delta < 90;
-          const int nslot = G == 4 ? 10 : (uses_ar ? 4 : 3);
+          // 4x4 / 8x8 sub-blocks: one CHAIN per transform type (rav1e rdo_tx_type_decision: the whole block with one type), each on a 16-lane row: the row prepares its
+          // sub-block's raw edges from its own chain's reconstructions, predicts it, evaluates it with its type, keeps reconstruction / levels / contexts in the chain's
+          // state and moves on -- no workgroup barrier until every chain is through.  Five types (the reduced set): the four DCT / ADST combinations on wave 0's rows,
+          // IDTX alone on wave 1 (a wave whose rows mix identity, DCT and ADST walks all three 1-D networks); up to eight types: four per wave on waves 0 and 1.  The
+          // chains' state lies in the scratch of waves 2 / 3, which have nothing to do here.  A chain whose running cost reaches the best so far (or the caller's
+          // budget) is dead: its row runs on harmlessly while another row of the wave is alive.  (Until round 6 every sub-block picked its own type: slots of
+          // predict -> barrier -> evaluate -> barrier -> pick + copy -> barrier, profiles/r05i_k1_phase_profile.txt: 13 % of the kernel in those barriers.)
+          constexpr int CH_BYTES = nn * 2 + G * G * sqn * 4 + G * G * 4;     // a chain: the block's reconstruction, the sub-blocks' levels, eob | cul << 16 | dcc << 24 per sub-block
+          static_assert(4 * CH_BYTES <= (int)sizeof(WaveScratch<MAXN>) && hnn <= 64 && 4 * 64 <= MAXN * MAXN, "four chains fit a wavefront's scratch; edges and predictions of four rows fit pred / dcp");
+          const int g = GROUP_ID, gl = GROUP_LANE;
+          const int e = sntx == 5 ? (W == 0 ? g + 1 : ((W == 1 && g == 0) ? 0 : 64)) : W * 4 + g;      // this row's transform type (symbol)
+          const bool has_chain = e < sntx, wave_has = sntx == 5 ? W < 2 : W * 4 < sntx;                   // row-uniform, wave-uniform
+          LDS long long *const cres_j = (LDS long long *)SH->cj;                                          // [8] complete chains' costs (the chroma costs' place: dead during luma)
+          LDS int *const cres_any = (LDS int *)(cres_j + 8);                                              // [8]
+          const long long thr = uni64(luma_j < budget ? luma_j : budget);                                // a chain at or above it can neither win nor keep the block below the budget
+          if (wave_has) {
+            // wave-uniform inputs of the chain loop, made scalar: the loop's many divergent regions (row-local edge loops, per-row contexts) otherwise carry them in VGPRs
+            const int x = uni32(x_), y = uni32(y_), r = uni32(r_), c = uni32(c_), availU = uni32(availU_), availL = uni32(availL_), have_ar = uni32(have_ar_), have_bl = uni32(have_bl_);
+            const int best_mode = uni32(best_mode_), best_delta = uni32(best_delta_), ftype_y = uni32(ftype_y_);
+            LDS uint8_t *cst = (LDS uint8_t *)k.wave(2 + W) + g * CH_BYTES;
+            LDS uint16_t *canvas = (LDS uint16_t *)cst; LDS int32_t *cqc = (LDS int32_t *)(cst + nn * 2); LDS uint32_t *cmeta = (LDS uint32_t *)(cst + nn * 2 + G * G * sqn * 4);
+            LDS uint16_t *A = S->pred + g * 64 + EDGE_OFF, *Lf = A + 32, *ppred = S->dcp + g * 64;
+            int txtype;
+            if (sntx > 1) txtype = sym_to_txtype(stx_set, has_chain ? e : 0);
+            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+            const int tx_sym = stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0;
+            const bool dirm = best_mode >= V_PRED && best_mode <= D67_PRED;
+            const int pa = dirm ? mode_angle_of(best_mode) + 3 * best_delta : 0;
+            const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+            const uint16_t *grec = f->rec[0];
+            long long jc = has_chain ? j_split : J_INF;
+            int any = 0;
+            if (W == 0) __builtin_amdgcn_s_setprio(3);           // the wave with four chains is the workgroup's critical path (profiles/r05zh_*)
 #pragma unroll 1
-          for (int slot = 0; slot < nslot; slot++) {
-            if (j_split >= budget && luma_j >= budget) { tr_done_(); return true; }   // wave-uniform (see the one-at-a-time loop below)
-            if (!(j_split < luma_j)) break;
-            // the slot's sub-blocks: q0 for pair 0, q1 for pair 1 (-1: none)
-            int q0, q1;
-            if (G == 4) { const int lo = imax_(0, (slot - 2) >> 1), hi = imin_(3, slot >> 1); q0 = lo * 4 + slot - 2 * lo; q1 = lo + 1 <= hi ? (lo + 1) * 4 + slot - 2 * (lo + 1) : -1; }
-            else if (uses_ar) { q0 = slot; q1 = -1; }
-            else { q0 = slot == 0 ? 0 : (slot == 1 ? 1 : 3); q1 = slot == 1 ? 2 : -1; }
-            const int q = P == 0 ? q0 : q1, bi = q / G, bj = q % G;
-            const int sx = x + bj * hn, sy = y + bi * hn;
-            const int sU = availU || bi, sL = availL || bj;
-            // The pair's first wave carries the slot's serial chain (edges -> prediction -> four evaluations) while the other waves have a quarter of that or
-            // nothing: it takes issue priority on its SIMD over the waves other workgroups have there until its evaluations are in (-1 % K1, profiles/r05zh_*).
-            if (WP == 0 && q >= 0) __builtin_amdgcn_s_setprio(3);
-            if (WP == 0 && q >= 0) {
-              const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
-              const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
-              LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
-              const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
-              const uint16_t *grec = f->rec[0];
-              const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
-              auto px = [&](int ax, int ay) -> int {
-                const int xr = ax - x, yr = ay - y;
-                if (xr >= 0 && xr < n && yr >= 0 && yr < n) return (int)split_rec[yr * n + xr];
-                if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
-                if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
-                return (int)grec[(size_t)ay * rs + ax];
-              };
-              for (int i = LANE; i <= 2 * hn; i += 64) {
-                const bool corner = i == 2 * hn;
-                int a, l;
-                if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
-                if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
-                if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
-                if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+            for (int q = 0; q < G * G; q++) {
+              if (MI_BALLOT64(jc < thr) == 0ull) break;          // every chain of this wave is dead
+              const int bi = q / G, bj = q % G;
+              const int sx = x + bj * hn, sy = y + bi * hn;
+              const int sU = availU || bi, sL = availL || bj;
+              {
+                // raw edges of the sub-block (spec 7.11.2; load_edges with the samples taken from the block's raw edges, this chain's sub-blocks so far, or -- beyond the
+                // block's right / bottom edge -- the frame), 16 lanes per chain
+                const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
+                const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
+                const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
+                // (straight-line: one LDS load from a selected pointer per sample -- this chain's reconstructions, the block's raw above edge or its raw left edge --,
+                // the frame only for the rare samples right of / below the block)
+                auto px = [&](int ax, int ay) -> int {
+                  const int xr = ax - x, yr = ay - y;
+                  const bool in_blk = xr >= 0 && xr < n && yr >= 0 && yr < n, on_a = yr == -1 && xr >= -1 && xr < 2 * n, on_l = xr == -1 && yr >= 0 && yr < 2 * n;
+                  const LDS uint16_t *p = in_blk ? (const LDS uint16_t *)canvas + (yr * n + xr) : (on_a ? ra + xr : rl + (on_l ? yr : 0));
+                  int v = (int)*p;
+                  if (!(in_blk || on_a || on_l)) v = (int)grec[(size_t)ay * rs + ax];
+                  return v;
+                };
+#pragma unroll
+                for (int it = 0; it < (2 * hn + 16) / 16; it++) {
+                  const int i = gl + 16 * it;
+                  const bool act = i <= 2 * hn, corner = i == 2 * hn;
+                  const int ii = act ? i : 0;                     // (idle lanes compute a harmless sample)
+                  int a, l;
+                  if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + ii), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+                  if (sL) l = px(sx - 1, imin_(lim_l, sy + ii)); else l = px(sx, sU ? sy - 1 : sy);
+                  if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+                  if (act && corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; }
+                  if (act && !corner) { A[ii] = (uint16_t)a; Lf[ii] = (uint16_t)l; }
+                }
               }
               WAVE_SYNC();
-              predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, ppred);
-            }
-            PH(23);
-            WG_SYNC();
-            PH(24);
-            long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0;
-            if (q >= 0 && WP * 4 < sntx) {                       // wave-uniform: this wave has at least one live row
+              if (dirm) predict_dir_group<hn>(f, sx, sy, sL, sU, pa, ftype_y, A, Lf, &S->gpred[g], ppred);
+              else predict_nondir_group<hn>(best_mode, sL, sU, bd, A, Lf, ppred);
+              PH(23);
+              // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs): outer neighbours from the staged contexts, inner ones from this chain
               int ssc, sdc;
               {
                 int top = 0, left = 0, dcs = 0;
+                const uint32_t mt = bi ? cmeta[q - G] : 0u, ml = bj ? cmeta[q - 1] : 0u;
 #pragma unroll
                 for (int k2 = 0; k2 < half; k2++) {
                   int l, d;
-                  if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
+                  if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = (int)((mt >> 16) & 0xFF); d = (int)(mt >> 24); if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
                   top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-                  if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
+                  if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = (int)((ml >> 16) & 0xFF); d = (int)(ml >> 24); if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
                   left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
                 }
                 sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
@@ -797,152 +828,170 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
                 else ssc = 6;
               }
               constexpr int pcp = n >= 8 ? n / 8 : 1;
-              // five tx types (the reduced set): the four DCT / ADST combinations on the pair's first wave, IDTX alone on its second -- a wave whose
-              // rows mix identity, DCT and ADST walks all three 1-D networks one after the other under exec masks
-              const int g = GROUP_ID, e = sntx == 5 ? (WP == 0 ? g + 1 : (g == 0 ? 0 : 64)) : WP * 4 + g;
               const int psv_q = hn == 4 ? (n == 8 ? SH->psv4[q] : psv16[q]) : SH->psv[bi * pcp + bj];
               const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
-              const bool live = e < sntx;
-              int txtype;
-              if (sntx > 1) txtype = sym_to_txtype(stx_set, live ? e : 0);
-              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
               GroupRes gr;
-              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0,
-                             Tools<TS>::tune_psnr(f) ? -1 : psv_q, pact_q, &gr);
-              long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
-              if (!live) j = J_INF;
+              eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, tx_sym, Tools<TS>::tune_psnr(f) ? -1 : psv_q, pact_q, &gr);
+              if (has_chain) jc += rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
+              // the chain keeps the sub-block: reconstruction (the next sub-blocks' edges), levels, contexts
+              {
+                const LDS uint16_t *srec = S->grp[g].rec; const LDS int32_t *sqc = S->grp[g].qc;
+                const int ro = bi * hn * n + bj * hn;
 #pragma unroll
-              for (int gg = 0; gg < 4; gg++) {
-                const long long jg = ((long long)__builtin_amdgcn_readlane((int)(j >> 32), gg * 16) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)j, gg * 16);
-                const int eg = __builtin_amdgcn_readlane(e, gg * 16);
-                if (jg < sj || (jg == sj && eg < se)) {
-                  sj = jg; se = eg; sg = gg; stx = __builtin_amdgcn_readlane(txtype, gg * 16);
-                  s_eob = __builtin_amdgcn_readlane(gr.eob, gg * 16); s_cul = __builtin_amdgcn_readlane(gr.cul, gg * 16); s_dcc = __builtin_amdgcn_readlane(gr.dcc, gg * 16);
+                for (int i = gl; i < hnn; i += 16) canvas[ro + (i / hn) * n + (i % hn)] = srec[i];
+#pragma unroll
+                for (int i = gl; i < sqn; i += 16) cqc[q * sqn + i] = sqc[i];
+                cmeta[q] = (uint32_t)gr.eob | ((uint32_t)gr.cul << 16) | ((uint32_t)gr.dcc << 24);      // (row-uniform: every lane of the row stores the same word)
+              }
+              any |= gr.eob > 0;
+              WAVE_SYNC();
+              PH(25);
+            }
+            // (a loop that ended early left every chain of the wave at or above thr; one that ran through left complete costs)
+            // Every lane stores, rows without a chain into a slot nobody reads: NO divergent region may end together with this wave-level one.  With
+            // `if (gl == 0 && has_chain) { ... }` as the region's last statement hipcc (ROCm 7.2) narrows EXEC for the inner `if` without saving it (the outer
+            // region's restore follows anyway) and then places rematerialised VALU instructions and spill reloads of LATER code between the two -- computed in
+            // lane 0 of each row only (seen on gfx950: the row index of the next trial's edge buffers; the CPU emulator cannot see it).
+            const int slot = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g;
+            cres_j[slot] = (has_chain && jc < thr) ? jc : J_INF; cres_any[slot] = any;
+          }
+          __builtin_amdgcn_s_setprio(0);
+          WG_SYNC();
+          PH(26);
+          int be = -1; long long bjc = J_INF;
+          for (int e2 = 0; e2 < sntx; e2++) { const long long v = cres_j[e2]; if (v < bjc) { bjc = v; be = e2; } }     // the cheapest complete chain, the lowest symbol among equals
+          j_split = bjc;
+          if (be >= 0) {                                          // (uniform over the workgroup: LDS values) the winner's state -> the block's split buffers, for the commit below
+            const int ow = sntx == 5 ? (be == 0 ? 1 : 0) : be >> 2, og = sntx == 5 ? (be == 0 ? 0 : be - 1) : be & 3;
+            if (W == ow) {
+              const LDS uint8_t *cst = (const LDS uint8_t *)k.wave(2 + W) + og * CH_BYTES;
+              const LDS uint16_t *canvas = (const LDS uint16_t *)cst; const LDS int32_t *cqc = (const LDS int32_t *)(cst + nn * 2); const LDS uint32_t *cmeta = (const LDS uint32_t *)(cst + nn * 2 + G * G * sqn * 4);
+              for (int i = LANE; i < nn; i += 64) split_rec[i] = canvas[i];
+              for (int i = LANE; i < G * G * sqn; i += 64) split_qc[i] = cqc[i];
+              int btx;
+              if (sntx > 1) btx = sym_to_txtype(stx_set, be);
+              else { btx = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, btx) < 0) btx = DCT_DCT; }
+              if (LANE < G * G) { const uint32_t m = cmeta[LANE]; const int eob = (int)(m & 0xFFFF); sub_eob[LANE] = eob; sub_cul[LANE] = (int)((m >> 16) & 0xFF); sub_dcc[LANE] = (int)(m >> 24); sub_tx[LANE] = eob ? btx : DCT_DCT; }
+            }
+            sub_any = cres_any[be];
+            WG_SYNC();
+          }
+          PH(27);
+        } else {
+          // larger sub-blocks: one chain per wavefront and round (transform type rd * NW + W), every wave on its own -- raw edges from its chain's reconstructions,
+          // prediction, evaluation, all in its private scratch (canvas = rec[1], levels = qc[1], prediction = dcp) --, a barrier only between rounds: the best
+          // complete chain so far moves into the block's split buffers, the next round's chains must beat it (a later type never wins a tie).
+          static_assert(nn <= (int)(sizeof(S->rec[1]) / 2) && G * G * sqn <= (int)(sizeof(S->qc[1]) / 4) && G * G <= 16, "a chain's state fits the wave's second candidate buffers");
+          LDS uint16_t *canvas = S->rec[1]; LDS int32_t *cqc = S->qc[1]; LDS uint32_t *cmeta = (LDS uint32_t *)SH->cj + W * 16;
+          LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
+          LDS int *ppsv = (LDS int *)S->etmp, *ppact = ppsv + 16;           // (etmp is predict_block's temporary: free between two predictions)
+          static_assert(sizeof(S->etmp) >= 32 * sizeof(int), "the sub-block's psychovisual references fit etmp");
+          const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
+          const uint16_t *grec = f->rec[0];
+          const long long j0 = j_split;
+          long long best_chain = J_INF;
+          sub_any = 0;
+#pragma unroll 1
+          for (int rd = 0; rd * NW < sntx; rd++) {
+            const int e = rd * NW + W;
+            const bool has_chain = e < sntx;
+            long long thr = luma_j < budget ? luma_j : budget;
+            if (best_chain < thr) thr = best_chain;
+            int txtype;
+            if (sntx > 1) txtype = sym_to_txtype(stx_set, has_chain ? e : 0);
+            else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
+            const int tx_sym = stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0;
+            long long jc = has_chain ? j0 : J_INF;
+            int any = 0;
+            if (has_chain) {
+#pragma unroll 1
+              for (int q = 0; q < G * G; q++) {
+                if (!(jc < thr)) break;                          // wave-uniform
+                const int bi = q / G, bj = q % G;
+                const int sx = x + bj * hn, sy = y + bi * hn;
+                const int sU = availU || bi, sL = availL || bj;
+                {
+                  const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
+                  const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
+                  const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
+                  auto px = [&](int ax, int ay) -> int {                  // absolute sample position -> value
+                    const int xr = ax - x, yr = ay - y;
+                    if (xr >= 0 && xr < n && yr >= 0 && yr < n) return (int)canvas[yr * n + xr];
+                    if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
+                    if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
+                    return (int)grec[(size_t)ay * rs + ax];
+                  };
+                  for (int i = LANE; i <= 2 * hn; i += 64) {
+                    const bool corner = i == 2 * hn;
+                    int a, l;
+                    if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
+                    if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
+                    if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
+                    if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
+                  }
+                  WAVE_SYNC();
+                  predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, S->dcp);
                 }
+                PH(23);
+                // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs): outer neighbours from the staged contexts, inner ones from this chain
+                int ssc, sdc;
+                {
+                  int top = 0, left = 0, dcs = 0;
+                  const uint32_t mt = bi ? cmeta[q - G] : 0u, ml = bj ? cmeta[q - 1] : 0u;
+#pragma unroll
+                  for (int k2 = 0; k2 < half; k2++) {
+                    int l, d;
+                    // (a 32x32 block may reach past the frame's last 8x8 column / row: the oracle's av1o_txb_ctx leaves out neighbour cells beyond the frame; smaller blocks never do)
+                    if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = (int)((mt >> 16) & 0xFF); d = (int)(mt >> 24); if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
+                    top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+                    if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = (int)((ml >> 16) & 0xFF); d = (int)(ml >> 24); if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
+                    left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
+                  }
+                  sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+                  if (top == 0 && left == 0) ssc = 1;
+                  else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
+                  else if (imax_(top, left) <= 3) ssc = 4;
+                  else if (imin_(top, left) <= 3) ssc = 5;
+                  else ssc = 6;
+                }
+                // psychovisual references of the sub-block: its own variance (4x4) or its 8x8 cells', and the activity of the 8x8 cells it lies in
+                constexpr int pcp = n >= 8 ? n / 8 : 1, scp = hn >= 8 ? hn / 8 : 1;
+                if (LANE < scp * scp) {
+                  if constexpr (hn == 4) { ppsv[0] = n == 8 ? SH->psv4[q] : psv16[q]; ppact[0] = SH->pact[(bi >> 1) * pcp + (bj >> 1)]; }
+                  else { const int pc = (bi * scp + LANE / scp) * pcp + bj * scp + LANE % scp; ppsv[LANE] = SH->psv[pc]; ppact[LANE] = SH->pact[pc]; }
+                }
+                WAVE_SYNC();
+                TxRes tr;
+                jc += eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, S->dcp, txtype, stx_off, tx_sym, S->rec[0], S->qc[0], &tr, ssrc + q * hnn, (const LDS int *)ppsv, (const LDS int *)ppact);
+                {
+                  const int ro = bi * hn * n + bj * hn;
+                  for (int i = LANE; i < hnn; i += 64) canvas[ro + (i / hn) * n + (i % hn)] = S->rec[0][i];
+                  for (int i = LANE; i < sqn; i += 64) cqc[q * sqn + i] = S->qc[0][i];
+                  if (LANE == 0) cmeta[q] = (uint32_t)tr.eob | ((uint32_t)tr.cul << 16) | ((uint32_t)tr.dcc << 24);
+                }
+                any |= tr.eob > 0;
+                WAVE_SYNC();
+                PH(25);
               }
             }
-            if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
-            __builtin_amdgcn_s_setprio(0);
-            PH(25);
+            if (LANE == 0) { SH->wbest_j[W] = jc < thr ? jc : J_INF; SH->wbest_e[W] = any; }
             WG_SYNC();
             PH(26);
-            // each pair's winner (lower cost, then lower symbol) keeps its reconstruction and levels in LDS
-            const int w0 = (SH->wbest_j[1] < SH->wbest_j[0] || (SH->wbest_j[1] == SH->wbest_j[0] && SH->wbest_e[1] < SH->wbest_e[0])) ? 1 : 0;
-            const int w1 = (SH->wbest_j[3] < SH->wbest_j[2] || (SH->wbest_j[3] == SH->wbest_j[2] && SH->wbest_e[3] < SH->wbest_e[2])) ? 3 : 2;
-            const long long sub_j0 = SH->wbest_j[w0], sub_j1 = q1 >= 0 ? SH->wbest_j[w1] : 0;
-            if (q >= 0 && W == (P == 0 ? w0 : w1)) {
-              const LDS uint16_t *srec = S->grp[sg].rec; const LDS int32_t *sqc = S->grp[sg].qc;
-              const int ro = bi * hn * n + bj * hn;
-              for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
-              for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
-              if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
+            int sw = 0;
+            for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw]) sw = w2;          // the lowest wave = the lowest symbol among equals
+            const long long rj = SH->wbest_j[sw];
+            if (rj < best_chain) {                               // (thr made it strictly smaller than every earlier round's)
+              best_chain = rj; sub_any = SH->wbest_e[sw];
+              if (W == sw) {
+                for (int i = LANE; i < nn; i += 64) split_rec[i] = canvas[i];
+                for (int i = LANE; i < G * G * sqn; i += 64) split_qc[i] = cqc[i];
+                if (LANE < G * G) { const uint32_t m = cmeta[LANE]; const int eob = (int)(m & 0xFFFF); sub_eob[LANE] = eob; sub_cul[LANE] = (int)((m >> 16) & 0xFF); sub_dcc[LANE] = (int)(m >> 24); sub_tx[LANE] = eob ? txtype : DCT_DCT; }
+              }
             }
             WG_SYNC();
             PH(27);
-            sub_any |= sub_eob[q0] > 0;
-            if (q1 >= 0) sub_any |= sub_eob[q1] > 0;
-            j_split += sub_j0 + sub_j1;
           }
-        } else
-#pragma unroll 1
-        for (int q = 0; q < G * G; q++) {
-          // costs only grow: once the split can neither beat the best transform size so far nor stay below the caller's budget
-          // (then the best so far is above the budget too and the caller discards this block) the rest is skipped
-          if (j_split >= budget && luma_j >= budget) { tr_done_(); return true; }   // wave-uniform
-          if (!(j_split < luma_j)) break;
-          const int bi = q / G, bj = q % G;
-          const int sx = x + bj * hn, sy = y + bi * hn;
-          const int sU = availU || bi, sL = availL || bj;
-          if (W == 0) {
-            // raw edges of the sub-block (spec 7.11.2; load_edges with the samples taken from the block's raw edges, the sub-blocks
-            // reconstructed so far, or -- beyond the block's right / bottom edge -- the frame)
-            const int s_ar = bi == 0 ? (bj < G - 1 ? availU : have_ar) : (bj < G - 1 ? 1 : sfl_r[bi]);
-            const int s_bl = bj == 0 ? (bi < G - 1 ? availL : have_bl) : (bi < G - 1 ? 0 : sfl_b[bj]);
-            LDS uint16_t *A = S->pred + EDGE_OFF, *Lf = S->pred + (MAXN * MAXN / 2) + EDGE_OFF;
-            const int max_x = f->mi_cols * 4 - 1, max_y = f->mi_rows * 4 - 1, rs = f->stride, bd = f->bd;
-            const uint16_t *grec = f->rec[0];
-            const int lim_a = imin_(max_x, sx + (s_ar ? 2 * hn : hn) - 1), lim_l = imin_(max_y, sy + (s_bl ? 2 * hn : hn) - 1);
-            auto px = [&](int ax, int ay) -> int {                  // absolute sample position -> value
-              const int xr = ax - x, yr = ay - y;
-              if (xr >= 0 && xr < n && yr >= 0 && yr < n) return (int)split_rec[yr * n + xr];
-              if (yr == -1 && xr >= -1 && xr < 2 * n) return (int)ra[xr];
-              if (xr == -1 && yr >= 0 && yr < 2 * n) return (int)rl[yr];
-              return (int)grec[(size_t)ay * rs + ax];
-            };
-            for (int i = LANE; i <= 2 * hn; i += 64) {
-              const bool corner = i == 2 * hn;
-              int a, l;
-              if (sU) a = px(corner ? (sL ? sx - 1 : sx) : imin_(lim_a, sx + i), sy - 1); else a = px(sL ? sx - 1 : sx, sy);
-              if (sL) l = px(sx - 1, imin_(lim_l, sy + i)); else l = px(sx, sU ? sy - 1 : sy);
-              if (!sU && !sL) { a = corner ? (1 << (bd - 1)) : (1 << (bd - 1)) - 1; l = (1 << (bd - 1)) + 1; }
-              if (corner) { A[-1] = (uint16_t)a; Lf[-1] = (uint16_t)a; } else { A[i] = (uint16_t)a; Lf[i] = (uint16_t)l; }
-            }
-            WAVE_SYNC();
-            predict_block(f, sx, sy, log2w - D, sL, sU, best_mode, best_delta, ftype_y, A, Lf, wa, wl, S->etmp, spred);
-          }
-          PH(23);
-          WG_SYNC();
-          PH(24);
-          // all_zero / dc_sign contexts of the sub-block (txb_ctx_dev with bs != txs) from the staged neighbour contexts
-          int ssc, sdc;
-          {
-            int top = 0, left = 0, dcs = 0;
-#pragma unroll
-            for (int k2 = 0; k2 < half; k2++) {
-              int l, d;
-              // (a 32x32 block may reach past the frame's last 8x8 column / row: the oracle's av1o_txb_ctx leaves out neighbour cells beyond the frame; smaller blocks never do)
-              if (bi == 0) { l = SH->nb_top[bj * half + k2][0]; d = SH->nb_top[bj * half + k2][1]; } else { l = sub_cul[q - G]; d = sub_dcc[q - G]; if (n >= 32 && c + bj * half + k2 >= f->mi_cols) l = d = 0; }
-              top = imax_(top, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-              if (bj == 0) { l = SH->nb_left[bi * half + k2][0]; d = SH->nb_left[bi * half + k2][1]; } else { l = sub_cul[q - 1]; d = sub_dcc[q - 1]; if (n >= 32 && r + bi * half + k2 >= f->mi_rows) l = d = 0; }
-              left = imax_(left, l); dcs += d == 1 ? -1 : (d == 2 ? 1 : 0);
-            }
-            sdc = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
-            if (top == 0 && left == 0) ssc = 1;
-            else if (top == 0 || left == 0) ssc = 2 + (imax_(top, left) > 3);
-            else if (imax_(top, left) <= 3) ssc = 4;
-            else if (imin_(top, left) <= 3) ssc = 5;
-            else ssc = 6;
-          }
-          // psychovisual references of the sub-block: its own variance (4x4) or its 8x8 cells', and the activity of the 8x8 cells it lies in
-          constexpr int pcp = n >= 8 ? n / 8 : 1;
-          if (W == 0) {
-            constexpr int scp = hn >= 8 ? hn / 8 : 1;
-            if (LANE < scp * scp) {
-              if constexpr (hn == 4) { SH->spsv[0] = n == 8 ? SH->psv4[q] : psv16[q]; SH->spact[0] = SH->pact[(bi >> 1) * pcp + (bj >> 1)]; }
-              else { const int pc = (bi * scp + LANE / scp) * pcp + bj * scp + LANE % scp; SH->spsv[LANE] = SH->psv[pc]; SH->spact[LANE] = SH->pact[pc]; }
-            }
-          }
-          long long sj = J_INF; int se = 1 << 30, stx = DCT_DCT, s_eob = 0, s_cul = 0, s_dcc = 0, sg = 0, scur = 0;
-          {
-            WG_SYNC();                                           // spsv / spact staged by wave 0
-            for (int e = W; e < sntx; e += NW) {
-              int txtype;
-              if (sntx > 1) txtype = sym_to_txtype(stx_set, e);
-              else { txtype = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, txtype) < 0) txtype = DCT_DCT; }
-              TxRes tr;
-              const long long j = eval_tx<MAXN, SBS, NW>(k, 0, ssc, sdc, spred, txtype, stx_off, stx_off >= 0 ? txtype_to_sym(stx_set, txtype) : 0, S->rec[scur], S->qc[scur], &tr,
-                                                     ssrc + q * hnn, (const LDS int *)SH->spsv, (const LDS int *)SH->spact);
-              if (j < sj) { sj = j; se = e; stx = txtype; s_eob = tr.eob; s_cul = tr.cul; s_dcc = tr.dcc; scur ^= 1; }
-            }
-          }
-          if (LANE == 0) { SH->wbest_j[W] = sj; SH->wbest_e[W] = se; }
-          PH(25);
-          WG_SYNC();
-          PH(26);
-          int sw = 0;
-          for (int w2 = 1; w2 < NW; w2++) if (SH->wbest_j[w2] < SH->wbest_j[sw] || (SH->wbest_j[w2] == SH->wbest_j[sw] && SH->wbest_e[w2] < SH->wbest_e[sw])) sw = w2;
-          const long long sub_j = SH->wbest_j[sw];
-          if (W == sw) {                                         // the winner's reconstruction and levels stay in LDS
-            const LDS uint16_t *srec = S->rec[scur ^ 1]; const LDS int32_t *sqc = S->qc[scur ^ 1];
-            const int ro = bi * hn * n + bj * hn;
-            for (int i = LANE; i < hnn; i += 64) split_rec[ro + (i / hn) * n + (i % hn)] = srec[i];
-            for (int i = LANE; i < sqn; i += 64) split_qc[q * sqn + i] = sqc[i];
-            if (LANE == 0) { sub_eob[q] = s_eob; sub_cul[q] = s_cul; sub_dcc[q] = s_dcc; sub_tx[q] = s_eob ? stx : DCT_DCT; }
-          }
-          WG_SYNC();
-          PH(27);
-          sub_any |= sub_eob[q] > 0;
-          j_split += sub_j;
+          j_split = best_chain;
         }
         if (j_split < luma_j) {
           // this depth wins: its reconstruction, levels and contexts replace the best so far in the frame
@@ -1665,7 +1714,7 @@ template <int MAXN, int MAXBS, int BS, int NW> struct RdPart {
     }
     if (do_split) {
       int chain = !must_split && !DBG_IS(f, 11);      // the four trial results are in place until a sibling decides to split
-#pragma unroll
+      MI_K1_WALK_SPLIT_LOOP
       for (int q = 0; q < 4; q++)
       {
         const int rr = r + (q >> 1) * half, cc = c + (q & 1) * half;

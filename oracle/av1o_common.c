@@ -244,7 +244,11 @@ void av1o_select_quantizers(Av1oFrame *f) {
   int dc_qi0 = select_qi(ac_quant, dc);
   double log_ac = log2((double)ac_quant) - norm, log_dc = log2((double)dc[dc_qi0]) - norm;
   double log_base = 0.5 * (log_ac + log_dc);
-  double log_q = log_base - (33810170.0 / 86043287.0);     /* key frame */
+  /* (AV1O_SWEEP_KFQ=<thousandths>, AV1O_SWEEP_LAMBDA=<percent>, oracle only: the recalled key-frame offset and lambda scaled, for the constants sweep of BASELINE.md
+   * section 5 -- tools/constants_sweep.py; unset = 1000 / 100) */
+  const char *e_kf = getenv("AV1O_SWEEP_KFQ"), *e_lm = getenv("AV1O_SWEEP_LAMBDA");
+  const double kf_scale = e_kf ? atoi(e_kf) / 1000.0 : 1.0; const long lm_pct = e_lm ? atoi(e_lm) : 100;
+  double log_q = log_base - kf_scale * (33810170.0 / 86043287.0);     /* key frame */
   double x = log_q > 0 ? log_q : 0;
   double y = f->np == 1 ? 0.0 : x * (1.0 / 16 + 1.0 / 32 + 1.0 / 256);
   double off[3] = { 0.0, log2(7.0 / 4.0) - y, log2(5.0 / 4.0) - y };
@@ -262,7 +266,7 @@ void av1o_select_quantizers(Av1oFrame *f) {
   }
   /* lambda = ln2/6 * (q/8)^2 SSE per bit (rav1e), here in 1/128-SSE per 1/512-bit fixed point;
      planes are weighted by (q_y/q_p)^2 == rav1e dist_scale. */
-  for (int p = 0; p < f->np; p++) f->rdmult[p] = ((int64_t)qy * qy * 242273) >> 20;
+  for (int p = 0; p < f->np; p++) f->rdmult[p] = (((int64_t)qy * qy * 242273) >> 20) * lm_pct / 100;
   f->qctx = f->base_q_idx <= 20 ? 0 : (f->base_q_idx <= 60 ? 1 : (f->base_q_idx <= 120 ? 2 : 3));
 }
 

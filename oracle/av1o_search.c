@@ -88,15 +88,16 @@ static void fill_map(uint8_t *m, int ms, int r, int c, int n4, int v) { fill_map
  * can be measured.  0 / unset = this encoder's shipped behaviour (what HIP == oracle tests pin).  Read once per process.
  *   AV1O_ABL_SATD4=1        (round 6: closed) SATD of every block with 4x4 Hadamards, as rounds 1-5 shipped, instead of the 8x8 Hadamard for blocks of 8x8 and more (rav1e get_satd)
  *   AV1O_ABL_SEQ_TXTYPE=1   mode decision with each mode's default transform type, then the transform-type search on the winning mode only (instead of mode x type jointly)
- *   AV1O_ABL_ONE_TXTYPE=1   one transform type for all sub-blocks of a split transform (rav1e rdo_tx_size_type) instead of one per sub-block */
-enum { ABL_SATD4 = 1, ABL_SEQ_TXTYPE = 2, ABL_ONE_TXTYPE = 4 };
+ *   AV1O_ABL_SUB_TXTYPE=1   (round 6: closed) every sub-block of a split transform picks its own transform type, as rounds 1-5 shipped, instead of one type for the whole
+ *                           block per transform size (rav1e rdo_tx_size_type / rdo_tx_type_decision) */
+enum { ABL_SATD4 = 1, ABL_SEQ_TXTYPE = 2, ABL_SUB_TXTYPE = 4 };
 static int abl_flags(void) {
   static int cached = -1;                                     /* (a benign race: every thread computes the same value) */
   if (cached < 0) {
     int v = 0; const char *e;
     if ((e = getenv("AV1O_ABL_SATD4")) && e[0] == '1') v |= ABL_SATD4;
     if ((e = getenv("AV1O_ABL_SEQ_TXTYPE")) && e[0] == '1') v |= ABL_SEQ_TXTYPE;
-    if ((e = getenv("AV1O_ABL_ONE_TXTYPE")) && e[0] == '1') v |= ABL_ONE_TXTYPE;
+    if ((e = getenv("AV1O_ABL_SUB_TXTYPE")) && e[0] == '1') v |= ABL_SUB_TXTYPE;
     cached = v;
   }
   return cached;
@@ -270,8 +271,8 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
   }
   /* ---- luma transform size (rav1e rdo_tx_size_type; TX_MODE_SELECT, rdo_tx_depth = 2): the largest transform against the
    * transforms one and two levels smaller (tx_depth 1 and 2: 2x2 / 4x4 transform blocks in raster order), same prediction mode,
-   * each sub-block predicted from the reconstruction of the ones before it (spec transform_block) and free to pick its own tx
-   * type.  A depth is abandoned as soon as its running cost reaches the best so far; the frame buffers always hold the trial in
+   * each sub-block predicted from the reconstruction of the ones before it (spec transform_block), one tx type per depth for the
+   * whole block (below).  A depth is abandoned as soon as its running cost reaches the best so far; the frame buffers always hold the trial in
    * progress, the best split so far waits in a snapshot of the block's area. */
   int txs_final = bs, any_coef = best_tr.eob > 0;
   if (f->tx_mode_select && bs != BS_4) {
@@ -293,8 +294,10 @@ static int64_t try_block(Search *s, int r, int c, int bs) {
         int stx_ns, stx_set;
         const int stx_off = av1o_intra_tx_cdf(f, stx, best_mode, &stx_ns, &stx_set);
         const int sntx = stx_off >= 0 ? stx_ns : 1;
-        /* AV1O_ABL_ONE_TXTYPE: the depth is tried once per transform type with every sub-block forced to it; the best type's trial is repeated last so that the frame holds it */
-        const int one_tx = (abl_flags() & ABL_ONE_TXTYPE) && sntx > 1;
+        /* One transform type per block and transform size (rav1e rdo_tx_size_type: rdo_tx_type_decision runs over the whole block for each size): the depth is tried once per
+         * type with every sub-block forced to it -- a chain of sub-blocks each predicted from that chain's own reconstructions --, a chain is abandoned as soon as its running
+         * cost reaches the best so far, the cheapest complete chain (lowest symbol among equals) competes; its trial is repeated last so that the frame holds it. */
+        const int one_tx = !(abl_flags() & ABL_SUB_TXTYPE) && sntx > 1;
         int forced = -1, forced_best = 0; int64_t forced_best_j = INT64_MAX;
         const int64_t j_split0 = j_split;
         for (int ft = 0; ft < (one_tx ? sntx + 1 : 1); ft++) {

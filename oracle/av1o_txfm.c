@@ -109,7 +109,10 @@ int av1o_quantize(const int32_t *coef, int32_t *qc, int txs, int txtype, int dcq
   const int ls = txs == TX_32X32 ? 1 : (txs == TX_64X64 ? 2 : 0);
   uint16_t tmp[1024];
   const uint16_t *scan = av1o_scan(txs, txtype, tmp);
-  const int dc_off = dcq * 109 / 256, off0 = acq * 98 / 256, off1 = acq * 109 / 256, off_eob = acq * 88 / 256;
+  /* (AV1O_SWEEP_DZ=<percent>, oracle only: the recalled dead-zone offsets scaled, for the constants sweep of BASELINE.md section 5 -- tools/constants_sweep.py; unset = 100) */
+  static int dz_pct = -1;
+  if (dz_pct < 0) { const char *e = getenv("AV1O_SWEEP_DZ"); dz_pct = e ? atoi(e) : 100; }
+  const int dc_off = dcq * 109 * dz_pct / 25600, off0 = acq * 98 * dz_pct / 25600, off1 = acq * 109 * dz_pct / 25600, off_eob = acq * 88 * dz_pct / 25600;
   memset(qc, 0, sizeof(int32_t) * (size_t)nc);
   int64_t a0 = (int64_t)iabs(coef[0]) << ls;
   int l0 = (int)((a0 + dc_off) / dcq);

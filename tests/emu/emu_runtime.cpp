@@ -292,6 +292,10 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       // or silent corruption of a neighbouring workgroup's LDS)
       uint8_t *dyn[2] = { smem, k4_smem };
       if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) memset(dyn[q] + lds_bytes, 0xA5, 256);
+      // MI_EMU_LDS_POISON=seed: a workgroup starts with garbage in its LDS, as on the GPU (the emulator's arena otherwise holds zeros or the previous workgroup's data):
+      // a kernel that reads LDS it never wrote gives other bytes
+      static const char *poison = getenv("MI_EMU_LDS_POISON");
+      if (poison && lds_bytes > 0) { uint32_t x = (uint32_t)atoi(poison) * 2654435761u + (uint32_t)b * 40503u + 12345u; for (int q = 0; q < 2; q++) for (size_t i = 0; i < lds_bytes; i++) { x = x * 1664525u + 1013904223u; dyn[q][i] = (uint8_t)(x >> 24); } }
       spins = 0;
       run_block(w, (int)nthreads);
       if (lds_bytes > 0 && lds_bytes + 256 <= 160 * 1024) for (int q = 0; q < 2; q++) for (int i = 0; i < 256; i++) if (dyn[q][lds_bytes + i] != 0xA5) {

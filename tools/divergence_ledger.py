@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The divergence ledger: every deliberate difference between this encoder's search and rav1e's (as recalled), switched to rav1e's form ONE at a
-time in the CPU oracle (environment switches, oracle/av1o_search.c `abl_flag`, AV1O_LIVE_CDF, AV1O_NO_SEGMENTATION), against the only numbers the reference itself holds
+time in the CPU oracle (environment switches, oracle/av1o_search.c `abl_flags`, AV1O_LIVE_CDF, AV1O_NO_SEGMENTATION), against the only numbers the reference itself holds
 for this arithmetic -- the `encode8_opaque` payload ("~215 B", ravif/src/lib.rs:90) and the size windows of its three tests -- plus bytes / MSE on four 960x540 synthetic
 images at the headline settings.  It does not pin parity (rav1e cannot run here); it tells whoever runs scripts/compare_with_cavif.sh where to look first.
 Usage: python tools/divergence_ledger.py [--json out.json]   (oracle only, about two minutes)"""
@@ -9,10 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [('shipped (HIP == oracle)', {}),
             ('live CDFs in RDO (rav1e: adaptive rates)', {'AV1O_LIVE_CDF': '1'}),
             ('tx type searched after the mode decision', {'AV1O_ABL_SEQ_TXTYPE': '1'}),
-            ('one tx type per block (split transforms)', {'AV1O_ABL_ONE_TXTYPE': '1'}),
-            ('8x8 Hadamard SATD for blocks >= 8x8', {'AV1O_ABL_SATD8': '1'}),
             ('segmentation off', {'AV1O_NO_SEGMENTATION': '1'}),
-            ('all five together', {'AV1O_LIVE_CDF': '1', 'AV1O_ABL_SEQ_TXTYPE': '1', 'AV1O_ABL_ONE_TXTYPE': '1', 'AV1O_ABL_SATD8': '1', 'AV1O_NO_SEGMENTATION': '1'})]
+            ('the three open ones together', {'AV1O_LIVE_CDF': '1', 'AV1O_ABL_SEQ_TXTYPE': '1', 'AV1O_NO_SEGMENTATION': '1'}),
+            ('CLOSED in round 6, switched BACK: every sub-block of a split transform picks its own tx type (rounds 1-5)', {'AV1O_ABL_SUB_TXTYPE': '1'}),
+            ('CLOSED in round 6, switched BACK: 4x4-Hadamard SATD for every block size (rounds 1-5)', {'AV1O_ABL_SATD4': '1'}),
+            ('both closed ones switched back = the round-5 encoder', {'AV1O_ABL_SUB_TXTYPE': '1', 'AV1O_ABL_SATD4': '1'})]
 def run(env):
     code = (
         "import sys, json, io, numpy as np\nsys.path.insert(0, %r)\n"
