@@ -27,8 +27,14 @@
 #define MI_K1_WALK_INLINE __forceinline__
 // The loop over the four children of a split node: unrolled, the recursion's inlining multiplies the node's code by four per level (64 copies of the 8x8 node's body in the
 // 16x16 class: ~600 KB of code, 1127 SGPR spills in the kernel body); rolled (-DMI_K1_WALK_ROLLED=1), one copy per level.
+#ifndef MI_K1_PAIRED_CHAINS                             /* 0: one row per chain (16 / 4 serial steps per depth), tools/build_variant.sh A/B */
+#define MI_K1_PAIRED_CHAINS 1
+#endif
+#ifndef MI_K1_CHAIN_PRIO_WAVES
+#define MI_K1_CHAIN_PRIO_WAVES 1
+#endif
 #ifndef MI_K1_WALK_ROLLED
-#define MI_K1_WALK_ROLLED 0
+#define MI_K1_WALK_ROLLED 1
 #endif
 #if MI_K1_WALK_ROLLED
 #define MI_K1_WALK_SPLIT_LOOP _Pragma("unroll 1")
@@ -745,17 +751,32 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
           constexpr int CH_BYTES = nn * 2 + G * G * sqn * 4 + G * G * 4;     // a chain: the block's reconstruction, the sub-blocks' levels, eob | cul << 16 | dcc << 24 per sub-block
           static_assert(4 * CH_BYTES <= (int)sizeof(WaveScratch<MAXN>) && hnn <= 64 && 4 * 64 <= MAXN * MAXN, "four chains fit a wavefront's scratch; edges and predictions of four rows fit pred / dcp");
           const int g = GROUP_ID, gl = GROUP_LANE;
-          const int e = sntx == 5 ? (W == 0 ? g + 1 : ((W == 1 && g == 0) ? 0 : 64)) : W * 4 + g;      // this row's transform type (symbol)
-          const bool has_chain = e < sntx, wave_has = sntx == 5 ? W < 2 : W * 4 < sntx;                   // row-uniform, wave-uniform
+          // PAIRED chains (the 16x16 class with the reduced set's five types): a chain runs on TWO rows of one wave -- the skewed wavefront over the sub-block grid that the
+          // per-sub-block search of rounds 3-5 ran on two wave pairs (a sub-block needs its left neighbour and the row above up to its above-right neighbour: slot = bj + 2 bi,
+          // 10 slots for the 16 sub-blocks of a 4 x 4 grid; (0), (1, 2), (3) for a 2 x 2 grid whose prediction reads no above-right samples), now inside a chain: the
+          // pair's rows share the chain's state, a wave barrier orders the slots.  Types 1, 2 on wave 0, types 3, 4 on wave 1, IDTX on wave 2 (two rows, two idle); the
+          // chains' state: types 1..4 in wave 3's scratch, IDTX directly in the block's split buffers.  16 serial steps -> 10 slots, 4 -> 3.
+          const bool paired = MI_K1_PAIRED_CHAINS && MAXN == 16 && sntx == 5;
+          const int mem = paired ? (g & 1) : 0;                                                          // which sub-block of a slot this row takes
+          const int e = paired ? (W == 0 ? 1 + (g >> 1) : (W == 1 ? 3 + (g >> 1) : ((W == 2 && g < 2) ? 0 : 64)))
+                               : (sntx == 5 ? (W == 0 ? g + 1 : ((W == 1 && g == 0) ? 0 : 64)) : W * 4 + g);   // this row's transform type (symbol)
+          const bool has_chain = e < sntx, wave_has = paired ? W < 3 : (sntx == 5 ? W < 2 : W * 4 < sntx);  // row-uniform, wave-uniform
           LDS long long *const cres_j = (LDS long long *)SH->cj;                                          // [8] complete chains' costs (the chroma costs' place: dead during luma)
           LDS int *const cres_any = (LDS int *)(cres_j + 8);                                              // [8]
+          LDS uint32_t *const meta_idtx = (LDS uint32_t *)SH->cj + 32;                                    // [16] the paired IDTX chain's contexts
           const long long thr = uni64(luma_j < budget ? luma_j : budget);                                // a chain at or above it can neither win nor keep the block below the budget
+          // where chain `ce` of this trial keeps its state
+          auto chain_state = [&](int ce, int cw, int cg, LDS uint16_t **cv, LDS int32_t **cq, LDS uint32_t **cm) {
+            if (paired && ce == 0) { *cv = split_rec; *cq = split_qc; *cm = meta_idtx; return; }
+            LDS uint8_t *cst = paired ? (LDS uint8_t *)k.wave(3) + (ce >= 1 && ce <= 4 ? ce - 1 : 0) * CH_BYTES : (LDS uint8_t *)k.wave(2 + cw) + cg * CH_BYTES;
+            *cv = (LDS uint16_t *)cst; *cq = (LDS int32_t *)(cst + nn * 2); *cm = (LDS uint32_t *)(cst + nn * 2 + G * G * sqn * 4);
+          };
           if (wave_has) {
             // wave-uniform inputs of the chain loop, made scalar: the loop's many divergent regions (row-local edge loops, per-row contexts) otherwise carry them in VGPRs
             const int x = uni32(x_), y = uni32(y_), r = uni32(r_), c = uni32(c_), availU = uni32(availU_), availL = uni32(availL_), have_ar = uni32(have_ar_), have_bl = uni32(have_bl_);
             const int best_mode = uni32(best_mode_), best_delta = uni32(best_delta_), ftype_y = uni32(ftype_y_);
-            LDS uint8_t *cst = (LDS uint8_t *)k.wave(2 + W) + g * CH_BYTES;
-            LDS uint16_t *canvas = (LDS uint16_t *)cst; LDS int32_t *cqc = (LDS int32_t *)(cst + nn * 2); LDS uint32_t *cmeta = (LDS uint32_t *)(cst + nn * 2 + G * G * sqn * 4);
+            LDS uint16_t *canvas; LDS int32_t *cqc; LDS uint32_t *cmeta;
+            chain_state(e, W, g, &canvas, &cqc, &cmeta);
             LDS uint16_t *A = S->pred + g * 64 + EDGE_OFF, *Lf = A + 32, *ppred = S->dcp + g * 64;
             int txtype;
             if (sntx > 1) txtype = sym_to_txtype(stx_set, has_chain ? e : 0);
@@ -767,10 +788,19 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
             const uint16_t *grec = f->rec[0];
             long long jc = has_chain ? j_split : J_INF;
             int any = 0;
-            if (W == 0) __builtin_amdgcn_s_setprio(3);           // the wave with four chains is the workgroup's critical path (profiles/r05zh_*)
+            if (W < MI_K1_CHAIN_PRIO_WAVES) __builtin_amdgcn_s_setprio(3);   // the waves with four rows at work are the workgroup's critical path (profiles/r05zh_*)
+            const bool uses_ar = dirm && pa < 90;
+            const int nslot = paired ? (G == 4 ? 10 : (uses_ar ? 4 : 3)) : G * G;
 #pragma unroll 1
-            for (int q = 0; q < G * G; q++) {
+            for (int slot = 0; slot < nslot; slot++) {
               if (MI_BALLOT64(jc < thr) == 0ull) break;          // every chain of this wave is dead
+              // the slot's sub-blocks: q0 for the pair's first row, q1 for its second (-1: none; that row then repeats q0: same chain, same inputs, same stores)
+              int q0 = slot, q1 = -1;
+              if (paired) {
+                if (G == 4) { const int lo = imax_(0, (slot - 2) >> 1), hi = imin_(3, slot >> 1); q0 = lo * 4 + slot - 2 * lo; q1 = lo + 1 <= hi ? (lo + 1) * 4 + slot - 2 * (lo + 1) : -1; }
+                else if (!uses_ar) { q0 = slot == 0 ? 0 : (slot == 1 ? 1 : 3); q1 = slot == 1 ? 2 : -1; }
+              }
+              const int q = (mem == 1 && q1 >= 0) ? q1 : q0;
               const int bi = q / G, bj = q % G;
               const int sx = x + bj * hn, sy = y + bi * hn;
               const int sU = availU || bi, sL = availL || bj;
@@ -832,9 +862,17 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
               const int pact_q = hn == 4 ? SH->pact[(bi >> 1) * pcp + (bj >> 1)] : SH->pact[bi * pcp + bj];
               GroupRes gr;
               eval_group<hn>(k.cc(), k.cost(), k.ls(), f, &S->grp[g], ssrc + q * hnn, ppred, 0, SBS, txtype, ssc, sdc, stx_off, tx_sym, Tools<TS>::tune_psnr(f) ? -1 : psv_q, pact_q, &gr);
-              if (has_chain) jc += rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
-              // the chain keeps the sub-block: reconstruction (the next sub-blocks' edges), levels, contexts
               {
+                const long long j = rd_dist32(f, 0, gr.sse) + rd_rate32(f, gr.rate);
+                long long jslot = j;
+                if (paired) {                                    // both rows of a pair add both sub-blocks' costs: the chain's cost is the same number in either
+                  const long long jo = ((long long)__shfl((int)(j >> 32), LANE ^ 16) << 32) | (unsigned int)__shfl((int)j, LANE ^ 16);
+                  jslot = q1 >= 0 ? j + jo : (mem == 0 ? j : jo);
+                }
+                if (has_chain) jc += jslot;
+              }
+              // the chain keeps the sub-block: reconstruction (the next sub-blocks' edges), levels, contexts
+              if (has_chain) {
                 const LDS uint16_t *srec = S->grp[g].rec; const LDS int32_t *sqc = S->grp[g].qc;
                 const int ro = bi * hn * n + bj * hn;
 #pragma unroll
@@ -852,8 +890,9 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
             // `if (gl == 0 && has_chain) { ... }` as the region's last statement hipcc (ROCm 7.2) narrows EXEC for the inner `if` without saving it (the outer
             // region's restore follows anyway) and then places rematerialised VALU instructions and spill reloads of LATER code between the two -- computed in
             // lane 0 of each row only (seen on gfx950: the row index of the next trial's edge buffers; the CPU emulator cannot see it).
-            const int slot = sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g;
-            cres_j[slot] = (has_chain && jc < thr) ? jc : J_INF; cres_any[slot] = any;
+            if (paired) any |= __shfl(any, LANE ^ 16);
+            const int rslot = paired ? (has_chain ? e : 5 + (g & 1) + (W == 2 ? 0 : 0)) : (sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g);
+            cres_j[rslot] = (has_chain && jc < thr) ? jc : J_INF; cres_any[rslot] = any;
           }
           __builtin_amdgcn_s_setprio(0);
           WG_SYNC();
@@ -862,12 +901,14 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
           for (int e2 = 0; e2 < sntx; e2++) { const long long v = cres_j[e2]; if (v < bjc) { bjc = v; be = e2; } }     // the cheapest complete chain, the lowest symbol among equals
           j_split = bjc;
           if (be >= 0) {                                          // (uniform over the workgroup: LDS values) the winner's state -> the block's split buffers, for the commit below
-            const int ow = sntx == 5 ? (be == 0 ? 1 : 0) : be >> 2, og = sntx == 5 ? (be == 0 ? 0 : be - 1) : be & 3;
+            const int ow = paired ? 0 : (sntx == 5 ? (be == 0 ? 1 : 0) : be >> 2), og = sntx == 5 ? (be == 0 ? 0 : be - 1) : be & 3;
             if (W == ow) {
-              const LDS uint8_t *cst = (const LDS uint8_t *)k.wave(2 + W) + og * CH_BYTES;
-              const LDS uint16_t *canvas = (const LDS uint16_t *)cst; const LDS int32_t *cqc = (const LDS int32_t *)(cst + nn * 2); const LDS uint32_t *cmeta = (const LDS uint32_t *)(cst + nn * 2 + G * G * sqn * 4);
-              for (int i = LANE; i < nn; i += 64) split_rec[i] = canvas[i];
-              for (int i = LANE; i < G * G * sqn; i += 64) split_qc[i] = cqc[i];
+              LDS uint16_t *canvas; LDS int32_t *cqc; LDS uint32_t *cmeta;
+              chain_state(be, ow, og, &canvas, &cqc, &cmeta);
+              if (canvas != split_rec) {                         // (the paired IDTX chain already lives in the split buffers)
+                for (int i = LANE; i < nn; i += 64) split_rec[i] = canvas[i];
+                for (int i = LANE; i < G * G * sqn; i += 64) split_qc[i] = cqc[i];
+              }
               int btx;
               if (sntx > 1) btx = sym_to_txtype(stx_set, be);
               else { btx = mode_to_txtype(best_mode); if (stx_off < 0 || txtype_to_sym(stx_set, btx) < 0) btx = DCT_DCT; }
