@@ -201,19 +201,55 @@ def _aom_worker(jobs):
     return t0, time.time(), n, len(jobs)
 
 
+def host_cores():
+    """The CPUs this process can actually use: its affinity mask bounded by the cgroup CPU quota (v2 cpu.max along the process's cgroup path, v1 cfs quota) -- what Rust's
+    std::thread::available_parallelism(), and with it rayon::current_num_threads() of the reference, returns.  (The MI355X boxes of this pool show 256 logical CPUs and a
+    quota of 16: one worker per logical CPU ran 25 x slower per image than sixteen workers.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        path = ''
+        with open('/proc/self/cgroup') as fh:
+            for ln in fh:
+                if ln.startswith('0::'):
+                    path = ln.strip()[3:]
+        d = os.path.normpath('/sys/fs/cgroup/' + path.lstrip('/'))
+        while d.startswith('/sys/fs/cgroup'):
+            f = os.path.join(d, 'cpu.max')
+            if os.path.exists(f):
+                lim, per = open(f).read().split()[:2]
+                if lim != 'max' and int(per) > 0:
+                    q = int(lim) // int(per)
+                    quota = q if quota is None else min(quota, q)
+            if d == '/sys/fs/cgroup':
+                break
+            d = os.path.dirname(d)
+    except Exception:
+        pass
+    if quota is None:
+        try:
+            q, per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()), int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and per > 0:
+                quota = q // per
+        except Exception:
+            pass
+    return max(1, min(n, quota)) if quota is not None else max(1, n)
+
+
 def _pool_baseline(worker, w, h, speed, quality, depth, per_worker, kind, what):
-    """Image-parallel over ALL of the host's logical cores (what the reference's files.into_par_iter() does, src/main.rs:223): one worker process per core,
+    """Image-parallel over all the CPUs the host gives this process (host_cores(): affinity and cgroup quota -- what the reference's files.into_par_iter() fans out
+    over, src/main.rs:223): one worker process per core,
     `per_worker` images each.  The clock runs from the first worker's first encode to the last worker's last (process start, imports and the synthetic image
     generator are outside it)."""
     import multiprocessing as mp
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    cores = host_cores()
     chunks = [[(k * per_worker + i, w, h, speed, quality, depth) for i in range(per_worker)] for k in range(cores)]
     with mp.get_context('spawn').Pool(cores) as pool:
         res = pool.map(worker, chunks, chunksize=1)
     wall = max(r[1] for r in res) - min(r[0] for r in res)
     n = sum(r[3] for r in res)
     return {"value": round(n * w * h / 1e6 / wall, 4), "unit": "MPix/s", "cores": cores, "kind": kind,
-            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, %s, one process per logical core x %d images each, %.1f s from the first encode's start to the last one's end (%.1f s mean per image, %.0f bytes mean)"
+            "sample": "%d x %dx%d synthetic images, speed %d q%g depth %d, %s, one process per usable CPU (affinity and cgroup quota) x %d images each, %.1f s from the first encode's start to the last one's end (%.1f s mean per image, %.0f bytes mean)"
                       % (n, w, h, speed, quality, depth, what, per_worker, wall, sum(r[1] - r[0] for r in res) / n, sum(r[2] for r in res) / n)}
 
 
@@ -355,7 +391,7 @@ def main():
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
     ap.add_argument('--threads', type=int, default=0, help='ravif with_num_threads / cavif -j: T bounds the tile target (av1encoder.rs:665-668); 0 = unspecified (None): uncapped on a GPU')
     ap.add_argument('--no-threads-line', action='store_true', help='skip the secondary line at T = host cores (what `cavif -j0` would ask for on this box)')
-    ap.add_argument('--pipeline', type=int, default=2, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the other searches); 2 = what the product stream path keeps per image shape (MI_STREAM_SLOTS_DEFAULT, mi_avif.hip); since round 5 one, two and four slots measure the same (profiles/r05y_slots_sweep.txt)')
+    ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search). Measured on resident inputs, 20 steps (profiles/r06s_pipeline_sweep.txt): 1 slot 495.5, 2 slots 482.6, 3 slots 483.3, 4 slots 497.9 ... 502.7 MPix/s -- two or three slots interleave one search with the other slots\' filter / entropy kernels badly. The product stream path (mi_ravif_encode_stream, MI_STREAM_SLOTS_DEFAULT = 2) keeps two objects per image shape because on a 256-file job every further object costs 0.07 s of allocation, more than its overlap returns (profiles/r05zk_e2e_knobs.txt); its clock is the end_to_end line')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -508,7 +544,7 @@ def main():
                        "tile_target": ("T = %d threads (with_num_threads / cavif -j%d): target min(T, w*h/min_tile_size^2) -> %d tiles per image" % (args.threads, args.threads, batch.num_tiles() // B)) if args.threads > 0
                                       else "T = threads unspecified (ravif None): target w*h/min_tile_size^2 uncapped -> %d tiles per image" % (batch.num_tiles() // B),
                        "tools": "partition 4..16, 13 modes + angle deltas, tx-type + tx-size RDO (TX_MODE_SELECT), CfL, Tune::Psychovisual, deblock level search, CDEF search, sgrproj loop restoration (reduced sets)",
-                       "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU, each holding different images, driven in rotation" % (world, depth_q)},
+                       "parallelism": "images sharded across %d GPU(s), no collective; %d resident batch slot(s) per GPU, each holding different images, driven in rotation (the product's stream path keeps 2 per image shape: allocation time on a file job, see end_to_end; on resident inputs 1 / 2 / 3 / 4 slots measure 495 / 483 / 483 / 498-503 MPix/s, profiles/r06s_pipeline_sweep.txt)" % (world, depth_q)},
             "roofline": {"bound": "hbm", "kernel": "tile_search_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBS, 8),
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
@@ -537,7 +573,7 @@ def main():
         bt.close()
     if rank == 0:
         if world == 1 and not args.no_threads_line and B <= MANIFEST_IMAGES:
-            T = max(1, os.cpu_count() or 1)
+            T = host_cores()
             timgs = synth_images(w, h, list(range(B)))
             out["threads_host_cores"] = threads_line(m, T, timgs, B, w, h, args.speed, args.quality, args.depth, device, default_tiles=tiles_per_image)
             if T != 16:       # a host of 16 threads (what round 4's CPU baseline ran on): the regime where T does bound the tile target -- 16 tiles per 1080p image, 512 per launch

@@ -43,13 +43,43 @@ bool read_all(FILE *f, std::vector<uint8_t> &out) {
   while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.insert(out.end(), buf, buf + n);
   return !ferror(f);
 }
-// rayon::current_num_threads() of a default global pool: RAYON_NUM_THREADS when set, else std::thread::available_parallelism() -- the CPUs this process may
-// run on (its affinity mask; cgroup CPU quotas, which Rust also honours, are not looked at here)
+// rayon::current_num_threads() of a default global pool: RAYON_NUM_THREADS when set, else std::thread::available_parallelism() -- the CPUs this process may run on (its
+// affinity mask) bounded by the cgroup CPU quota (v2: cpu.max along the process's cgroup path; v1: cfs quota / period), integer division, at least one
+static long cgroup_cpu_quota() {
+  long quota = -1;
+  std::string path;
+  if (FILE *f = fopen("/proc/self/cgroup", "r")) {
+    char ln[4096];
+    while (fgets(ln, sizeof(ln), f)) if (!strncmp(ln, "0::", 3)) { path = ln + 3; while (!path.empty() && (path.back() == '\n' || path.back() == '\r')) path.pop_back(); }
+    fclose(f);
+  }
+  std::string d = "/sys/fs/cgroup" + (path.empty() || path[0] != '/' ? "/" + path : path);
+  while (d.size() > 1 && d.back() == '/') d.pop_back();
+  for (;;) {
+    if (FILE *f = fopen((d + "/cpu.max").c_str(), "r")) {
+      char lim[64]; long per = 0;
+      if (fscanf(f, "%63s %ld", lim, &per) == 2 && strcmp(lim, "max") != 0 && per > 0) { const long q = atol(lim) / per; if (quota < 0 || q < quota) quota = q; }
+      fclose(f);
+    }
+    if (d == "/sys/fs/cgroup" || d.size() <= strlen("/sys/fs/cgroup")) break;
+    d = d.substr(0, d.find_last_of('/'));
+  }
+  if (quota < 0) {
+    long q = -1, per = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%ld", &q) != 1) q = -1; fclose(f); }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%ld", &per) != 1) per = 0; fclose(f); }
+    if (q > 0 && per > 0) quota = q / per;
+  }
+  return quota;
+}
 int host_threads() {
   if (const char *e = getenv("RAYON_NUM_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
   cpu_set_t set; CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return CPU_COUNT(&set);
-  return (int)std::max(1u, std::thread::hardware_concurrency());
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+  const long q = cgroup_cpu_quota();
+  if (q >= 0) n = (int)std::min<long>(n, std::max<long>(q, 1));
+  return n;
 }
 int usage(const char *msg) {
   fprintf(stderr, "error: %s\nusage: cavif_mi [-Q quality 1-100] [-s speed 1-10] [-j threads] [-f|--overwrite] [-o path] [-q] [--dirty-alpha]\n"
@@ -230,7 +260,7 @@ int main(int argc, char **argv) {
     c->cv->notify_all();
   };
   std::vector<mi_encoded_image> enc_out(jobs.size()); std::vector<int> status(jobs.size(), MI_OK);
-  if (timing) fprintf(stderr, "[timing] setup %.3f s\n", now_s() - t_start);
+  if (timing) fprintf(stderr, "[timing] setup %.3f s (tile target bounded by %d threads)\n", now_s() - t_start, enc.threads);
   const size_t ndev_used = devices.empty() ? (size_t)std::max(1, mi_device_count()) : devices.size();      // brings the HIP runtime up while the loaders run
   const size_t nw_all = std::min<size_t>(files.size(), std::min<size_t>(loaders_cap, getenv("CAVIF_MI_LOADERS") ? nw : loaders_per_device * (ndev_used + 1)));
   { std::lock_guard<std::mutex> lk(mu); window = 4 * 32 * ndev_used + nw_all; }

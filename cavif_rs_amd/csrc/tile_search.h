@@ -30,8 +30,14 @@
 #ifndef MI_K1_PAIRED_CHAINS                             /* 0: one row per chain (16 / 4 serial steps per depth), tools/build_variant.sh A/B */
 #define MI_K1_PAIRED_CHAINS 1
 #endif
+#ifndef MI_K1_PAIRED_MIN_N                               /* the smallest block whose trial runs paired chains (8: every trial of the 16x16 class) */
+#define MI_K1_PAIRED_MIN_N 8
+#endif
+#ifndef MI_K1_PAIRED_MAX_HN                              /* the largest sub-block whose chains run paired (8: both depths of a 16x16 block) */
+#define MI_K1_PAIRED_MAX_HN 8
+#endif
 #ifndef MI_K1_CHAIN_PRIO_WAVES
-#define MI_K1_CHAIN_PRIO_WAVES 1
+#define MI_K1_CHAIN_PRIO_WAVES 0
 #endif
 #ifndef MI_K1_WALK_ROLLED
 #define MI_K1_WALK_ROLLED 1
@@ -756,7 +762,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
           // 10 slots for the 16 sub-blocks of a 4 x 4 grid; (0), (1, 2), (3) for a 2 x 2 grid whose prediction reads no above-right samples), now inside a chain: the
           // pair's rows share the chain's state, a wave barrier orders the slots.  Types 1, 2 on wave 0, types 3, 4 on wave 1, IDTX on wave 2 (two rows, two idle); the
           // chains' state: types 1..4 in wave 3's scratch, IDTX directly in the block's split buffers.  16 serial steps -> 10 slots, 4 -> 3.
-          const bool paired = MI_K1_PAIRED_CHAINS && MAXN == 16 && sntx == 5;
+          const bool paired = MI_K1_PAIRED_CHAINS && MAXN == 16 && sntx == 5 && n >= MI_K1_PAIRED_MIN_N && hn <= MI_K1_PAIRED_MAX_HN;
           const int mem = paired ? (g & 1) : 0;                                                          // which sub-block of a slot this row takes
           const int e = paired ? (W == 0 ? 1 + (g >> 1) : (W == 1 ? 3 + (g >> 1) : ((W == 2 && g < 2) ? 0 : 64)))
                                : (sntx == 5 ? (W == 0 ? g + 1 : ((W == 1 && g == 0) ? 0 : 64)) : W * 4 + g);   // this row's transform type (symbol)

@@ -33,7 +33,8 @@ typedef struct mi_av1_config {
   int32_t threads;          /* bounds the tile target min(threads, w*h / min_tile_size^2) (:665-668).  <= 0 = unspecified: the
                                reference then takes rayon::current_num_threads() (:666), i.e. the host's core count; a GPU has no
                                such number, so the target is left uncapped (1080p speed 4 -> 31, i.e. 32 tiles).  Pass the
-                               reference box's core count for an equal-tile comparison (cavif_mi -j N does). */
+                               host's core count to get the reference's tile split: the Rust binding of INTEGRATION.md and the
+                               cavif_mi command line do (no -j = this host's logical cores). */
   int8_t has_color_desc; uint8_t matrix, transfer, primaries;
   /* resolved SpeedTweaks (mi_av1_tweaks_from_preset fills them; callers may override) */
   uint8_t part_min, part_max, complex_pred_modes, sgr_full, encode_bottomup, rdo_tx_decision,

@@ -312,14 +312,15 @@ def test_wide_picture_beyond_4096_columns_of_4x4_cells(oracle):
 
 def test_cli_without_j_takes_the_host_core_count(tmp_path):
     """`threads: None` of the reference resolves to rayon::current_num_threads() = the host's logical cores (ravif/src/av1encoder.rs:665-668), and that bounds the tile
-    target.  cavif_mi without -j (and with -j0) == cavif_mi -jN == the library with with_num_threads(N), N = this process's CPUs; RAYON_NUM_THREADS overrides N as it
+    target.  cavif_mi without -j (and with -j0) == cavif_mi -jN == the library with with_num_threads(N), N = the CPUs this process can use (affinity mask and cgroup quota, `bench.host_cores()`); RAYON_NUM_THREADS overrides N as it
     does for rayon's global pool.  768x512 at speed 4 asks for min(N, 6) tiles: on hosts with fewer than six CPUs the bound is live."""
     Image = pytest.importorskip('PIL.Image')
     import cavif_rs_amd as m
     from cavif_rs_amd.synth import synth_image
     img = synth_image(768, 512, index=11)
     Image.fromarray(img, 'RGB').save(tmp_path / 'a.png')
-    n = len(os.sched_getaffinity(0))
+    import bench
+    n = bench.host_cores()                # affinity and cgroup quota: Rust's available_parallelism()
     outs = {}
     for name, args, env in (('none', [], {}), ('j0', ['-j0'], {}), ('jN', ['-j%d' % min(n, 255)], {}), ('rayon3', [], {'RAYON_NUM_THREADS': '3'}), ('j3', ['-j3'], {})):
         r = subprocess.run([CLI, '-f', '-q', '-o', str(tmp_path / (name + '.avif'))] + args + [str(tmp_path / 'a.png')], capture_output=True, env=dict(os.environ, **env))

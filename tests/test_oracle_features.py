@@ -218,3 +218,27 @@ def test_live_cdf_pricing_experiment_decodes_and_pays(oracle, avifdec):
     assert [x[0] for x in res['live']] != [x[0] for x in res['static']]                    # the switch switches
     assert sum(x[0] for x in res['live']) <= sum(x[0] for x in res['static'])              # and pays in bytes
     print('live-CDF pricing: bytes %s -> %s, SSE %s -> %s' % ([x[0] for x in res['static']], [x[0] for x in res['live']], [x[1] for x in res['static']], [x[1] for x in res['live']]))
+
+
+def test_closed_divergences_switch_back_to_the_round5_encoder():
+    """round 6 closed two deliberate differences from rav1e (8x8-Hadamard SATD for blocks >= 8x8, one transform type per block and depth in the
+    tx-size trial).  The oracle's switches AV1O_ABL_SATD4 / AV1O_ABL_SUB_TXTYPE turn them BACK one by one; both together must reproduce the round-5 encoder byte for byte
+    (sha256 of the round-5 golden vectors), each alone must differ from both -- the ledger's rows are what they say they are."""
+    import subprocess, sys, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib\nsys.path.insert(0, %r)\nfrom tests.helpers import oracle\nfrom tests.helpers.images import planes\nout = []\n"
+            "for (w, h, bd, sp, q, mono) in [(129, 101, 10, 4, 121, False), (200, 120, 10, 1, 121, False), (256, 200, 10, 4, 66, True)]:\n"
+            "    pl = planes(h, w, seed=w + h, bd=bd, mono=mono)\n"
+            "    r = oracle.encode_planes(oracle.make_config(w, h, bd, mono, q, sp), pl)\n"
+            "    out.append(hashlib.sha256(r['obu']).hexdigest())\nprint(json.dumps(out))\n") % root
+    def run(env):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    round5 = ['dbae4b1474128888215fffe6ce37addc16aa35a599660e63e5a74394ec65cda4', '85b80d378245b8941c31848c3c8d1ef095e704e85ab27b33c35d441f782181ce',
+              '570ff3d9f6756db1a2277bd25dcc1d23e54f3cf4fc5f7a6a6a03d29e50db0d08']
+    now, back = run({}), run({'AV1O_ABL_SATD4': '1', 'AV1O_ABL_SUB_TXTYPE': '1'})
+    assert back == round5
+    assert all(a != b for a, b in zip(now, round5))
+    satd4, sub = run({'AV1O_ABL_SATD4': '1'}), run({'AV1O_ABL_SUB_TXTYPE': '1'})
+    assert satd4 != now and satd4 != round5 and sub != round5

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=$(readlink -f gpurun_out); mkdir -p $OUT; export TMPDIR=/tmp
 ROOT=$(pwd)
 cd /tmp
-for P in 2 1; do
+for P in 4 1; do
   rm -rf /tmp/prof_$P
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$P -- python $ROOT/bench.py --steps 3 --warmup 1 --pipeline $P --no-cpu-baseline --no-pcie-loop --end-to-end 0 --no-threads-line > $OUT/${TAG}_bench_under_rocprof_pipeline$P.log 2>&1
   DB=$(find /tmp/prof_$P -name '*.db' | head -1)
