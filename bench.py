@@ -67,7 +67,7 @@ def valu_roofline(kernel, cfg, launch_ms, pixels):
                "frac": round(achieved / peak, 4), "lane_utilisation": round(thr / (64.0 * c['SQ_ACTIVE_INST_VALU']), 4),
                "valu_wave_instructions_per_launch": insts, "valu_wave_instructions_per_pixel": round(insts / pixels, 2),
                "counters_launch_ms": c.get('avg_launch_ms'), "launch_ms": round(launch_ms, 3),
-               "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks: on gfx950 the multiplies, compares, selects, min / max, left shifts, DPP, packed and dot forms and anything with an SGPR operand issue in ~4 clocks per wave, adds / logic / right shifts in ~2 (tools/probe/valu_rates.hip, profiles/r05_valu_rates.txt): frac 1.0 is reachable only by a kernel made of the first kind; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); counters from profiles/valu_counters.json (own rocprofv3 --pmc passes), launch time from this run"}
+               "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks: on gfx950 the multiplies, compares, selects, min / max, left shifts, DPP, packed and dot forms and anything with an SGPR operand issue in ~4 clocks per wave, adds / logic / right shifts in ~2 (tools/probe/valu_rates.hip, profiles/r05_valu_rates.txt, profiles/r06_valu_rates.txt: float min / max / compare are slow too): frac 1.0 is reachable only by a kernel made of the first kind; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); counters from profiles/valu_counters.json (own rocprofv3 --pmc passes), launch time from this run"}
         if 'SQ_WAIT_ANY' in c and 'SQ_WAVE_CYCLES' in c:
             out["wave_time_waiting"] = round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 4)
         if 'SQ_INSTS_SALU' in c:
@@ -549,7 +549,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBS, 8),
                          "traffic": hbm_traffic_bytes("tile_search_kernel", {"images_per_gpu": B, "width": w, "height": h, "speed": args.speed,
                                                                              "quality": args.quality, "bit_depth": args.depth}),
-                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, the partition walker's area snapshots, partial-line coefficient writes and the walker's register spills (profiles/r05_kernel_resources.txt: 464 B of scratch per lane in the kernel body, none worth mentioning in the block searches), served by L2 / Infinity Cache; not what limits the kernel -- see roofline_valu; TCP / TCC request, hit and stall counters of the same run: profiles/r05_final_pmc_summary.json",
+                         "traffic_note": "bytes per launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/hbm_counters.json (separate rocprofv3 --pmc passes); far above the algorithmic bytes: the search's own trial commits, the partition walker's area snapshots, partial-line coefficient writes and register spills (profiles/r06_kernel_resources.txt: 544 B of scratch per lane in the kernel, 80 ... 272 B of it in the block searches since the paired chains of round 6 -- profiles/r06u_k1_traffic_by_variant.txt attributes a third of the traffic to them), served by L2 / Infinity Cache; not what limits the kernel -- see roofline_valu; TCP / TCC request, hit and stall counters of the same run: profiles/r06_final_pmc_summary.json",
                          "frac_of_step": round(algo / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 8),
                          "frac_note": "frac = algorithmic bytes / the dominant kernel's launch time; frac_of_step = the same bytes / the driver-timed step (every kernel of the step: the 4 B/px RGB read belongs to the front-end kernel, the 6 B/px plane reads to the tile search)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(isolated_k1_ms, 3),
