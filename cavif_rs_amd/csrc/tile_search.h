@@ -745,6 +745,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
         }
         WG_SYNC();
         PH(22);
+        // (the block's wave-uniform geometry under second names: the chain loop below re-declares the first ones as scalars)
         [[maybe_unused]] const int x_ = x, y_ = y, r_ = r, c_ = c, availU_ = availU, availL_ = availL, have_ar_ = have_ar, have_bl_ = have_bl, best_mode_ = best_mode, best_delta_ = best_delta, ftype_y_ = ftype_y;
         if constexpr (SBS <= BS_8 && NW == 4 && MAXN <= 32) {
           // 4x4 / 8x8 sub-blocks: one CHAIN per transform type (rav1e rdo_tx_type_decision: the whole block with one type), each on a 16-lane row: the row prepares its
@@ -897,7 +898,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
             // region's restore follows anyway) and then places rematerialised VALU instructions and spill reloads of LATER code between the two -- computed in
             // lane 0 of each row only (seen on gfx950: the row index of the next trial's edge buffers; the CPU emulator cannot see it).
             if (paired) any |= __shfl(any, LANE ^ 16);
-            const int rslot = paired ? (has_chain ? e : 5 + (g & 1) + (W == 2 ? 0 : 0)) : (sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g);
+            const int rslot = paired ? (has_chain ? e : 5 + (g & 1)) : (sntx == 5 ? (W == 0 ? g + 1 : (g == 0 ? 0 : 4 + g)) : W * 4 + g);
             cres_j[rslot] = (has_chain && jc < thr) ? jc : J_INF; cres_any[rslot] = any;
           }
           __builtin_amdgcn_s_setprio(0);
