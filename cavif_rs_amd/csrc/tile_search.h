@@ -795,7 +795,7 @@ __device__ MI_K1_TRY_ATTR long long try_block(const Ctx<MAXN, NW, TS> k, int r, 
             const uint16_t *grec = f->rec[0];
             long long jc = has_chain ? j_split : J_INF;
             int any = 0;
-            if (W < MI_K1_CHAIN_PRIO_WAVES) __builtin_amdgcn_s_setprio(3);   // the waves with four rows at work are the workgroup's critical path (profiles/r05zh_*)
+            if (W < MI_K1_CHAIN_PRIO_WAVES) __builtin_amdgcn_s_setprio(3);   // off (0 waves): with chains, issue priority for the chain-carrying waves COSTS 1.4 % (profiles/r06p_ab_chain_priority.txt; it gained 1 % for round 5's slots)
             const bool uses_ar = dirm && pa < 90;
             const int nslot = paired ? (G == 4 ? 10 : (uses_ar ? 4 : 3)) : G * G;
 #pragma unroll 1
