@@ -33,8 +33,10 @@
 #ifndef MI_K1_PAIRED_MIN_N                               /* the smallest block whose trial runs paired chains (8: every trial of the 16x16 class) */
 #define MI_K1_PAIRED_MIN_N 8
 #endif
-#ifndef MI_K1_PAIRED_MAX_HN                              /* the largest sub-block whose chains run paired: 4 = the 4x4 sub-block chains (8x8 blocks, depth 2 of 16x16 blocks); with 8 as well the kernel is no faster and spills a tenth more (profiles/r06v_ab_pair_only_4x4.txt) */
-#define MI_K1_PAIRED_MAX_HN 4
+#ifndef MI_K1_PAIRED_MAX_HN                              /* the largest sub-block whose chains run paired: 8 = every grouped chain of the 16x16 class.  (With the build flags of the
+                                                           round's first half pairing the 8x8 sub-block chains bought nothing and spilled more -- profiles/r06v_ab_pair_only_4x4.txt --;
+                                                           with -sink-insts-to-avoid-spills / -disable-machine-licm it is worth 0.6 ms: profiles/r06_ab_switches_under_final_flags.txt) */
+#define MI_K1_PAIRED_MAX_HN 8
 #endif
 #ifndef MI_K1_CHAIN_PRIO_WAVES
 #define MI_K1_CHAIN_PRIO_WAVES 0
