@@ -5,7 +5,8 @@
 //                          symbols are written by all lanes at once (contexts depend on the level map only, exclusive scans place them);
 //   adapters (MI_K4_ADAPTERS waves)  own disjoint sets of CDF rows (a row's state depends only on the symbols coded through that row, never on
 //                          the coder state): each turns ITS records into bounds records in place (read the row, pick fl / fh, adapt);
-//   coder (last wave)      does nothing but the range arithmetic and the byte output over the finished records.
+//   coder (last wave)      runs the range recurrence of the finished records on the scalar unit and leaves `low` -- a sum -- to its 64 lanes: prefix sum of the
+//                          shifts, every symbol's contribution added into a ring of byte accumulators in LDS (RangeEncDev below).
 // While the coder works on superblock k the adapters convert k + 1 and the producer writes k + 2; one workgroup barrier per superblock.
 // A tile's serial chain used to be ~100 instructions per symbol on one wave (a lone wave issues a dependent instruction every ~7 cycles:
 // 46 ms per 1080p tile); it is now the busiest stage's share.
@@ -15,44 +16,35 @@
 #include "dev_rate.h"
 #include "restoration.h"
 
+// The coder's state.  An AV1 range coder keeps two things: the 16-bit range, whose next value depends on the symbol before it -- a serial chain --, and `low`,
+// which is nothing but a sum: symbol i adds delta_i = rng_i - u_i at the bit position the window stands at, T_i = the normalisation shifts d_k of all symbols before
+// it.  The tile's bytes are the big number  L = sum_i delta_i * 2^-T_i  written from bit 14 downwards (libaom od_ec_enc: cnt starts at -9, the first byte leaves when
+// 17 window bits are there).  So the wave's scalar unit runs the range recurrence only (k4_rng_step: 19 instructions per symbol, nothing about `low`, no flush branch)
+// and drops (delta, d) into lane j of two vector registers; the 64 lanes then place the chunk's deltas at once: prefix sum of d -> bit offset -> three byte slices
+// added into a ring of byte accumulators in LDS (ds_add).  Accumulators below the window are final and leave as the pre-carry units re_finish_dev resolves
+// (a unit = its own low byte + what the two accumulators after it hold above their low bytes, so that a unit's carry part stays below 2^8).
+#define MI_K4_ACC 256                      /* ring entries: a chunk of 64 symbols moves the window by at most 64 * 15 bits = 120 bytes */
 struct RangeEncDev {
-  uint16_t *pre; uint32_t cap, offs;     // pre-carry units in HBM; offs counts every unit flushed so far, stored or not (overflow <=> the total exceeds cap)
-  uint32_t low; uint32_t rng; int cnt;   // low stays below 2^31: 16 + cnt + 9 + d bits, flushed whenever cnt + d >= 0
-  int ov, on;                            // the last `on` (< 64) units, lane k of `ov` = unit k: a select per unit, one coalesced store per 64
+  uint16_t *pre; uint32_t cap;           // pre-carry units in HBM (one per output byte: byte + carry part), stored while below cap
+  uint32_t rng;                          // the range, 2^15 <= rng < 2^16 (wave-uniform: an SGPR)
+  uint32_t tbits;                        // T: bits the window has moved so far
+  uint32_t flushed;                      // units handed to `pre` so far (stored or not: overflow <=> the total exceeds cap)
+  LDS uint32_t *acc;                     // byte k of the stream accumulates in acc[k & (MI_K4_ACC - 1)]
 };
-
-__device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap) {
-  e->pre = pre; e->cap = cap; e->offs = 0; e->low = 0; e->rng = 0x8000; e->cnt = -9; e->ov = 0; e->on = 0;
+__device__ __forceinline__ void re_init_dev(RangeEncDev *e, uint16_t *pre, uint32_t cap, LDS uint32_t *acc) {
+  e->pre = pre; e->cap = cap; e->rng = 0x8000; e->tbits = 0; e->flushed = 0; e->acc = acc;
 }
-__device__ __forceinline__ void re_flush_units(RangeEncDev *e) {          // whole wave
-  const uint32_t at = e->offs + (uint32_t)LANE;
-  if (LANE < e->on && at < e->cap) e->pre[at] = (uint16_t)e->ov;
-  e->offs += (uint32_t)e->on; e->on = 0;
-}
-__device__ __forceinline__ void re_put16(RangeEncDev *e, uint32_t v) {     // wave-uniform v
-  e->ov = LANE == e->on ? (int)(v & 0xFFFFu) : e->ov;       // (v_writelane has no clang builtin: compare + select)
-  if (++e->on == 64) re_flush_units(e);
-}
-__device__ __forceinline__ void re_normalize_dev(RangeEncDev *e, uint32_t low, uint32_t rng) {
-  int c = e->cnt;
-  const int d = 16 - (32 - __clz(rng));
-  int s = c + d;
-  if (s >= 0) {
-    c += 16;
-    uint32_t m = (1u << c) - 1;
-    if (s >= 8) { re_put16(e, low >> c); low &= m; c -= 8; m >>= 8; }
-    re_put16(e, low >> c);
-    s = c + d - 24;
-    low &= m;
+// units [e->flushed, end): whole wave.  Unit k needs acc[k], acc[k + 1], acc[k + 2] final.
+__device__ __forceinline__ void re_flush_units(RangeEncDev *e, uint32_t end) {
+  for (uint32_t base = e->flushed; base < end; base += 64) {
+    const uint32_t k = base + (uint32_t)LANE;
+    const uint32_t a0 = e->acc[k & (MI_K4_ACC - 1)], a1 = e->acc[(k + 1) & (MI_K4_ACC - 1)], a2 = e->acc[(k + 2) & (MI_K4_ACC - 1)];
+    if (k < end && k < e->cap) e->pre[k] = (uint16_t)((a0 & 255u) + ((a1 >> 8) & 255u) + (a2 >> 16));
+    WAVE_SYNC();
+    if (k < end) e->acc[k & (MI_K4_ACC - 1)] = 0;
+    WAVE_SYNC();
   }
-  e->low = low << d; e->rng = rng << d; e->cnt = s;
-}
-// one symbol with the bounds fl (32768 for the first symbol of the alphabet) and fh; no branch: u = rng leaves `low` where it is
-__device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, uint32_t fh, int s, int nsyms) {
-  const uint32_t r = e->rng, r8 = r >> 8, nms = (uint32_t)(nsyms - 1 - s);
-  const uint32_t v = ((r8 * (fh >> 6)) >> 1) + 4u * nms;
-  const uint32_t u = fl < 32768u ? ((r8 * (fl >> 6)) >> 1) + 4u * nms + 4u : r;
-  re_normalize_dev(e, e->low + (r - u), u - v);
+  if (end > e->flushed) e->flushed = end;
 }
 // ---- symbol records ----
 //   adaptive symbol  bits 31..30 = 00: bits 0..15 the CDF row's offset, 16..19 the symbol, 20..23 alphabet size - 1;
@@ -86,12 +78,26 @@ __device__ __forceinline__ void re_encode_q15_dev(RangeEncDev *e, uint32_t fl, u
 #define MI_K4_TXB_RECORDS ((uint32_t)(1024 * 36 + 1024))
 // which adapter owns a CDF row: the low bits of its offset (the hot tables have strides 5 and 3: neighbouring contexts and the same context of
 // neighbouring transform sizes land on different waves)
+// MI_K4_SPREAD (measured, not kept): with two adapter waves the producer and the coder take rows as well -- owners 2 and 3: the producer turns its own rows' records
+// into bounds before it hands a buffer on, the coder right before it codes one (a row's state only depends on the symbols coded through it, in order, and each of
+// them meets the buffers in order).  After the coder lost its `low` arithmetic (RangeEncDev) the second adapter was the busiest stage of a long tile by a third
+// (12.8 ms against 7.5 / 9.5 / 8.7, profiles/r06k_k4_stage_profiles.txt); the table below -- owner by (context index + table block) & 7, fitted on the oracle's symbol
+// streams of two 1080p pictures -- evens the four stages out (all 8 ... 11 ms, profiles/r06m_k4s2_stage.txt), the bytes are the same, and the kernel is SLOWER:
+// 15.5 against 14.6 ms (profiles/r06l_*, r06m_*).  The four waves of a SIMD -- one stage of each of four tiles -- share its instruction issue: what the two extra
+// passes over every buffer add is paid by all of them, and a tile does not end sooner for being balanced.
+#ifndef MI_K4_SPREAD
+#define MI_K4_SPREAD 0
+#endif
+#ifndef MI_K4_SPREAD_LUT
+#define MI_K4_SPREAD_LUT 0x8704u                         /* 2 bits per bucket, bucket 0 first: 0 1 0 0 3 1 0 2 */
+#endif
 template <int NA> __device__ __forceinline__ int k4_row_owner(uint32_t row) {
   static_assert(NA == 2 || NA == 3 || NA == 4, "two, three or four adapters");
   // the parity (or the low two bits) of (context index + table block) of the stride-5 tables -- the coefficient base-level rows are 85 % of all
   // adaptive symbols and four of them (contexts 21 / 22 of the 16x16 luma and chroma blocks) carry 70 %; plain offset parity put 68 % of a 1080p
   // tile's symbols on one of two waves, this puts 53 ... 58 % there, and 35 ... 43 % on the busiest of four (measured on the oracle's symbol stream)
   if constexpr (NA == 3) return (int)((row / 5u + row / 210u) % 3u);
+  if constexpr (NA == 2 && MI_K4_SPREAD) return (int)((MI_K4_SPREAD_LUT >> (2u * ((row / 5u + row / 210u) & 7u))) & 3u);
   return (int)((row / 5u + row / 210u) & (uint32_t)(NA - 1));
 }
 // exclusive prefix sum over the 64 lanes (lane order), *total = the wave's sum
@@ -111,8 +117,10 @@ __device__ __forceinline__ unsigned long long k4_ballot(bool p) { return MI_BALL
 template <int NA> __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf, uint32_t *buf, int n_in, int a) {
   const int n = uni32(n_in), i = LANE;
   int row = -1, v = 0;
+  uint32_t nx = n > 0 ? buf[imin_(i, n - 1)] : 0u;
   for (int cb = 0; cb < n; cb += 64) {
-    const uint32_t rv = cb + i < n ? buf[cb + i] : 0x80000000u;
+    const uint32_t rv = cb + i < n ? nx : 0x80000000u;
+    if (cb + 64 < n) nx = buf[imin_(cb + 64 + i, n - 1)];                    // the next chunk's load flies behind this chunk's chain (its records of this adapter's rows are nobody else's to change)
     const bool mine = (rv >> 30) == 0u && k4_row_owner<NA>(rv & 0xFFFFu) == a;
     unsigned long long todo = k4_ballot(mine);
     uint32_t outv = rv;
@@ -149,55 +157,102 @@ template <int NA> __device__ __forceinline__ void k4_adapt_sb(LDS uint16_t *cdf,
     if (mine) buf[cb + i] = outv;
   }
 }
-// The coder over one superblock's finished records: range arithmetic and byte output only, on the scalar unit.
+// The coder over one superblock's finished records.
 #ifndef MI_SMUL32
 #define MI_SMUL32(r, a, b) asm("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b))
 #endif
+#ifndef MI_SSEL_GE                                       /* r = a >= b ? x : y on the scalar unit, both sides computed (as a C conditional the compiler makes it a branch around the multiply) */
+#define MI_SSEL_GE(r, a, b, x, y) asm("s_cmp_ge_u32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc")
+#endif
+#ifndef MI_WRITELANE                                     /* v_writelane_b32 has no clang builtin; a constant lane, a scalar value */
+#define MI_WRITELANE(v, s, lane) asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(lane))
+#endif
 __device__ __forceinline__ uint32_t k4_smul(uint32_t a, uint32_t b) { uint32_t r; MI_SMUL32(r, a, b); return r; }   // (the compiler would route a provably-24-bit uniform product through the vector unit)
+// One symbol of the range recurrence, all of it on the scalar unit: record J's bounds (fl >> 6, fh >> 6, 4 * (N - 1 - s): lane J of three registers) against the
+// range; what the symbol adds to `low` and how far it moves the window go to lane J of vdelta / vd.  libaom od_ec_encode_q15 + od_ec_enc_normalize without `low`.
+template <int J> __device__ __forceinline__ void k4_rng_step(uint32_t &rng, int vfl, int vfh, int vnm, int &vdelta, int &vd) {
+  const uint32_t fl6 = (uint32_t)__builtin_amdgcn_readlane(vfl, J), fh6 = (uint32_t)__builtin_amdgcn_readlane(vfh, J), nm = (uint32_t)__builtin_amdgcn_readlane(vnm, J);
+  const uint32_t r = rng, r8 = r >> 8, top = r - nm;
+  const uint32_t v = k4_smul(r8, fh6) >> 1;                                     // (the 4 * (N - 1 - s) of both bounds: inside `top`)
+  uint32_t u; MI_SSEL_GE(u, fl6, 512u, top, (k4_smul(r8, fl6) >> 1) + 4u);      // the first symbol of an alphabet: u = rng
+  const uint32_t nw = u - v, delta = top - u;
+  const int d = __builtin_clz(nw) - 16;                                          // (never 0: every symbol keeps a range of 4 at least)
+  rng = nw << d;
+  MI_WRITELANE(vdelta, delta, J); MI_WRITELANE(vd, d, J);
+}
+template <int J0> __device__ __forceinline__ void k4_rng_steps16(uint32_t &rng, int vfl, int vfh, int vnm, int &vdelta, int &vd) {
+  k4_rng_step<J0 + 0>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 1>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 2>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 3>(rng, vfl, vfh, vnm, vdelta, vd);
+  k4_rng_step<J0 + 4>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 5>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 6>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 7>(rng, vfl, vfh, vnm, vdelta, vd);
+  k4_rng_step<J0 + 8>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 9>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 10>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 11>(rng, vfl, vfh, vnm, vdelta, vd);
+  k4_rng_step<J0 + 12>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 13>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 14>(rng, vfl, vfh, vnm, vdelta, vd); k4_rng_step<J0 + 15>(rng, vfl, vfh, vnm, vdelta, vd);
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl(x, imax_(LANE - d, 0)); if (LANE >= d) x += t; }
+  return x;
+}
 __device__ __forceinline__ void k4_code_sb(RangeEncDev *e, const uint32_t *buf, int n_in) {
   const int n = uni32(n_in);
   uint32_t rv = n > 0 ? buf[imin_(LANE, n - 1)] : 0u;
+  uint32_t rng = e->rng;
   for (int cb = 0; cb < n; cb += 64) {
-    const uint32_t cur = rv;
-    if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
     const int m = imin_(64, n - cb);
-    // every record carries its bounds (the adapters turned the symbols into them, the producer wrote literal bits as such): three field
-    // extractions and the range arithmetic, one normalisation site
-    for (int j = 0; j < m; j++) {
-      const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)cur, j);
-      const uint32_t fl6 = rec & 1023u, fh6 = (rec >> 10) & 1023u, nms4 = (rec >> 18) & 60u;
-      const uint32_t r = e->rng, r8 = r >> 8;
-      const uint32_t v = (k4_smul(r8, fh6) >> 1) + nms4;
-      const uint32_t u = fl6 >= 512u ? r : (k4_smul(r8, fl6) >> 1) + nms4 + 4u;
-      re_normalize_dev(e, e->low + (r - u), u - v);
-    }
+    const uint32_t cur = LANE < m ? rv : K4_BOUNDS(512u, 0u, 0u);              // past the end: a symbol that leaves range and window where they are
+    if (cb + 64 < n) rv = buf[imin_(cb + 64 + LANE, n - 1)];                 // the next chunk's load flies behind this chunk's arithmetic
+    // every record carries its bounds (the adapters turned the symbols into them, the producer wrote literal bits as such)
+    const int vfl = (int)(cur & 1023u), vfh = (int)((cur >> 10) & 1023u), vnm = (int)((cur >> 18) & 60u);
+    int vdelta = 0, vd = 0;
+    k4_rng_steps16<0>(rng, vfl, vfh, vnm, vdelta, vd);
+    if (m > 16) k4_rng_steps16<16>(rng, vfl, vfh, vnm, vdelta, vd);
+    if (m > 32) k4_rng_steps16<32>(rng, vfl, vfh, vnm, vdelta, vd);
+    if (m > 48) k4_rng_steps16<48>(rng, vfl, vfh, vnm, vdelta, vd);
+    // the chunk's 64 additions to `low`, lane-parallel: symbol i's delta has its bit 0 at stream bit 14 + T_i (bit 0 = the top bit of byte 0)
+    const int incl = wave_incl_scan_i32(vd);
+    const uint32_t q = 14u + e->tbits + (uint32_t)(incl - vd), kk = q >> 3;
+    const uint32_t val = (uint32_t)vdelta << (7u - (q & 7u));                  // < 2^23: byte kk and the two above it
+    if (val & 255u) (void)__hip_atomic_fetch_add(e->acc + (kk & (MI_K4_ACC - 1)), val & 255u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((val >> 8) & 255u) (void)__hip_atomic_fetch_add(e->acc + ((kk - 1u) & (MI_K4_ACC - 1)), (val >> 8) & 255u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (val >> 16) (void)__hip_atomic_fetch_add(e->acc + ((kk - 2u) & (MI_K4_ACC - 1)), val >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    e->tbits += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+    WAVE_SYNC();
+    // later symbols reach byte ((14 + T) >> 3) - 2 at the highest: the units four and more below the window are final
+    const uint32_t kmin = (14u + e->tbits) >> 3;
+    if (kmin >= 4u && kmin - 4u > e->flushed) re_flush_units(e, kmin - 4u);
   }
+  e->rng = rng;
 }
 
-// Flushes the coder and resolves the carries of the pre-carry units into `out`; returns the number of bytes (0xFFFFFFFF: a buffer overflowed).
-// Whole wave: the 16-bit units form one big base-256 number (bits 8.. of a unit belong to the byte above it), normalised 64 units at a time from
+// Ends the stream (libaom od_ec_enc_done: low rounded up to a multiple of 2^14, bit 14 set, as many bytes as reach that bit) and resolves the carries of the
+// pre-carry units into `out`; returns the number of bytes (0xFFFFFFFF: a buffer overflowed).
+// Whole wave: the units form one big base-256 number (bits 8.. of a unit belong to the byte above it), normalised 64 units at a time from
 // the least significant end with a carry-lookahead scan over the lanes (generate: the byte sum reaches 256, propagate: it is 255) -- exactly the
 // bytes of the unit-by-unit loop `carry += pre[i]; out[i] = carry & 255; carry >>= 8` without its thousands of dependent global round trips.
 __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, uint32_t out_cap) {
-  unsigned long long l = e->low; int c = e->cnt; int s = 10;
-  const unsigned long long m = 0x3FFF;
-  unsigned long long x = ((l + m) & ~m) | (m + 1);
-  s += c;
-  if (s > 0) {
-    unsigned long long n = (1ULL << (c + 16)) - 1;
-    do {
-      const uint16_t u16 = (uint16_t)(x >> (c + 16));
-      re_put16(e, u16);
-      x &= n; s -= 8; c -= 8; n >>= 8;
-    } while (s > 0);
+  // the window's bit 0 stands at stream bit q = 14 + T, i.e. at bit sh of byte kend; V = what the stream holds from byte kend - 3 down (every accumulator there is
+  // still in the ring: re_flush_units stays five bytes behind the window).  Rounding up only adds: the difference goes into the ring like a symbol's delta.
+  const uint32_t q = 14u + e->tbits, kend = q >> 3, sh = 7u - (q & 7u);
+  {
+    unsigned long long V = 0;
+    for (uint32_t j = 0; j < 4; j++) if (kend >= j) V += (unsigned long long)e->acc[(kend - j) & (MI_K4_ACC - 1)] << (8 * j);
+    const unsigned long long A = 0x3FFFull << sh, B = 0x4000ull << sh;
+    const uint32_t add = (uint32_t)((((V + A) & ~(B - 1)) | B) - V);             // < 2^23
+    WAVE_SYNC();
+    if (LANE == 0) {
+      e->acc[kend & (MI_K4_ACC - 1)] += add & 255u;
+      e->acc[(kend - 1u) & (MI_K4_ACC - 1)] += (add >> 8) & 255u;
+      if (kend >= 2u) e->acc[(kend - 2u) & (MI_K4_ACC - 1)] += add >> 16;
+    }
+    WAVE_SYNC();
   }
-  re_flush_units(e);
-  const uint32_t nb = e->offs;
-  if (nb > e->cap || nb > out_cap) return 0xFFFFFFFFu;
+  const uint32_t nb = (e->tbits >> 3) + 1u, nu = kend + 1u;    // bytes of the tile; units down to the window's last byte (nb + 1 or nb + 2: the bytes past nb are zero once the carries are in)
+  re_flush_units(e, nu);
+  if (nu > e->cap || nb > out_cap) return 0xFFFFFFFFu;
   __threadfence();                                         // the unit stores, read back below in another lane order
   WAVE_SYNC();
   int cin = 0, ein = 0;                                    // carry into the chunk's last byte; the high bits of the unit right after the chunk
-  for (int top = (int)nb; top > 0; top -= 64) {            // lane i <-> unit top - 64 + i (lane 63 the least significant)
+  for (int top = (int)nu; top > 0; top -= 64) {            // lane i <-> unit top - 64 + i (lane 63 the least significant)
     const int idx = top - 64 + LANE;
     const int p = idx >= 0 ? (int)e->pre[idx] : 0;
     const int hi = p >> 8;
@@ -212,7 +267,7 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
     }
     const int gx = __shfl(G, imin_(LANE + 1, 63)), px = __shfl(P, imin_(LANE + 1, 63));
     const int ci = LANE == 63 ? cin : (gx | (px & cin));
-    if (idx >= 0) out[idx] = (uint8_t)(t + ci);
+    if (idx >= 0 && idx < (int)nb) out[idx] = (uint8_t)(t + ci);
     cin = __builtin_amdgcn_readlane(G | (P & cin), 0); ein = __builtin_amdgcn_readlane(hi, 0);
   }
   return nb;
@@ -221,10 +276,11 @@ __device__ __forceinline__ uint32_t re_finish_dev(RangeEncDev *e, uint8_t *out, 
 struct TileWriter {                                                 // the producer's state
   const FrameDev *f; TileB t;
   uint32_t *out; uint32_t n, cap;                                   // the current record buffer (HBM), records written so far, its capacity
-  uint32_t *bufs; LDS uint32_t *nrec; LDS int *total; int chunk;    // the three rotating buffers, their published counts, the number of buffers of the tile (-1 while unknown), the current one's index
+  uint32_t *bufs; LDS uint32_t *nrec; LDS int *total; int chunk;    // the ring of record buffers, their published counts, the number of buffers of the tile (-1 while unknown), the current one's index
   LDS int32_t *qc; LDS uint8_t *lev; const LDS uint16_t *ls;       // LDS staging + LDS copy of the scan tables
   LDS uint16_t *rec_off, *rec_br; LDS uint32_t *rec_lv;            // per-coefficient context rows / levels of the current transform block
   LDS int *lr_ref;                                                  // RefSgrXqd[plane][2]
+  LDS uint16_t *cdf; int own_rows;                                  // the tables; own_rows: the producer adapts the rows k4_row_owner gives it (owner 2)
   int cdef_pending;                                                 // the 64x64 superblock being walked has not signalled its cdef_idx yet
   int sb_cols_tile;
   // Frame scalars that steer the walk, pinned to SGPRs once per tile: every control value the walk loads (skip, modes, transform sizes, eob,
@@ -238,9 +294,18 @@ struct TileWriter {                                                 // the produ
 // the producer's emitters (wave-uniform arguments; lane 0 stores)
 __device__ __forceinline__ void k4_put(TileWriter *w, uint32_t rec) { if (LANE == 0 && w->n < w->cap) w->out[w->n] = rec; w->n++; }
 __device__ __forceinline__ void k4_sym(TileWriter *w, int s, int off, int ns) { k4_put(w, K4_REC(uni32(off), uni32(s), uni32(ns))); }
+// (one copy of the adapter loop for the producer's hand-off sites; the arguments by value: the writer's state stays in registers)
+__device__ __attribute__((noinline)) void k4_adapt_own_rows(LDS uint16_t *cdf, uint32_t *buf, int n, int owner) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the records were stored by other lanes of this wave
+  WAVE_SYNC();
+  k4_adapt_sb<2>(cdf, buf, n, owner);
+}
 // The producer hands its buffer to the adapters: publishes the count, meets the other stages at the workgroup barrier (they sit in the kernel's
 // stage loop; a barrier is a barrier wherever the wave executes it) and moves on to the next of the three buffers.  `last`: the tile ends here.
+// (Measured and not kept, profiles/r06n_*: a ring of six half-size buffers with release / acquire counters in LDS instead of the barrier -- stages running ahead of
+// each other -- is byte-identical and exactly as fast, 14.65 ms: what a tile loses against its busiest stage is not the lockstep.)
 __device__ __forceinline__ void k4_handoff(TileWriter *w, bool last) {
+  if (w->own_rows) k4_adapt_own_rows(w->cdf, w->out, (int)(w->n < w->cap ? w->n : w->cap), 2);
   WAVE_SYNC();
   if (LANE == 0) { w->nrec[w->chunk % 3] = w->n; if (last) *w->total = w->chunk + 1; }
   __syncthreads();
@@ -358,6 +423,68 @@ __device__ __forceinline__ void k4_segment_id(TileWriter *w, int own, int up, in
   k4_sym(w, seg_symbol(own >> 1, pred, w->seg_n), CDF_SEG_ID + ctx * CDF_SEG_ID_STRIDE, 8);
 }
 
+// One transform block's inputs, loaded ahead: while the wave turns block k into records, the loads of block k + 1 -- eob, type, coefficients, and the neighbours'
+// level / dc cells its all_zero and dc_sign contexts come from -- are in flight (everything K4 reads was left by K1: nothing here depends on the walk).  A lone wave
+// pays every dependent round trip to L2 / HBM in full: staged one after the other they were 39 % of the producer's time (profiles/r04_k4_phase_profile.txt).
+template <int BS> struct K4TxPre {
+  static constexpr int NC = BS <= 1 ? 1 : (BS == 2 ? 4 : 16);               // coefficients per lane: up to 8x8 / 16x16 / 32x32
+  int l_eob, l_txt, la, da, ll, dl; int32_t cv[NC];
+  int p, bi, rr, cc, txs;                                                   // which block (wave-uniform)
+};
+template <int BS> __device__ __forceinline__ void k4_tx_issue(const TileWriter *w, K4TxPre<BS> &o) {
+  const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, p = o.p, rr = o.rr, cc = o.cc, tmi = rr * ms + cc, k = LANE;
+  o.l_eob = f->m_eob[p][tmi]; o.l_txt = f->m_txtype[tmi];
+  {                                                                         // txb_ctx_dev's loads (dev_rate.h): a neighbour outside the tile / frame reads the block's own cell
+    const bool ha = rr - 1 >= t->mi_row_start && cc + k < w->mi_cols, hl = cc - 1 >= t->mi_col_start && rr + k < w->mi_rows;
+    const int ia = (k < 16 && ha) ? (rr - 1) * ms + cc + k : tmi, il = (k < 16 && hl) ? (rr + k) * ms + cc - 1 : tmi;   // (at most 16 cells: the 64x64 transform)
+    o.la = f->m_lvl[p][ia]; o.da = f->m_dc[p][ia]; o.ll = f->m_lvl[p][il]; o.dl = f->m_dc[p][il];
+  }
+  const int l2n = imin_(5, 2 + o.txs), n = 1 << l2n;
+  const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
+#pragma unroll
+  for (int q = 0; q < K4TxPre<BS>::NC; q++) { const int idx = LANE + 64 * q; o.cv[q] = idx < n * n ? src[(idx >> l2n) * f->stride + (idx & (n - 1))] : 0; }
+}
+// all_zero and dc_sign contexts (txb_ctx_dev) from the cells loaded ahead: two sums over the lanes that hold cells (8; 16 for the 64x64 transform of a 64x64
+// block) -- the counts of cells above / left that are non-zero, above 3, coded at all, each in its own 5-bit field, and the dc signs
+template <int BS> __device__ __forceinline__ void k4_txb_ctx(const TileWriter *w, const K4TxPre<BS> &o, int bs, int *skip_ctx, int *dc_ctx) {
+  const TileB *t = &w->t; const int k = LANE, w4 = 1 << o.txs;
+  const bool ha = k < w4 && o.rr - 1 >= t->mi_row_start && o.cc + k < w->mi_cols, hl = k < w4 && o.cc - 1 >= t->mi_col_start && o.rr + k < w->mi_rows;
+  int pk = 0, dcs = 0;
+  if (ha) { pk += (o.la != 0) + ((o.la > 3) << 5) + (((o.la | o.da) != 0) << 20); dcs += o.da == 1 ? -1 : (o.da == 2 ? 1 : 0); }
+  if (hl) { pk += ((o.ll != 0) << 10) + ((o.ll > 3) << 15) + (((o.ll | o.dl) != 0) << 25); dcs += o.dl == 1 ? -1 : (o.dl == 2 ? 1 : 0); }
+  pk += DPP_(0, pk, 0xB1, 0xF); pk += DPP_(0, pk, 0x4E, 0xF); pk += DPP_(0, pk, 0x141, 0xF);         // quad_perm, quad_perm, row_half_mirror: lanes 0 .. 7
+  dcs += DPP_(0, dcs, 0xB1, 0xF); dcs += DPP_(0, dcs, 0x4E, 0xF); dcs += DPP_(0, dcs, 0x141, 0xF);
+  if constexpr (BS >= 4) { pk += DPP_(0, pk, 0x140, 0xF); dcs += DPP_(0, dcs, 0x140, 0xF); }           // row_mirror: lanes 0 .. 15
+  pk = uni32(pk); dcs = uni32(dcs);
+  const int top0 = (pk & 31) == 0, left0 = ((pk >> 10) & 31) == 0, top3 = ((pk >> 5) & 31) != 0, left3 = ((pk >> 15) & 31) != 0;
+  *dc_ctx = dcs < 0 ? 1 : (dcs > 0 ? 2 : 0);
+  if (o.p == 0) {
+    int ctx;
+    if (bs == o.txs) ctx = 0;
+    else if (top0 && left0) ctx = 1;
+    else if (top0 || left0) ctx = 2 + (top3 || left3);
+    else if (!(top3 || left3)) ctx = 4;
+    else if (!(top3 && left3)) ctx = 5;
+    else ctx = 6;
+    *skip_ctx = ctx;
+  } else {
+    *skip_ctx = 7 + (((pk >> 20) & 31) != 0) + (((pk >> 25) & 31) != 0) + (bs > o.txs ? 3 : 0);
+  }
+}
+// the block's next transform block in coding order (per plane the transform blocks in raster order; those outside the frame are skipped); false: none left
+template <int BS> __device__ __forceinline__ bool k4_tx_next(const TileWriter *w, int r, int c, int txs_y, int p, int bi, K4TxPre<BS> &o) {
+  for (; p < w->np; p++, bi = 0) {
+    const int txs = p == 0 ? txs_y : (BS == BS_64 ? 3 : BS) /* chroma transforms stop at 32x32 (spec get_tx_size) */, step = 1 << txs, nblk = 1 << (BS - txs);
+    for (; bi < nblk * nblk; bi++) {
+      const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step;
+      if (rr >= w->mi_rows || cc >= w->mi_cols) continue;
+      o.p = p; o.bi = bi; o.rr = rr; o.cc = cc; o.txs = txs;
+      return true;
+    }
+  }
+  return false;
+}
+
 template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w, int r, int c) {
   k4_room(w);
   const FrameDev *f = w->f; const TileB *t = &w->t; const int ms = w->ms, mi = r * ms + c;
@@ -409,19 +536,22 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
   }
   K4PH(1); K4CNT(8, 1);
   if (skip) return;                                    // wave-uniform
-  // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not)
-  for (int p = 0; p < w->np; p++) {
-    const int txs = p == 0 ? txs_y : (BS == BS_64 ? 3 : BS) /* chroma transforms stop at 32x32 (spec get_tx_size) */, l2n = imin_(5, 2 + txs), n = 1 << l2n, step = 1 << txs, nblk = 1 << (BS - txs);
-    for (int bi = 0; bi < nblk * nblk; bi++) {
-      const int rr = r + (bi / nblk) * step, cc = c + (bi % nblk) * step, tmi = rr * ms + cc;
-      if (rr >= w->mi_rows || cc >= w->mi_cols) continue;
-      const int l_eob = f->m_eob[p][tmi], l_txt = f->m_txtype[tmi];      // issued with the coefficient loads below
-      const int32_t *src = f->coef[p] + (size_t)(rr * 4) * f->stride + cc * 4;
+  // residual(): per plane the transform blocks of the block in raster order (luma may be split one level, chroma is not), each one's loads a block ahead
+  K4TxPre<BS> cur;
+  if (!k4_tx_next<BS>(w, r, c, txs_y, 0, 0, cur)) return;
+  k4_tx_issue<BS>(w, cur);
+  for (;;) {
+    K4TxPre<BS> nxt;
+    const bool more = k4_tx_next<BS>(w, r, c, txs_y, cur.p, cur.bi + 1, nxt);
+    if (more) k4_tx_issue<BS>(w, nxt);
+    {
+      const int p = cur.p, txs = cur.txs, l2n = imin_(5, 2 + txs), n = 1 << l2n;
       WAVE_SYNC();
-      for (int idx = LANE; idx < n * n; idx += 64) w->qc[idx] = src[(idx >> l2n) * f->stride + (idx & (n - 1))];
+#pragma unroll
+      for (int q = 0; q < K4TxPre<BS>::NC; q++) { const int idx = LANE + 64 * q; if (idx < n * n) w->qc[idx] = cur.cv[q]; }
       WAVE_SYNC();
       build_level_map(w->qc, w->lev, n);
-      const int eob = U_(l_eob), v_txt = U_(l_txt);
+      const int eob = U_(cur.l_eob), v_txt = U_(cur.l_txt);
       int txtype, off = -1, sym = 0, ns = 0, set;
       if (p == 0) {
         txtype = v_txt;
@@ -433,10 +563,12 @@ template <int BS> __device__ __forceinline__ void write_block_dev(TileWriter *w,
         if (txtype_to_sym(set, txtype) < 0) txtype = DCT_DCT;
       }
       int sctx2, dctx;
-      txb_ctx_dev(f, t, p, rr, cc, txs, BS, &sctx2, &dctx);
+      k4_txb_ctx<BS>(w, cur, BS, &sctx2, &dctx);
       K4PH(2);
       code_coeffs_lane0(w, eob, p, txs, txtype, sctx2, dctx, off, sym, ns);
     }
+    if (!more) break;
+    cur = nxt;
   }
   WAVE_SYNC();
 }
@@ -611,6 +743,7 @@ template <int CS> struct EntropyLds {
   uint16_t rec_off[CS * CS], rec_br[CS * CS];
   uint32_t rec_lv[CS * CS];
   int lr_ref[6];
+  uint32_t acc[MI_K4_ACC];                  // the coder's ring of byte accumulators (RangeEncDev)
   uint32_t nrec[3];                        // records in the three rotating buffers
   int total;                               // buffers of the tile: -1 until the producer has handed on its last one
 };
@@ -652,7 +785,7 @@ __global__ __launch_bounds__(MI_K4_THREADS_OF(NA) MI_K4_LB_EXTRA) void tile_entr
     w.t.mi_row_start = row0; w.t.mi_row_end = row1; w.t.mi_col_start = col0; w.t.mi_col_end = col1;
     w.qc = (LDS int32_t *)L.qc; w.lev = (LDS uint8_t *)L.lev; w.cdef_pending = 1; w.ls = (LDS uint16_t *)L.scans;
     w.rec_off = (LDS uint16_t *)L.rec_off; w.rec_br = (LDS uint16_t *)L.rec_br; w.rec_lv = (LDS uint32_t *)L.rec_lv;
-    w.lr_ref = (LDS int *)L.lr_ref; w.cap = rec_cap; w.out = bufs; w.n = 0;
+    w.lr_ref = (LDS int *)L.lr_ref; w.cap = rec_cap; w.out = bufs; w.n = 0; w.cdf = (LDS uint16_t *)L.cdf; w.own_rows = NA == 2 && MI_K4_SPREAD;
     w.np = U_(f->np); w.mi_rows = U_(f->mi_rows); w.mi_cols = U_(f->mi_cols); w.ms = U_(f->mi_stride); w.tx_mode_select = U_(f->tx_mode_select);
     w.seg_n = U_(f->seg_n); w.enable_cdef = U_(f->enable_cdef); w.cdef_bits = U_(f->cdef_bits); w.enable_restoration = U_(f->enable_restoration); w.sb_cols = U_(f->sb_cols);
     w.fw = U_(f->w); w.fh = U_(f->h); w.txc.reduced_tx_set = U_(f->reduced_tx_set); w.txc.base_q_idx = U_(f->base_q_idx);
@@ -662,7 +795,10 @@ __global__ __launch_bounds__(MI_K4_THREADS_OF(NA) MI_K4_LB_EXTRA) void tile_entr
     for (int i = 0; i < 16; i++) w.prof[i] = 0;
     w.pt = clock64();
 #endif
-  } else if (wave == NA + 1) re_init_dev(&ec, precarry + (size_t)job * pre_cap, pre_cap);
+  } else if (wave == NA + 1) {
+    for (int i = LANE; i < MI_K4_ACC; i += 64) L.acc[i] = 0;
+    re_init_dev(&ec, precarry + (size_t)job * pre_cap, pre_cap, (LDS uint32_t *)L.acc);
+  }
   if (threadIdx.x == 0) L.total = -1;
   __syncthreads();
   int overflow = 0;
@@ -691,7 +827,15 @@ __global__ __launch_bounds__(MI_K4_THREADS_OF(NA) MI_K4_LB_EXTRA) void tile_entr
       if (wave <= NA) {
         if (t >= 1 && (total < 0 || t - 1 < total)) k4_adapt_sb<NA>((LDS uint16_t *)L.cdf, bufs + (size_t)((t - 1) % 3) * rec_cap, (int)imin_((int)L.nrec[(t - 1) % 3], (int)rec_cap), wave - 1);
       } else {
-        if (t >= 2 && (total < 0 || t - 2 < total)) { const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1; k4_code_sb(&ec, bufs + (size_t)((t - 2) % 3) * rec_cap, (int)imin_((int)n, (int)rec_cap)); }   // (k4_room keeps n below the capacity: a guard, not a path)
+        if (t >= 2 && (total < 0 || t - 2 < total)) {
+          const uint32_t n = L.nrec[(t - 2) % 3]; if (n > rec_cap) overflow = 1;   // (k4_room keeps n below the capacity: a guard, not a path)
+          uint32_t *const buf = bufs + (size_t)((t - 2) % 3) * rec_cap; const int nc = (int)imin_((int)n, (int)rec_cap);
+          if constexpr (NA == 2 && MI_K4_SPREAD) {                // the coder's own rows (owner 3): symbols -> bounds right before they are coded
+            k4_adapt_sb<NA>((LDS uint16_t *)L.cdf, buf, nc, 3);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); WAVE_SYNC();
+          }
+          k4_code_sb(&ec, buf, nc);
+        }
       }
 #if MI_PROFILE == 2
       busy += clock64() - t0_;

@@ -3,7 +3,7 @@
 (kernels and the non-inlined device functions they call).  Usage: tools/kernel_resources.py [extra hipcc flags] > profiles/rNN_kernel_resources.txt"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ['hipcc', '--offload-arch=gfx950', '-O2', '-mllvm', '-sink-insts-to-avoid-spills', '-mllvm', '-inline-threshold=1000', '-mllvm', '-disable-machine-licm', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-Wno-unused-variable', '-Rpass-analysis=kernel-resource-usage',
+cmd = ['hipcc', '--offload-arch=gfx950', '-O2', '-mllvm', '-sink-insts-to-avoid-spills', '-mllvm', '-inline-threshold=1000', '-mllvm', '-disable-machine-licm', '-mllvm', '-phi-node-folding-threshold=1', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-Wno-unused-variable', '-Rpass-analysis=kernel-resource-usage',
        '-o', '/tmp/libmi_resources_probe.so', os.path.join(root, 'cavif_rs_amd', 'csrc', 'mi_avif.hip'), '-lz'] + sys.argv[1:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
