@@ -89,6 +89,7 @@ inline unsigned long long emu_ballot64(bool p) {
 }
 #define MI_BALLOT64(p) emu_ballot64(p)
 #define MI_SMUL32(r, a, b) ((r) = (a) * (b))
+#define MI_BITSET0_64(m, j) ((m) &= ~(1ull << (j)))
 #define MI_SSEL_GE(r, a, b, x, y) ((r) = (a) >= (b) ? (x) : (y))
 #define MI_WRITELANE(v, s, lane) ((v) = ((int)(threadIdx.x & 63) == (lane)) ? (int)(s) : (v))     /* tile_entropy.h: v_writelane_b32 */
 #define MI_MAD24(r, x, c, acc) ((r) = __mul24((x), (c)) + (acc))     /* txfm_gen.hip.h: v_mad_i32_i24 */
