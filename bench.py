@@ -391,7 +391,7 @@ def main():
     ap.add_argument('--end-to-end', type=int, default=-1, metavar='N', help='PNG files -> .avif files through the cavif_mi command line on N synthetic PNGs (default: 256 at N=1 GPU -- BASELINE config 4 is a batch of 256 files --, 0 = skip)')
     ap.add_argument('--threads', type=int, default=0, help='ravif with_num_threads / cavif -j: T bounds the tile target (av1encoder.rs:665-668); 0 = unspecified (None): uncapped on a GPU')
     ap.add_argument('--no-threads-line', action='store_true', help='skip the secondary line at T = host cores (what `cavif -j0` would ask for on this box)')
-    ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search). Measured on resident inputs, 20 steps (profiles/r06s_pipeline_sweep.txt): 1 slot 495.5, 2 slots 482.6, 3 slots 483.3, 4 slots 497.9 ... 502.7 MPix/s; at the round's end (profiles/r06Y_pipeline_sweep.txt): 1 / 2 / 3 / 4 / 5 / 6 / 8 slots 537 / 519 / 525 / 533 ... 543 / 534 / 538 / 540 -- two or three slots interleave one search with the other slots\' filter / entropy kernels badly. The product stream path (mi_ravif_encode_stream, MI_STREAM_SLOTS_DEFAULT = 2) keeps two objects per image shape because on a 256-file job every further object costs 0.07 s of allocation, more than its overlap returns (profiles/r05zk_e2e_knobs.txt); its clock is the end_to_end line')
+    ap.add_argument('--pipeline', type=int, default=4, help='resident batch slots driven in rotation (one batch entropy-codes and filters while the others search). Measured on resident inputs, 20 steps (profiles/r06s_pipeline_sweep.txt): 1 slot 495.5, 2 slots 482.6, 3 slots 483.3, 4 slots 497.9 ... 502.7 MPix/s; at the end of the round (profiles/r06Y_pipeline_sweep.txt): 1 / 2 / 3 / 4 / 5 / 6 / 8 slots 537 / 519 / 525 / 533 ... 543 / 534 / 538 / 540 -- two or three slots interleave one search with the other slots\' filter / entropy kernels badly. The product stream path (mi_ravif_encode_stream, MI_STREAM_SLOTS_DEFAULT = 2) keeps two objects per image shape because on a 256-file job every further object costs 0.07 s of allocation, more than its overlap returns (profiles/r05zk_e2e_knobs.txt); its clock is the end_to_end line')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
